@@ -1,0 +1,138 @@
+"""ctypes front-end of the CPU oracle (oracle/ckks_oracle.c).
+
+TEST INFRASTRUCTURE ONLY — see the header of ckks_oracle.c.  Only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import this module; the product package never does.
+
+All functions take C-contiguous numpy arrays (int64 data / constants, int32 index tables) and
+mutate `a` in place exactly where the reference op does.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "ckks_oracle.c")
+_LIB = os.path.join(_HERE, "_build", "libckks_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
+        os.makedirs(os.path.dirname(_LIB), exist_ok=True)
+        subprocess.check_call(
+            ["gcc", "-O2", "-fwrapv", "-fopenmp", "-shared", "-fPIC", "-o", _LIB, _SRC])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+        i64 = ctypes.c_int64
+        _lib.lfo_mm_scalar.restype = i64
+        _lib.lfo_mm_scalar.argtypes = [i64] * 6
+        _lib.lfo_redc_scalar.restype = i64
+        _lib.lfo_redc_scalar.argtypes = [i64] * 5
+    return _lib
+
+
+def _p(x: np.ndarray):
+    assert x.flags["C_CONTIGUOUS"], "oracle arrays must be C-contiguous"
+    return ctypes.c_void_p(x.ctypes.data)
+
+
+def _i64(x):
+    assert x.dtype == np.int64, x.dtype
+    return _p(x)
+
+
+def _i32(x):
+    assert x.dtype == np.int32, x.dtype
+    return _p(x)
+
+
+def _N(a):
+    return ctypes.c_int64(a.shape[-1])
+
+
+def mm_scalar(a, b, ql, qh, kl, kh) -> int:
+    return int(lib().lfo_mm_scalar(a, b, ql, qh, kl, kh))
+
+
+def redc_scalar(x, ql, qh, kl, kh) -> int:
+    return int(lib().lfo_redc_scalar(x, ql, qh, kl, kh))
+
+
+def mont_mult(a, b, c, rows, ql, qh, kl, kh):
+    lib().lfo_mont_mult(_i64(a), _i64(b), _i64(c), int(rows), _N(a), _i64(ql), _i64(qh), _i64(kl), _i64(kh))
+
+
+def mont_enter(a, Rs, rows, ql, qh, kl, kh):
+    lib().lfo_mont_enter(_i64(a), _i64(Rs), int(rows), _N(a), _i64(ql), _i64(qh), _i64(kl), _i64(kh))
+
+
+def mont_redc(a, rows, ql, qh, kl, kh):
+    lib().lfo_mont_redc(_i64(a), int(rows), _N(a), _i64(ql), _i64(qh), _i64(kl), _i64(kh))
+
+
+def ntt_tab(a, even, odd, psi, rows, _2q, ql, qh, kl, kh):
+    logN = even.shape[0]
+    lib().lfo_ntt_tab(_i64(a), _i32(even), _i32(odd), _i64(psi), int(rows), int(logN), _N(a),
+                      _i64(_2q), _i64(ql), _i64(qh), _i64(kl), _i64(kh))
+
+
+def enter_ntt_tab(a, Rs, even, odd, psi, rows, _2q, ql, qh, kl, kh):
+    logN = even.shape[0]
+    lib().lfo_enter_ntt_tab(_i64(a), _i64(Rs), _i32(even), _i32(odd), _i64(psi), int(rows), int(logN), _N(a),
+                            _i64(_2q), _i64(ql), _i64(qh), _i64(kl), _i64(kh))
+
+
+def intt_tab(a, even, odd, psi, Ninv, rows, _2q, ql, qh, kl, kh):
+    logN = even.shape[0]
+    lib().lfo_intt_tab(_i64(a), _i32(even), _i32(odd), _i64(psi), _i64(Ninv), int(rows), int(logN), _N(a),
+                       _i64(_2q), _i64(ql), _i64(qh), _i64(kl), _i64(kh))
+
+
+def ntt(a, psi_br, rows, logN, _2q, ql, qh, kl, kh):
+    assert a.shape[-1] == (1 << logN) and psi_br.shape[-1] == (1 << logN)
+    lib().lfo_ntt(_i64(a), _i64(psi_br), int(rows), int(logN), _i64(_2q), _i64(ql), _i64(qh), _i64(kl), _i64(kh))
+
+
+def intt(a, ipsi_br, Ninv, rows, logN, _2q, ql, qh, kl, kh):
+    assert a.shape[-1] == (1 << logN) and ipsi_br.shape[-1] == (1 << logN)
+    lib().lfo_intt(_i64(a), _i64(ipsi_br), _i64(Ninv), int(rows), int(logN),
+                   _i64(_2q), _i64(ql), _i64(qh), _i64(kl), _i64(kh))
+
+
+def reduce_2q(a, rows, _2q):
+    lib().lfo_reduce_2q(_i64(a), int(rows), _N(a), _i64(_2q))
+
+
+def make_signed(a, rows, _2q):
+    lib().lfo_make_signed(_i64(a), int(rows), _N(a), _i64(_2q))
+
+
+def make_unsigned(a, rows, _2q):
+    lib().lfo_make_unsigned(_i64(a), int(rows), _N(a), _i64(_2q))
+
+
+def tile_unsigned(a, dst, rows, _2q):
+    lib().lfo_tile_unsigned(_i64(a), _i64(dst), int(rows), _N(dst), _i64(_2q))
+
+
+def mont_add(a, b, c, rows, _2q):
+    lib().lfo_mont_add(_i64(a), _i64(b), _i64(c), int(rows), _N(a), _i64(_2q))
+
+
+def mont_sub(a, b, c, rows, _2q):
+    lib().lfo_mont_sub(_i64(a), _i64(b), _i64(c), int(rows), _N(a), _i64(_2q))
+
+
+def galois(a, dst, rows, p):
+    lib().lfo_galois(_i64(a), _i64(dst), int(rows), _N(a), ctypes.c_int64(p))

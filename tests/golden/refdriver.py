@@ -1,0 +1,274 @@
+"""Import the reference's Python layers in the BUILD container and drive them on CPU.
+
+Only used by tests/golden/make_golden.py (fixture generation) and by tests that are skipped when
+/root/reference is absent (it never exists on the GPU box).  The reference's five CUDA extension
+modules cannot be built here; this module registers stand-ins for them:
+
+  * liberate.ntt.ntt_cuda                -> the C oracle (oracle/ckks_oracle.c) behind the
+                                            reference's exact 15-function list-of-tensors signature
+  * liberate.csprng.*_cuda               -> NumPy samplers (deterministic, seeded) — the reference's
+                                            CSPRNG is unseedable, so fixtures inject their own randomness
+
+plus the small environment shims listed in SURVEY.md §8(c): np.bool8 alias, a writable copy of the
+shipped prime pickles, no-op pin_memory, Tensor.cuda -> clone, and a CPU-safe `decode`.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+REFERENCE_SRC = "/root/reference/src"
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_SRC, "liberate"))
+
+
+def _oracle():
+    if REPO not in sys.path:
+        sys.path.insert(0, REPO)
+    from oracle import oracle as orc
+    return orc
+
+
+def _make_ntt_cuda_standin():
+    """`ntt_cuda` stand-in: reference signatures (ntt.cpp:8-113, 421-437), oracle arithmetic."""
+    orc = _oracle()
+    m = types.ModuleType("liberate.ntt.ntt_cuda")
+
+    def npv(t):
+        assert t.dtype in (torch.int64, torch.int32) and t.is_contiguous(), (t.dtype, t.is_contiguous())
+        return t.numpy()
+
+    def mont_mult(a, b, ql, qh, kl, kh):
+        out = []
+        for ai, bi, l, h, kl_, kh_ in zip(a, b, ql, qh, kl, kh):
+            c = torch.empty_like(ai)
+            rows = ai.size(0)
+            bb = bi if bi.is_contiguous() else bi.contiguous()
+            orc.mont_mult(npv(ai.contiguous()), npv(bb), npv(c), rows, npv(l), npv(h), npv(kl_), npv(kh_))
+            out.append(c)
+        return out
+
+    def _inplace(ai):
+        # the reference mutates views in place; numpy() of a contiguous view aliases the storage
+        if ai.is_contiguous():
+            return ai, None
+        tmp = ai.contiguous()
+        return tmp, ai
+
+    def mont_enter(a, Rs, ql, qh, kl, kh):
+        for ai, r, l, h, kl_, kh_ in zip(a, Rs, ql, qh, kl, kh):
+            w, back = _inplace(ai)
+            orc.mont_enter(npv(w), npv(r.contiguous()), w.size(0), npv(l), npv(h), npv(kl_), npv(kh_))
+            if back is not None:
+                back.copy_(w)
+
+    def ntt(a, even, odd, psi, _2q, ql, qh, kl, kh):
+        for ai, e, o, p, q2, l, h, kl_, kh_ in zip(a, even, odd, psi, _2q, ql, qh, kl, kh):
+            w, back = _inplace(ai)
+            orc.ntt_tab(npv(w), npv(e), npv(o), npv(p.contiguous()), l.size(0), npv(q2), npv(l), npv(h), npv(kl_), npv(kh_))
+            if back is not None:
+                back.copy_(w)
+
+    def enter_ntt(a, Rs, even, odd, psi, _2q, ql, qh, kl, kh):
+        for ai, r, e, o, p, q2, l, h, kl_, kh_ in zip(a, Rs, even, odd, psi, _2q, ql, qh, kl, kh):
+            w, back = _inplace(ai)
+            orc.enter_ntt_tab(npv(w), npv(r.contiguous()), npv(e), npv(o), npv(p.contiguous()), l.size(0),
+                              npv(q2), npv(l), npv(h), npv(kl_), npv(kh_))
+            if back is not None:
+                back.copy_(w)
+
+    def _intt_chain(a, even, odd, psi, Ninv, _2q, ql, qh, kl, kh, redc, reduce, signed):
+        for ai, e, o, p, ni, q2, l, h, kl_, kh_ in zip(a, even, odd, psi, Ninv, _2q, ql, qh, kl, kh):
+            w, back = _inplace(ai)
+            rows = l.size(0)
+            orc.intt_tab(npv(w), npv(e), npv(o), npv(p.contiguous()), npv(ni.contiguous()), rows,
+                         npv(q2), npv(l), npv(h), npv(kl_), npv(kh_))
+            # chains (K.cu:709-973) run their elementwise tails over the first `rows` rows
+            view = npv(w)[:rows]
+            if redc:
+                orc.mont_redc(view, rows, npv(l), npv(h), npv(kl_), npv(kh_))
+            if reduce:
+                orc.reduce_2q(view, rows, npv(q2))
+            if signed:
+                orc.make_signed(view, rows, npv(q2))
+            if back is not None:
+                back.copy_(w)
+
+    def intt(a, *args):
+        _intt_chain(a, *args, redc=False, reduce=False, signed=False)
+
+    def intt_exit(a, *args):
+        _intt_chain(a, *args, redc=True, reduce=False, signed=False)
+
+    def intt_exit_reduce(a, *args):
+        _intt_chain(a, *args, redc=True, reduce=True, signed=False)
+
+    def intt_exit_reduce_signed(a, *args):
+        _intt_chain(a, *args, redc=True, reduce=True, signed=True)
+
+    def mont_redc(a, ql, qh, kl, kh):
+        for ai, l, h, kl_, kh_ in zip(a, ql, qh, kl, kh):
+            w, back = _inplace(ai)
+            orc.mont_redc(npv(w), w.size(0), npv(l), npv(h), npv(kl_), npv(kh_))
+            if back is not None:
+                back.copy_(w)
+
+    def _fix(fn):
+        def op(a, _2q):
+            for ai, q2 in zip(a, _2q):
+                w, back = _inplace(ai)
+                fn(npv(w), w.size(0), npv(q2.contiguous()))
+                if back is not None:
+                    back.copy_(w)
+        return op
+
+    def _bin(fn):
+        def op(a, b, _2q):
+            out = []
+            for ai, bi, q2 in zip(a, b, _2q):
+                c = torch.empty_like(ai, memory_format=torch.contiguous_format)
+                fn(npv(ai.contiguous()), npv(bi.contiguous()), npv(c), ai.size(0), npv(q2.contiguous()))
+                out.append(c)
+            return out
+        return op
+
+    def tile_unsigned(a, _2q):
+        out = []
+        for ai, q2 in zip(a, _2q):
+            ai.squeeze_()
+            c = ai.new_empty((q2.size(0), ai.size(0)))
+            orc.tile_unsigned(npv(ai.contiguous()), npv(c), q2.size(0), npv(q2.contiguous()))
+            out.append(c)
+        return out
+
+    m.mont_mult, m.mont_enter, m.ntt, m.enter_ntt = mont_mult, mont_enter, ntt, enter_ntt
+    m.intt, m.intt_exit, m.intt_exit_reduce, m.intt_exit_reduce_signed = intt, intt_exit, intt_exit_reduce, intt_exit_reduce_signed
+    m.mont_redc = mont_redc
+    m.reduce_2q, m.make_signed, m.make_unsigned = _fix(orc.reduce_2q), _fix(orc.make_signed), _fix(orc.make_unsigned)
+    m.mont_add, m.mont_sub = _bin(orc.mont_add), _bin(orc.mont_sub)
+    m.tile_unsigned = tile_unsigned
+    return m
+
+
+class SeededCsprng:
+    """Deterministic replacement for the reference's Csprng (csprng.py:18-323): same method names,
+    shapes and value ranges; randomness from numpy's PCG64 so fixtures are reproducible."""
+
+    def __init__(self, N, C, repeats, devices=None, seed=12345):
+        self.N, self.C, self.num_repeating_channels = N, list(C), repeats
+        self.devices = devices or ["cpu"]
+        self.num_devices = len(self.devices)
+        self.g = np.random.Generator(np.random.PCG64(seed))
+
+    def _t(self, x):
+        return torch.from_numpy(np.ascontiguousarray(x).astype(np.int64))
+
+    def randint(self, amax=3, shift=0, repeats=1):
+        # amax scalar -> [repeats, N] shared by every device; amax per-device list of per-row moduli
+        # -> [C_dev + repeats, N] with the trailing `repeats` rows identical on every device.
+        if not isinstance(amax, (list, tuple)):
+            x = self.g.integers(0, amax, size=(max(repeats, 1), self.N)) + shift
+            return [self._t(x).clone() for _ in range(self.num_devices)]
+        out = []
+        rep_rows = None
+        for dev, q in enumerate(amax):
+            q = list(q)
+            n_rep = repeats
+            body = q[: len(q) - n_rep] if n_rep else q
+            rows = [self.g.integers(0, qi, size=self.N) + shift for qi in body]
+            if n_rep:
+                if rep_rows is None:
+                    rep_rows = [self.g.integers(0, qi, size=self.N) + shift for qi in q[len(q) - n_rep:]]
+                rows += rep_rows
+            out.append(self._t(np.stack(rows)))
+        return out
+
+    def discrete_gaussian(self, non_repeats=0, repeats=1, sigma=3.2):
+        x = np.rint(self.g.normal(0.0, 3.2, size=(max(repeats, 1), self.N)))
+        return [self._t(x).clone() for _ in range(self.num_devices)]
+
+    def randround(self, coef):
+        c = coef.numpy() if isinstance(coef, torch.Tensor) else np.asarray(coef)
+        fl = np.floor(c)
+        r = fl + (self.g.random(c.shape) < (c - fl))
+        return torch.from_numpy(r.astype(np.int64))
+
+
+_state = {}
+
+
+def load_reference(seed=12345):
+    """Returns the reference's `liberate.fhe` module with the stand-ins installed."""
+    if "fhe" in _state:
+        return _state["fhe"]
+    if not reference_available():
+        raise RuntimeError("reference not present")
+    if not hasattr(np, "bool8"):
+        np.bool8 = np.bool_
+    sys.path.insert(0, REFERENCE_SRC)
+    sys.modules["liberate.ntt.ntt_cuda"] = _make_ntt_cuda_standin()
+    for name in ("chacha20_cuda", "randint_cuda", "randround_cuda", "discrete_gaussian_cuda"):
+        sys.modules["liberate.csprng." + name] = types.ModuleType("liberate.csprng." + name)
+    import liberate.csprng.csprng as csprng_mod  # noqa: E402
+    import liberate.csprng as csprng_pkg  # noqa: E402
+    csprng_mod.Csprng = SeededCsprng
+    csprng_pkg.Csprng = SeededCsprng
+    from liberate import fhe  # noqa: E402
+    # `liberate.fhe.ckks_engine` the attribute is the CLASS (fhe/__init__ re-exports it); the module
+    # object has to come from sys.modules.
+    eng_mod = sys.modules["liberate.fhe.ckks_engine"]
+    eng_mod.Csprng = SeededCsprng
+
+    # CPU plumbing
+    torch.Tensor.pin_memory = lambda self, *a, **k: self
+    torch.Tensor.cuda = lambda self, *a, **k: self.clone()
+
+    encdec_mod = sys.modules["liberate.fhe.encdec.encdec"]
+    orig_decode = encdec_mod.decode
+
+    def decode_cpu(m, scale=2 ** 40, correction=1.0, norm="forward", return_without_scaling=False):
+        N = len(m)
+        device = "cpu"
+        if (N, device) not in encdec_mod.perm_cache:
+            encdec_mod.perm_cache[(N, device)] = encdec_mod.prepost_perms(N, device=device)
+        pre_perm, post_perm = encdec_mod.perm_cache[(N, device)]
+        if (N, device) not in encdec_mod.skewer_cache:
+            encdec_mod.skewer_cache[N, device] = encdec_mod.generate_skewer(N, device)
+        skewer = encdec_mod.skewer_cache[N, device]
+        mm = encdec_mod.poly2m(m, skewer, norm=norm)
+        if not return_without_scaling:
+            mm = mm / scale * correction
+        return encdec_mod.post_permute(mm, post_perm)
+
+    encdec_mod.decode = decode_cpu
+    eng_mod.decode = decode_cpu
+
+    cache = tempfile.mkdtemp(prefix="lfa_refcache_")
+    res = os.path.join(REFERENCE_SRC, "liberate/fhe/cache/resources")
+    for f in os.listdir(res):
+        shutil.copy(os.path.join(res, f), cache)
+    _state.update(fhe=fhe, cache=cache, eng_mod=eng_mod)
+    return fhe
+
+
+def reference_engine(n_devices=1, **params):
+    fhe = load_reference()
+    params = dict(params)
+    params.pop("devices", None)
+    return fhe.ckks_engine(devices=["cpu"] * n_devices, cache_folder=_state["cache"],
+                           read_cache=False, save_cache=False, **params)
+
+
+def reference_context(**params):
+    load_reference()
+    from liberate.fhe.context.ckks_context import ckks_context
+    return ckks_context(cache_folder=_state["cache"], read_cache=False, save_cache=False, **params)
