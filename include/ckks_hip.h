@@ -1,0 +1,100 @@
+/*
+ * ckks_hip.h — C ABI of libckks_hip.so, the MI355X (gfx950) RNS-CKKS arithmetic library.
+ *
+ * This is the drop-in boundary for the reference's pybind11 module `liberate.ntt.ntt_cuda`
+ * (reference: src/liberate/ntt/ntt.cpp:421-437 exports 15 functions over std::vector<torch::Tensor>,
+ * one tensor per GPU).  Each entry point below replaces ONE of those functions for ONE device: the
+ * per-GPU loop of ntt.cpp:130-141 lives in the caller (one process per GPU, or the Python shim
+ * liberate_fhe_amd/ntt/ntt_cuda.py which walks the tensor lists).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers on `device`; data and constants are int64 (the reference's
+ *     62-bit word mode, Montgomery radix R = 2^62, values lazily in [0, 2q));
+ *   - polynomials are row-major [rows][N], one RNS limb per row, row pitch = N words;
+ *   - per-row constant vectors are indexed by row id exactly as the reference kernels do
+ *     (K.cu = src/liberate/ntt/ntt_cuda_kernel.cu): ql/qh = q & (2^31-1), q >> 31; kl/kh likewise
+ *     for k = -q^-1 mod 2^62; _2q = 2q;
+ *   - the reference's implicit extent rules are explicit arguments: elementwise ops run over
+ *     `rows` = a.size(0) (K.cu:110-114), NTT-family ops over `rows` = ql.size(0) (K.cu:298);
+ *   - twiddles are the compact table psi_br[rows][N] (entry x = Montgomery form of psi^brev(x)),
+ *     not the reference's [rows][logN][N/2] per-stage table; the butterfly DAG and per-butterfly
+ *     formulas are the reference's, so every lazy output word is bit-identical;
+ *   - `stream` is a hipStream_t (0 = the null stream); launches are asynchronous, nothing syncs;
+ *   - return value: 0 on success, otherwise the hipError_t of the failed call/launch, or
+ *     LF_ERR_ARG for an invalid argument.  (The reference returns nothing and checks nothing.)
+ */
+#ifndef CKKS_HIP_H
+#define CKKS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LF_ERR_ARG 10001
+
+/* Library / device probe: returns the ABI version (currently 1). */
+int lf_abi_version(void);
+
+/* ---- elementwise family --------------------------------------------------------------------- */
+
+/* ntt_cuda.mont_mult (ntt.cpp:120-144, K.cu:66-146): c[i][j] = REDC62(a[i][j] * b[i][j]). */
+int lf_mont_mult(const int64_t *a, const int64_t *b, int64_t *c, int rows, int64_t N,
+                 const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
+                 int device, void *stream);
+
+/* ntt_cuda.mont_enter (ntt.cpp:146-163, K.cu:154-226): a[i][j] = REDC62(a[i][j] * Rs[i]) in place. */
+int lf_mont_enter(int64_t *a, const int64_t *Rs, int rows, int64_t N,
+                  const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
+                  int device, void *stream);
+
+/* ntt_cuda.mont_redc (ntt.cpp:248-263, K.cu:559-653): a = (a + ((a*k) mod R) * q) / R in place. */
+int lf_mont_redc(int64_t *a, int rows, int64_t N,
+                 const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
+                 int device, void *stream);
+
+/* ntt_cuda.reduce_2q (K.cu:664-680, 1187-1191): a = a < q ? a : a - q, q = _2q >> 1. */
+int lf_reduce_2q(int64_t *a, int rows, int64_t N, const int64_t *_2q, int device, void *stream);
+/* ntt_cuda.make_signed (K.cu:682-699): a = a <= q/2 ? a : a - q. */
+int lf_make_signed(int64_t *a, int rows, int64_t N, const int64_t *_2q, int device, void *stream);
+/* ntt_cuda.make_unsigned (K.cu:980-995): a += q. */
+int lf_make_unsigned(int64_t *a, int rows, int64_t N, const int64_t *_2q, int device, void *stream);
+/* ntt_cuda.tile_unsigned (K.cu:997-1014, 1205-1214): dst[i][j] = a[j] + q_i, rows = _2q.size(0). */
+int lf_tile_unsigned(const int64_t *a, int64_t *dst, int rows, int64_t N, const int64_t *_2q,
+                     int device, void *stream);
+/* ntt_cuda.mont_add / mont_sub (K.cu:1016-1058): c = (a +/- b) csub 2q. */
+int lf_mont_add(const int64_t *a, const int64_t *b, int64_t *c, int rows, int64_t N, const int64_t *_2q,
+                int device, void *stream);
+int lf_mont_sub(const int64_t *a, const int64_t *b, int64_t *c, int rows, int64_t N, const int64_t *_2q,
+                int device, void *stream);
+
+/* ---- NTT family -------------------------------------------------------------------------------
+ * `batch` polynomials of `rows` limbs each, stored back to back ([batch][rows][N]); limb i of every
+ * polynomial uses constant/twiddle row i.  The reference API is batch = 1. */
+
+/* ntt_cuda.ntt (ntt.cpp:166-188, K.cu:236-342): forward negacyclic NTT, natural in -> bit-reversed out.
+ * ntt_cuda.enter_ntt (ntt.cpp:191-216, K.cu:349-423) when Rs != NULL: mont_enter(Rs) first. */
+int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, const int64_t *Rs,
+           const int64_t *_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
+           int device, void *stream);
+
+/* ntt_cuda.intt / intt_exit / intt_exit_reduce / intt_exit_reduce_signed
+ * (ntt.cpp:219-345, K.cu:433-548, 709-973): inverse NTT, bit-reversed in -> natural out, then
+ * x Ninv (= N^-1 * R mod q); `tail` selects the fused chain:
+ *   0 intt, 1 + mont_redc, 2 + reduce (canonical [0,q)), 3 + make_signed. */
+int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, const int64_t *Ninv, int tail,
+            const int64_t *_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
+            int device, void *stream);
+
+/* Galois automorphism of coefficient-domain rows (reference: encdec.py:224-270 `rotate`/`conjugate`,
+ * done there with torch advanced indexing): dst[i][(p*n mod 2N) mod N] = +/- a[i][n], sign - iff
+ * (p*n mod 2N) >= N.  If _2q != NULL the reference's follow-up make_unsigned + reduce_2q
+ * (ckks_engine.py:1198-1200) is fused: the stored value is canonical in [0, q). */
+int lf_galois(const int64_t *a, int64_t *dst, int rows, int logN, int64_t p, const int64_t *_2q,
+              int device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,58 @@
+"""ctypes binding of libckks_hip.so (C ABI declared in include/ckks_hip.h).
+
+There is NO fallback: if the HIP library has not been built (python -c "import __graft_entry__ as g;
+g.build()" or `make -C liberate_fhe_amd/csrc`), importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libckks_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: the HIP extension has not been built. "
+        "Run `python -c 'import __graft_entry__ as g; g.build()'` at the repo root "
+        "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path."
+    )
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_int64
+
+_SIGNATURES = {
+    "lf_abi_version": [],
+    "lf_mont_mult": [_P, _P, _P, _I, _L, _P, _P, _P, _P, _I, _P],
+    "lf_mont_enter": [_P, _P, _I, _L, _P, _P, _P, _P, _I, _P],
+    "lf_mont_redc": [_P, _I, _L, _P, _P, _P, _P, _I, _P],
+    "lf_reduce_2q": [_P, _I, _L, _P, _I, _P],
+    "lf_make_signed": [_P, _I, _L, _P, _I, _P],
+    "lf_make_unsigned": [_P, _I, _L, _P, _I, _P],
+    "lf_tile_unsigned": [_P, _P, _I, _L, _P, _I, _P],
+    "lf_mont_add": [_P, _P, _P, _I, _L, _P, _I, _P],
+    "lf_mont_sub": [_P, _P, _P, _I, _L, _P, _I, _P],
+    "lf_ntt": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lf_intt": [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P],
+    "lf_galois": [_P, _P, _I, _I, _L, _P, _I, _P],
+}
+
+for _name, _args in _SIGNATURES.items():
+    _fn = getattr(lib, _name)
+    _fn.argtypes = _args
+    _fn.restype = ctypes.c_int
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise HipError(f"{what} failed with status {code}")
+
+
+EXPORTED = tuple(_SIGNATURES)

@@ -1,0 +1,209 @@
+"""`ntt_cuda`: the reference's 15-function extension module, served by libckks_hip.so.
+
+Same names, argument order and mutation/allocation behaviour as the pybind11 module the reference
+builds from src/liberate/ntt/ntt.cpp:421-437 — every tensor argument is a list with one entry per
+participating GPU — so orchestration code written against the reference runs unchanged.  Each call
+walks the lists and issues one C-ABI call per device on that device's current torch stream
+(reference: ntt.cpp:130-141, K.cu:103-107).  Outputs of mont_mult / mont_add / mont_sub /
+tile_unsigned are allocated here with torch (K.cu:138, 1209, 1217, 1225) so ownership stays with
+torch's caching allocator.
+
+Twiddles: the reference passes `even, odd, psi` = per-stage gather indices and a [rows, logN, N/2]
+table.  The HIP kernels index a compact [rows, N] table.  `psi` may therefore be either
+  * a 2-D compact table (what liberate_fhe_amd's own ntt_context passes; even/odd may be None), or
+  * the reference's 3-D table, from which the compact table is extracted once and cached
+    (entry m+i of stage s is column i*t of that stage, t = N/2m forward, t = 2^s inverse).
+"""
+from __future__ import annotations
+
+import torch
+
+from .._native import lib, check
+
+__all__ = [
+    "mont_mult", "mont_enter", "ntt", "enter_ntt", "intt", "mont_redc", "intt_exit", "intt_exit_reduce",
+    "intt_exit_reduce_signed", "reduce_2q", "make_signed", "make_unsigned", "mont_add", "mont_sub",
+    "tile_unsigned",
+]
+
+
+def _dev_stream(t: torch.Tensor):
+    if t.device.type != "cuda":
+        raise RuntimeError(
+            f"ntt_cuda: tensor on {t.device}; the HIP kernels need device memory (no CPU fallback)")
+    idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    return idx, torch.cuda.current_stream(idx).cuda_stream
+
+
+def _ptr(t: torch.Tensor):
+    if t.dtype != torch.int64:
+        raise TypeError(f"ntt_cuda: int64 tensors only (62-bit word mode), got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("ntt_cuda: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _inplace(t: torch.Tensor):
+    """Row-sliced views are contiguous and updated in place; anything else round-trips through a copy."""
+    if t.is_contiguous():
+        return t, None
+    return t.contiguous(), t
+
+
+_compact_cache = {}
+
+
+def _compact(psi: torch.Tensor, inverse: bool) -> torch.Tensor:
+    if psi.dim() == 2:
+        return psi
+    key = (psi.data_ptr(), tuple(psi.shape), psi._version, inverse, psi.device)
+    hit = _compact_cache.get(key)
+    if hit is not None:
+        return hit
+    rows, logN, half = psi.shape
+    N = 2 * half
+    out = torch.zeros((rows, N), dtype=psi.dtype, device=psi.device)
+    for s in range(logN):
+        t = (1 << s) if inverse else (N >> (s + 1))
+        m = (N >> (s + 1)) if inverse else (1 << s)
+        out[:, m:2 * m] = psi[:, s, ::t]
+    if len(_compact_cache) > 256:
+        _compact_cache.clear()
+    _compact_cache[key] = out
+    return out
+
+
+def mont_mult(a, b, ql, qh, kl, kh):
+    out = []
+    for ai, bi, l, h, kl_, kh_ in zip(a, b, ql, qh, kl, kh):
+        dev, st = _dev_stream(ai)
+        ai_c = ai.contiguous()
+        bi_c = bi.contiguous()
+        c = torch.empty_like(ai_c)
+        check(lib.lf_mont_mult(_ptr(ai_c), _ptr(bi_c), _ptr(c), ai_c.size(0), ai_c.size(-1),
+                               _ptr(l), _ptr(h), _ptr(kl_), _ptr(kh_), dev, st), "mont_mult")
+        out.append(c)
+    return out
+
+
+def mont_enter(a, Rs, ql, qh, kl, kh):
+    for ai, r, l, h, kl_, kh_ in zip(a, Rs, ql, qh, kl, kh):
+        dev, st = _dev_stream(ai)
+        w, back = _inplace(ai)
+        check(lib.lf_mont_enter(_ptr(w), _ptr(r.contiguous()), w.size(0), w.size(-1),
+                                _ptr(l), _ptr(h), _ptr(kl_), _ptr(kh_), dev, st), "mont_enter")
+        if back is not None:
+            back.copy_(w)
+
+
+def mont_redc(a, ql, qh, kl, kh):
+    for ai, l, h, kl_, kh_ in zip(a, ql, qh, kl, kh):
+        dev, st = _dev_stream(ai)
+        w, back = _inplace(ai)
+        check(lib.lf_mont_redc(_ptr(w), w.size(0), w.size(-1), _ptr(l), _ptr(h), _ptr(kl_), _ptr(kh_), dev, st),
+              "mont_redc")
+        if back is not None:
+            back.copy_(w)
+
+
+def _logN(ai):
+    N = ai.size(-1)
+    if N & (N - 1):
+        raise ValueError("ntt_cuda: polynomial length must be a power of two")
+    return N.bit_length() - 1
+
+
+def _forward(a, Rs, psi, _2q, ql, qh, kl, kh, what):
+    for i, ai in enumerate(a):
+        dev, st = _dev_stream(ai)
+        w, back = _inplace(ai)
+        table = _compact(psi[i], inverse=False)
+        rs = 0 if Rs is None else _ptr(Rs[i].contiguous())
+        # extent = ql.size(0) rows (K.cu:298, 371)
+        check(lib.lf_ntt(_ptr(w), 1, ql[i].size(0), _logN(w), _ptr(table), rs, _ptr(_2q[i]),
+                         _ptr(ql[i]), _ptr(qh[i]), _ptr(kl[i]), _ptr(kh[i]), dev, st), what)
+        if back is not None:
+            back.copy_(w)
+
+
+def ntt(a, even, odd, psi, _2q, ql, qh, kl, kh):
+    _forward(a, None, psi, _2q, ql, qh, kl, kh, "ntt")
+
+
+def enter_ntt(a, Rs, even, odd, psi, _2q, ql, qh, kl, kh):
+    _forward(a, Rs, psi, _2q, ql, qh, kl, kh, "enter_ntt")
+
+
+def _inverse(a, psi, Ninv, _2q, ql, qh, kl, kh, tail, what):
+    for i, ai in enumerate(a):
+        dev, st = _dev_stream(ai)
+        w, back = _inplace(ai)
+        table = _compact(psi[i], inverse=True)
+        check(lib.lf_intt(_ptr(w), 1, ql[i].size(0), _logN(w), _ptr(table), _ptr(Ninv[i].contiguous()), tail,
+                          _ptr(_2q[i]), _ptr(ql[i]), _ptr(qh[i]), _ptr(kl[i]), _ptr(kh[i]), dev, st), what)
+        if back is not None:
+            back.copy_(w)
+
+
+def intt(a, even, odd, psi, Ninv, _2q, ql, qh, kl, kh):
+    _inverse(a, psi, Ninv, _2q, ql, qh, kl, kh, 0, "intt")
+
+
+def intt_exit(a, even, odd, psi, Ninv, _2q, ql, qh, kl, kh):
+    _inverse(a, psi, Ninv, _2q, ql, qh, kl, kh, 1, "intt_exit")
+
+
+def intt_exit_reduce(a, even, odd, psi, Ninv, _2q, ql, qh, kl, kh):
+    _inverse(a, psi, Ninv, _2q, ql, qh, kl, kh, 2, "intt_exit_reduce")
+
+
+def intt_exit_reduce_signed(a, even, odd, psi, Ninv, _2q, ql, qh, kl, kh):
+    _inverse(a, psi, Ninv, _2q, ql, qh, kl, kh, 3, "intt_exit_reduce_signed")
+
+
+def _fixup(fn, what):
+    def op(a, _2q):
+        for ai, q2 in zip(a, _2q):
+            dev, st = _dev_stream(ai)
+            w, back = _inplace(ai)
+            check(fn(_ptr(w), w.size(0), w.size(-1), _ptr(q2.contiguous()), dev, st), what)
+            if back is not None:
+                back.copy_(w)
+    op.__name__ = what
+    return op
+
+
+reduce_2q = _fixup(lib.lf_reduce_2q, "reduce_2q")
+make_signed = _fixup(lib.lf_make_signed, "make_signed")
+make_unsigned = _fixup(lib.lf_make_unsigned, "make_unsigned")
+
+
+def _binary(fn, what):
+    def op(a, b, _2q):
+        out = []
+        for ai, bi, q2 in zip(a, b, _2q):
+            dev, st = _dev_stream(ai)
+            ai_c, bi_c = ai.contiguous(), bi.contiguous()
+            c = torch.empty_like(ai_c)
+            check(fn(_ptr(ai_c), _ptr(bi_c), _ptr(c), ai_c.size(0), ai_c.size(-1), _ptr(q2.contiguous()), dev, st), what)
+            out.append(c)
+        return out
+    op.__name__ = what
+    return op
+
+
+mont_add = _binary(lib.lf_mont_add, "mont_add")
+mont_sub = _binary(lib.lf_mont_sub, "mont_sub")
+
+
+def tile_unsigned(a, _2q):
+    out = []
+    for ai, q2 in zip(a, _2q):
+        dev, st = _dev_stream(ai)
+        ai.squeeze_()  # K.cu:1206
+        src = ai.contiguous()
+        c = src.new_empty((q2.size(0), src.size(0)))
+        check(lib.lf_tile_unsigned(_ptr(src), _ptr(c), q2.size(0), src.size(0), _ptr(q2.contiguous()), dev, st),
+              "tile_unsigned")
+        out.append(c)
+    return out

@@ -1,0 +1,20 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Make sure the native pieces exist before any test imports them."""
+    import __graft_entry__ as g
+    g.build()

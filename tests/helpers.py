@@ -1,0 +1,83 @@
+"""Shared test scaffolding: synthetic limb sets for any logN, seeded inputs, oracle-side constants."""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+from liberate_fhe_amd.fhe.context import primes as P
+from liberate_fhe_amd.fhe.context.ckks_context import bit_reverse_indices, _power_table
+
+R = 1 << 62
+LB = (1 << 31) - 1
+
+
+def primitive_root_2N(q, N):
+    """Same search as the context's, but not capped at x < N (tiny test rings need larger x)."""
+    e = (q - 1) // (2 * N)
+    for x in range(2, 1000):
+        g = pow(x, e, q)
+        if pow(g, N, q) != 1:
+            return g
+    raise ValueError(q)
+
+
+def i64(v):
+    return np.ascontiguousarray(np.asarray(v, dtype=np.int64))
+
+
+class Limbs:
+    """Montgomery / NTT constants of a list of primes for ring degree 2^logN, as host int64 arrays."""
+
+    def __init__(self, logN, q):
+        self.logN, self.N, self.q = logN, 1 << logN, [int(x) for x in q]
+        N = self.N
+        self.rows = len(self.q)
+        self.k = [(R * pow(R, -1, qi) - 1) // qi for qi in self.q]
+        self.ql, self.qh = i64([x & LB for x in self.q]), i64([x >> 31 for x in self.q])
+        self.kl, self.kh = i64([x & LB for x in self.k]), i64([x >> 31 for x in self.k])
+        self._2q = i64([2 * x for x in self.q])
+        self.Rs = i64([R * R % x for x in self.q])
+        self.Ninv = i64([pow(N, -1, x) * R % x for x in self.q])
+        brev = bit_reverse_indices(logN)
+        self.root = [primitive_root_2N(x, N) for x in self.q]
+        self.psi_plain = np.stack([_power_table(g, N, x)[brev] for g, x in zip(self.root, self.q)])
+        self.ipsi_plain = np.stack([_power_table(pow(g, -1, x), N, x)[brev] for g, x in zip(self.root, self.q)])
+        self._mont = None
+
+    def mont_tables(self):
+        """psi_br / ipsi_br entered into Montgomery form with the ORACLE's mm (as the reference does on device)."""
+        if self._mont is None:
+            from oracle import oracle as orc
+            psi, ipsi = self.psi_plain.copy(), self.ipsi_plain.copy()
+            orc.mont_enter(psi, self.Rs, self.rows, self.ql, self.qh, self.kl, self.kh)
+            orc.mont_enter(ipsi, self.Rs, self.rows, self.ql, self.qh, self.kl, self.kh)
+            self._mont = (psi, ipsi)
+        return self._mont
+
+    def mont_args(self):
+        return self.ql, self.qh, self.kl, self.kh
+
+    def uniform(self, seed, lazy=False):
+        rng = np.random.default_rng(seed)
+        return np.stack([rng.integers(0, (2 if lazy else 1) * x, size=self.N, dtype=np.int64) for x in self.q])
+
+
+def pick_primes(logN, n40=2, n60=1):
+    """A few NTT-friendly primes for ring degree 2^logN: `n40` near 2^40 and `n60` just below 2^60."""
+    M = 2 << logN
+    out, q = [], (1 << 40) + 1
+    for _ in range(n40):
+        q = P.next_ntt_prime(q, M, up=True)
+        out.append(q)
+        q += 2
+    q = (1 << 60) - 1
+    for _ in range(n60):
+        q = P.next_ntt_prime(q, M, up=False)
+        out.append(q)
+        q -= 2
+    return out
+
+
+def sha(arr) -> str:
+    return hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()

@@ -1,0 +1,190 @@
+"""GPU parity of the 15 `ntt_cuda` ops (through the C ABI) against the CPU oracle — bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import Limbs, pick_primes, i64
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from liberate_fhe_amd.ntt import ntt_cuda
+    from oracle import oracle as orc
+    return ntt_cuda, orc
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def signed_inputs(lim, seed):
+    """Rows mixing canonical, lazy [0,2q), negative (-2q,0) and a few boundary words."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for x in lim.q:
+        v = rng.integers(-2 * x + 1, 2 * x, size=lim.N, dtype=np.int64)
+        v[:6] = [0, 1, x - 1, x, 2 * x - 1, -(x - 1)]
+        rows.append(v)
+    return np.stack(rows)
+
+
+@pytest.mark.parametrize("logN", [4, 12])
+def test_elementwise_ops(mods, logN):
+    nc, orc = mods
+    lim = Limbs(logN, pick_primes(logN, 3, 2))
+    C = lim.rows
+    a, b = signed_inputs(lim, 1), signed_inputs(lim, 2)
+    d = lambda v: [dev(v)]
+    mont = [d(lim.ql), d(lim.qh), d(lim.kl), d(lim.kh)]
+
+    want = np.empty_like(a)
+    orc.mont_mult(a, b, want, C, *lim.mont_args())
+    got = nc.mont_mult(d(a), d(b), *mont)[0].cpu().numpy()
+    assert (got == want).all()
+
+    want = a.copy()
+    orc.mont_enter(want, lim.Rs, C, *lim.mont_args())
+    t = d(a)
+    nc.mont_enter(t, d(lim.Rs), *mont)
+    assert (t[0].cpu().numpy() == want).all()
+
+    want = a.copy()
+    orc.mont_redc(want, C, *lim.mont_args())
+    t = d(a)
+    nc.mont_redc(t, *mont)
+    assert (t[0].cpu().numpy() == want).all()
+
+    for name in ("reduce_2q", "make_signed", "make_unsigned"):
+        want = a.copy()
+        getattr(orc, name)(want, C, lim._2q)
+        t = d(a)
+        getattr(nc, name)(t, d(lim._2q))
+        assert (t[0].cpu().numpy() == want).all(), name
+
+    for name in ("mont_add", "mont_sub"):
+        want = np.empty_like(a)
+        getattr(orc, name)(a, b, want, C, lim._2q)
+        got = getattr(nc, name)(d(a), d(b), d(lim._2q))[0].cpu().numpy()
+        assert (got == want).all(), name
+
+    vec = a[0].copy()
+    want = np.empty_like(a)
+    orc.tile_unsigned(vec, want, C, lim._2q)
+    src = dev(vec[None, :])
+    got = nc.tile_unsigned([src], d(lim._2q))[0]
+    assert tuple(got.shape) == (C, lim.N) and (got.cpu().numpy() == want).all()
+    assert src.dim() == 1  # squeezed in place like the reference (K.cu:1206)
+
+
+def test_b_taller_than_a_and_row_extent(mods):
+    """mont_mult runs over a.size(0) rows and indexes b / constants by row id (ckks_engine.py:399)."""
+    nc, orc = mods
+    lim = Limbs(8, pick_primes(8, 3, 1))
+    a, b = lim.uniform(3, lazy=True)[:3].copy(), lim.uniform(4, lazy=True)
+    want = np.empty_like(a)
+    orc.mont_mult(a, b, want, 3, *lim.mont_args())
+    got = nc.mont_mult([dev(a)], [dev(b)], [dev(lim.ql)], [dev(lim.qh)], [dev(lim.kl)], [dev(lim.kh)])[0]
+    assert (got.cpu().numpy() == want).all()
+
+
+def test_rescale_known_answer(mods):
+    """REDC of a negative difference must return the NEGATIVE representative."""
+    nc, orc = mods
+    q_l, q_i = 1099510054913, 1099515691009
+    d_, s_ = 49326798554, 1033533601499
+    k = (2**62 * pow(2**62, -1, q_i) - 1) // q_i
+    scale = pow(q_l, -1, q_i) * 2**62 % q_i
+    a = dev(np.full((1, 16), d_ - s_, dtype=np.int64))
+    lb = (1 << 31) - 1
+    t = lambda v: [dev(i64([v]))]
+    nc.mont_enter([a], t(scale), t(q_i & lb), t(q_i >> 31), t(k & lb), t(k >> 31))
+    assert (a.cpu().numpy() == -20459).all()
+
+
+@pytest.mark.parametrize("logN", [1, 2, 3, 4, 5, 6, 7, 9, 11, 12, 13, 14, 15, 16, 17])
+def test_ntt_family_bit_exact(mods, logN):
+    nc, orc = mods
+    lim = Limbs(logN, pick_primes(logN, 2, 1))
+    C = lim.rows
+    psi, ipsi = lim.mont_tables()
+    d = lambda v: [dev(v)]
+    consts = [d(lim._2q), d(lim.ql), d(lim.qh), d(lim.kl), d(lim.kh)]
+    x = lim.uniform(10 + logN, lazy=True)
+
+    # ntt
+    want = x.copy()
+    orc.ntt(want, psi, C, logN, lim._2q, *lim.mont_args())
+    t = d(x)
+    nc.ntt(t, [None], [None], d(psi), *consts)
+    fwd = t[0].cpu().numpy()
+    assert (fwd == want).all(), "ntt"
+
+    # enter_ntt
+    xc = lim.uniform(20 + logN)
+    want_e = xc.copy()
+    orc.mont_enter(want_e, lim.Rs, C, *lim.mont_args())
+    orc.ntt(want_e, psi, C, logN, lim._2q, *lim.mont_args())
+    t = d(xc)
+    nc.enter_ntt(t, d(lim.Rs), [None], [None], d(psi), *consts)
+    assert (t[0].cpu().numpy() == want_e).all(), "enter_ntt"
+
+    # the four inverse chains
+    for tail, name in enumerate(("intt", "intt_exit", "intt_exit_reduce", "intt_exit_reduce_signed")):
+        want_i = want_e.copy()
+        orc.intt(want_i, ipsi, lim.Ninv, C, logN, lim._2q, *lim.mont_args())
+        if tail >= 1:
+            orc.mont_redc(want_i, C, *lim.mont_args())
+        if tail >= 2:
+            orc.reduce_2q(want_i, C, lim._2q)
+        if tail >= 3:
+            orc.make_signed(want_i, C, lim._2q)
+        t = d(want_e)
+        getattr(nc, name)(t, [None], [None], d(ipsi), d(lim.Ninv), *consts)
+        assert (t[0].cpu().numpy() == want_i).all(), name
+        if tail == 2:
+            assert (want_i == xc).all(), "round trip must be the identity"
+
+
+def test_ntt_extent_is_constant_rows(mods):
+    """NTT-family ops transform ql.size(0) rows and leave further rows of `a` alone (K.cu:298)."""
+    nc, orc = mods
+    logN = 12
+    lim = Limbs(logN, pick_primes(logN, 2, 1))
+    psi, _ = lim.mont_tables()
+    x = lim.uniform(5, lazy=True)
+    t = dev(x)
+    cut = lambda v: [dev(v[:2])]
+    nc.ntt([t], [None], [None], cut(psi), cut(lim._2q), cut(lim.ql), cut(lim.qh), cut(lim.kl), cut(lim.kh))
+    got = t.cpu().numpy()
+    want = x.copy()
+    orc.ntt(want[:2], psi[:2].copy(), 2, logN, lim._2q[:2], lim.ql[:2], lim.qh[:2], lim.kl[:2], lim.kh[:2])
+    assert (got == want).all()
+
+
+def test_reference_shaped_tables_are_accepted(mods):
+    """Drop-in: the reference passes [rows, logN, N/2] per-stage tables; results must be identical."""
+    nc, orc = mods
+    from liberate_fhe_amd.fhe.context.ckks_context import stage_butterfly_indices
+    logN = 10
+    lim = Limbs(logN, pick_primes(logN, 2, 1))
+    psi, ipsi = lim.mont_tables()
+    ev, od, tw = stage_butterfly_indices(logN, inverse=False)
+    iev, iod, itw = stage_butterfly_indices(logN, inverse=True)
+    psi3, ipsi3 = np.ascontiguousarray(psi[:, tw]), np.ascontiguousarray(ipsi[:, itw])
+    d = lambda v: [dev(v)]
+    consts = [d(lim._2q), d(lim.ql), d(lim.qh), d(lim.kl), d(lim.kh)]
+    x = lim.uniform(9, lazy=True)
+    a, b = d(x), d(x)
+    nc.ntt(a, d(ev), d(od), d(psi3), *consts)
+    nc.ntt(b, [None], [None], d(psi), *consts)
+    assert torch.equal(a[0], b[0])
+    want = x.copy()
+    orc.ntt_tab(want, ev, od, psi3, lim.rows, lim._2q, *lim.mont_args())
+    assert (a[0].cpu().numpy() == want).all()
+    nc.intt(a, d(iev), d(iod), d(ipsi3), d(lim.Ninv), *consts)
+    nc.intt(b, [None], [None], d(ipsi), d(lim.Ninv), *consts)
+    assert torch.equal(a[0], b[0])
+    orc.intt_tab(want, iev, iod, ipsi3, lim.Ninv, lim.rows, lim._2q, *lim.mont_args())
+    assert (a[0].cpu().numpy() == want).all()
