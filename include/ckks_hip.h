@@ -94,6 +94,45 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
 int lf_galois(const int64_t *a, int64_t *dst, int rows, int logN, int64_t p, const int64_t *_2q,
               int device, void *stream);
 
+/* ---- engine-level fused ops -------------------------------------------------------------------
+ * Each replaces a run of ntt_cuda calls + torch elementwise ops issued by the reference's Python
+ * engine (ckks_engine.py = src/liberate/fhe/ckks_engine.py); arithmetic is op-for-op the reference's. */
+
+/* ckks_engine.rescale body (ckks_engine.py:1017-1041): out[i] = reduce_q(REDC((in[i] - row0) * scales[i])
+ * + [row0 > round_at]); `in` points at the first surviving row, constants are those of the surviving rows. */
+int lf_rescale(const int64_t *in, const int64_t *row0, int64_t *out, int rows, int64_t N, const int64_t *scales,
+               int64_t round_at, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
+               int device, void *stream);
+
+/* cc_mult's tensor product (ckks_engine.py:1095-1101): d0 = x0*y0, d1 = x0*y1 (+) x1*y0, d2 = x1*y1 (REDC, lazy). */
+int lf_tensor(const int64_t *x0, const int64_t *x1, const int64_t *y0, const int64_t *y1, int64_t *d0, int64_t *d1,
+              int64_t *d2, int rows, int64_t N, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+              const int64_t *kh, int device, void *stream);
+
+/* pre_extend (ckks_engine.py:654-705) for all local key-switch digits at once: mixed-radix (Garner) digits.
+ * desc[p] = {row_start, alpha, y_off, l_off} (int64 x4); tab holds Y_scalar / L_scalar (ntt_context.py:328-345). */
+int lf_ks_digits(const int64_t *a, int64_t *state, int nparts, const int64_t *desc, const int64_t *tab, int64_t N,
+                 const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+
+/* extend (ckks_engine.py:707-743) of every digit to every local target row: ext[p][r] in Montgomery form.
+ * desc[p] = {row_start, alpha, e_off} (int64 x3); E[e_off + i*rows + r] = R^2 (i = 0) or L_{i-1} R^2 mod q_r. */
+int lf_ks_extend(const int64_t *state, int64_t *ext, int nparts, int rows, int64_t N, const int64_t *desc,
+                 const int64_t *E, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
+                 int device, void *stream);
+
+/* switcher_later_part's two mont_mults + the sum over digits (ckks_engine.py:931-934, 832-840); the key is
+ * addressed as ksk[p*part_stride + comp*comp_stride + (row_off + r)*N + j], comp 0 = b, 1 = a. */
+int lf_ks_inner(const int64_t *ext, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
+                int64_t *s0, int64_t *s1, int nparts, int rows, int64_t N, const int64_t *ql, const int64_t *qh,
+                const int64_t *kl, const int64_t *kh, int device, void *stream);
+
+/* division by P = prod(special primes) (ckks_engine.py:850-901) on canonical coefficient rows s[ell+K][N];
+ * PiR[P_ind][row] = P_j^-1 R mod q_row ([K][ell+K], specials last-first); optional addend:
+ * out = reduce_q(result + addend) (relinearize 1135-1140 / switch_key 952-953). */
+int lf_ks_moddown(const int64_t *s, int64_t *out, const int64_t *addend, int ell, int K, int64_t N,
+                  const int64_t *PiR, const int64_t *Rs, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+                  const int64_t *kh, int device, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,12 @@ _SIGNATURES = {
     "lf_ntt": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_intt": [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P],
     "lf_galois": [_P, _P, _I, _I, _L, _P, _I, _P],
+    "lf_rescale": [_P, _P, _P, _I, _L, _P, _L, _P, _P, _P, _P, _I, _P],
+    "lf_tensor": [_P, _P, _P, _P, _P, _P, _P, _I, _L, _P, _P, _P, _P, _I, _P],
+    "lf_ks_digits": [_P, _P, _I, _P, _P, _L, _P, _P, _P, _P, _I, _P],
+    "lf_ks_extend": [_P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lf_ks_inner": [_P, _P, _L, _L, _L, _P, _P, _I, _I, _L, _P, _P, _P, _P, _I, _P],
+    "lf_ks_moddown": [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _I, _P],
 }
 
 for _name, _args in _SIGNATURES.items():

@@ -1,0 +1,76 @@
+// ckks_common.h — device-side scalar arithmetic shared by the gfx950 kernels.
+//
+// Word model = the reference's 62-bit mode: int64 words, Montgomery radix R = 2^62, lazy values in
+// [0, 2q).  The reference builds REDC62 from 31-bit half-words (K.cu:12-59, K.cu =
+// src/liberate/ntt/ntt_cuda_kernel.cu); here the same function is evaluated in closed form with
+// native 64x64->128 products:
+//     mm(a,b) = hi62(a*b) + floor(4*s*q / 2^64) + [lo62(a*b) != 0],   s = lo62(a*b) * k mod 2^62
+// which equals (a*b + s*q) / 2^62 exactly for all |a|,|b| < 2^62, i.e. bit-identical outputs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef long long i64;
+typedef unsigned long long u64;
+typedef unsigned __int128 u128;
+typedef __int128 i128;
+
+#define M62 ((1ull << 62) - 1ull)
+
+// ------------------------------------------------------------------------------------------------
+// Scalar arithmetic
+// ------------------------------------------------------------------------------------------------
+
+// REDC62 of a signed product (reference K.cu:12-59), any |a|,|b| < 2^62.
+static __device__ __forceinline__ i64 mm62s(i64 a, i64 b, u64 q, u64 k) {
+    const i128 x = (i128)a * (i128)b;
+    const u64 lo = (u64)x;
+    const i64 hi = (i64)(x >> 64);
+    const u64 xl = lo & M62;
+    const i64 xh = (i64)(((u64)hi << 2) | (lo >> 62));
+    const u64 s = (xl * k) & M62;
+    return xh + (i64)__umul64hi(s << 2, q) + (i64)(xl != 0);
+}
+
+// Same for operands known to be non-negative (butterflies: both in [0, 2q)).
+static __device__ __forceinline__ i64 mm62u(u64 a, u64 b, u64 q, u64 k) {
+    const u128 x = (u128)a * (u128)b;
+    const u64 lo = (u64)x;
+    const u64 hi = (u64)(x >> 64);
+    const u64 xl = lo & M62;
+    const u64 xh = (hi << 2) | (lo >> 62);
+    const u64 s = (xl * k) & M62;
+    return (i64)(xh + __umul64hi(s << 2, q) + (u64)(xl != 0));
+}
+
+// mont_redc body (K.cu:587-606): (x + ((x*k) mod R) * q) / R for signed x, |x| < 2^62.
+static __device__ __forceinline__ i64 redc62(i64 x, u64 q, u64 k) {
+    const u64 xl = (u64)x & M62;
+    const i64 xh = x >> 62;
+    const u64 s = (xl * k) & M62;
+    return xh + (i64)__umul64hi(s << 2, q) + (i64)(xl != 0);
+}
+
+static __device__ __forceinline__ i64 csub(i64 v, i64 m) { return v < m ? v : v - m; }
+
+struct RowMod {
+    u64 q, k;
+    i64 q2;
+};
+
+static __device__ __forceinline__ RowMod load_mod(const i64 *ql, const i64 *qh, const i64 *kl, const i64 *kh, int i) {
+    RowMod m;
+    m.q = ((u64)qh[i] << 31) | (u64)ql[i];
+    m.k = ((u64)kh[i] << 31) | (u64)kl[i];
+    m.q2 = (i64)(m.q << 1);
+    return m;
+}
+
+
+static inline int lf_set_device(int device) {
+    if (device >= 0) {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}

@@ -1,0 +1,301 @@
+// ckks_fused.hip — engine-level fused kernels: rescale, tensor product, hybrid key switching.
+//
+// Each kernel replaces a run of `ntt_cuda` calls plus plain torch ops that the reference engine
+// issues from Python (src/liberate/fhe/ckks_engine.py: rescale 967-1052, cc_mult 1095-1101,
+// pre_extend 654-705, extend 707-743, switcher_later_part 931-934, create_switcher 832-901).
+// The per-word arithmetic follows the reference op by op (same REDC, same conditional subtractions,
+// same order), so every intermediate word — including the signed-lazy Garner digits that the result
+// depends on as INTEGERS — is bit-identical; what changes is that a column of a digit / a ciphertext
+// stays in registers across the whole chain instead of round-tripping through HBM per op.
+#include "../../include/ckks_hip.h"
+#include "ckks_common.h"
+
+#define KS_MAX_ALPHA 8   // limbs per key-switch digit (= number of special primes, <= 6 in the presets)
+#define KS_MAX_K 8
+
+namespace {
+
+// ---- rescale (ckks_engine.py:1029-1041) ----------------------------------------------------------
+// out = reduce_q( REDC(in - row0, q_l^-1 * R mod q_i) + [row0 > q_l/2] )
+__global__ void __launch_bounds__(256) rescale_kernel(const i64 *__restrict__ in, const i64 *__restrict__ row0,
+                                                      i64 *__restrict__ out, i64 N, const i64 *__restrict__ scales,
+                                                      i64 round_at, const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                      const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    const int r = blockIdx.y;
+    const i64 j = ((i64)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (j >= N) return;
+    const RowMod m = load_mod(ql, qh, kl, kh, r);
+    const i64 sc = scales[r];
+    const longlong2 x = *reinterpret_cast<const longlong2 *>(in + (i64)r * N + j);
+    const longlong2 z = *reinterpret_cast<const longlong2 *>(row0 + j);
+    longlong2 o;
+    i64 v = mm62s(x.x - z.x, sc, m.q, m.k) + (i64)(z.x > round_at);
+    o.x = v < (i64)m.q ? v : v - (i64)m.q;
+    v = mm62s(x.y - z.y, sc, m.q, m.k) + (i64)(z.y > round_at);
+    o.y = v < (i64)m.q ? v : v - (i64)m.q;
+    *reinterpret_cast<longlong2 *>(out + (i64)r * N + j) = o;
+}
+
+// ---- tensor product (ckks_engine.py:1095-1101) ---------------------------------------------------
+__global__ void __launch_bounds__(256) tensor_kernel(const i64 *__restrict__ x0, const i64 *__restrict__ x1,
+                                                     const i64 *__restrict__ y0, const i64 *__restrict__ y1,
+                                                     i64 *__restrict__ d0, i64 *__restrict__ d1, i64 *__restrict__ d2, i64 N,
+                                                     const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                     const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    const int r = blockIdx.y;
+    const i64 j = ((i64)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (j >= N) return;
+    const RowMod m = load_mod(ql, qh, kl, kh, r);
+    const i64 off = (i64)r * N + j;
+    const longlong2 a0 = *reinterpret_cast<const longlong2 *>(x0 + off), a1 = *reinterpret_cast<const longlong2 *>(x1 + off);
+    const longlong2 b0 = *reinterpret_cast<const longlong2 *>(y0 + off), b1 = *reinterpret_cast<const longlong2 *>(y1 + off);
+    longlong2 o0, o1, o2;
+    o0.x = mm62s(a0.x, b0.x, m.q, m.k);
+    o0.y = mm62s(a0.y, b0.y, m.q, m.k);
+    o1.x = csub(mm62s(a0.x, b1.x, m.q, m.k) + mm62s(a1.x, b0.x, m.q, m.k), m.q2);
+    o1.y = csub(mm62s(a0.y, b1.y, m.q, m.k) + mm62s(a1.y, b0.y, m.q, m.k), m.q2);
+    o2.x = mm62s(a1.x, b1.x, m.q, m.k);
+    o2.y = mm62s(a1.y, b1.y, m.q, m.k);
+    *reinterpret_cast<longlong2 *>(d0 + off) = o0;
+    *reinterpret_cast<longlong2 *>(d1 + off) = o1;
+    *reinterpret_cast<longlong2 *>(d2 + off) = o2;
+}
+
+// ---- key-switch step 1: mixed-radix digits of each key-switch part (pre_extend, 654-705) ---------
+// desc[p] = {row_start, alpha, y_off, l_off}; Y_scalar[i] = tab[y_off + i];
+// L_scalar[i][j-(i+2)] = tab[l_off + running index in (i, j) order].
+__global__ void __launch_bounds__(256) ks_digits_kernel(const i64 *__restrict__ a, i64 *__restrict__ state,
+                                                        const i64 *__restrict__ desc, const i64 *__restrict__ tab, i64 N,
+                                                        const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                        const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    const int p = blockIdx.y;
+    const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const int row_start = (int)desc[p * 4 + 0], alpha = (int)desc[p * 4 + 1];
+    const i64 *Y = tab + desc[p * 4 + 2];
+    const i64 *Ls = tab + desc[p * 4 + 3];
+    i64 x[KS_MAX_ALPHA], st[KS_MAX_ALPHA];
+#pragma unroll
+    for (int i = 0; i < KS_MAX_ALPHA; ++i)
+        if (i < alpha) x[i] = a[(i64)(row_start + i) * N + j];
+#pragma unroll
+    for (int i = 0; i < KS_MAX_ALPHA; ++i) st[i] = x[0];
+    int lc = 0;
+#pragma unroll
+    for (int i = 0; i < KS_MAX_ALPHA - 1; ++i) {
+        if (i + 1 < alpha) {
+            const RowMod m = load_mod(ql, qh, kl, kh, row_start + i + 1);
+            const i64 y = mm62s(x[i + 1] - st[i + 1], Y[i], m.q, m.k);
+            st[i + 1] = y;
+#pragma unroll
+            for (int jj = i + 2; jj < KS_MAX_ALPHA; ++jj) {
+                if (jj < alpha) {
+                    const RowMod mj = load_mod(ql, qh, kl, kh, row_start + jj);
+                    st[jj] += mm62s(y, Ls[lc], mj.q, mj.k);
+                    ++lc;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < KS_MAX_ALPHA; ++i)
+        if (i < alpha) state[(i64)(row_start + i) * N + j] = st[i];
+}
+
+// ---- key-switch step 2: extend every digit to every target row (extend, 707-743) -----------------
+// desc[p] = {row_start, alpha, e_off};  E[e_off + i*rows + r]: i = 0 -> R^2 mod q_r, i >= 1 -> L_{i-1} R^2 mod q_r
+__global__ void __launch_bounds__(256) ks_extend_kernel(const i64 *__restrict__ state, i64 *__restrict__ ext, int rows,
+                                                        i64 N, const i64 *__restrict__ desc, const i64 *__restrict__ E,
+                                                        const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                        const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    const int r = blockIdx.y, p = blockIdx.z;
+    const i64 j = ((i64)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (j >= N) return;
+    const int row_start = (int)desc[p * 3 + 0], alpha = (int)desc[p * 3 + 1];
+    const i64 *e = E + desc[p * 3 + 2] + r;
+    const RowMod m = load_mod(ql, qh, kl, kh, r);
+    longlong2 acc;
+    {
+        const longlong2 y = *reinterpret_cast<const longlong2 *>(state + (i64)row_start * N + j);
+        acc.x = mm62s(y.x, e[0], m.q, m.k);
+        acc.y = mm62s(y.y, e[0], m.q, m.k);
+    }
+    for (int i = 1; i < alpha; ++i) {
+        const longlong2 y = *reinterpret_cast<const longlong2 *>(state + (i64)(row_start + i) * N + j);
+        const i64 c = e[(i64)i * rows];
+        acc.x = csub(acc.x + mm62s(y.x, c, m.q, m.k), m.q2);
+        acc.y = csub(acc.y + mm62s(y.y, c, m.q, m.k), m.q2);
+    }
+    *reinterpret_cast<longlong2 *>(ext + ((i64)p * rows + r) * N + j) = acc;
+}
+
+// ---- key-switch step 3: inner product with the key, summed over digits (931-934, 832-840) --------
+__global__ void __launch_bounds__(256) ks_inner_kernel(const i64 *__restrict__ ext, const i64 *__restrict__ ksk,
+                                                       i64 part_stride, i64 comp_stride, i64 row_off, i64 *__restrict__ s0,
+                                                       i64 *__restrict__ s1, int nparts, int rows, i64 N,
+                                                       const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                       const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    const int r = blockIdx.y;
+    const i64 j = ((i64)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (j >= N) return;
+    const RowMod m = load_mod(ql, qh, kl, kh, r);
+    longlong2 a0 = {0, 0}, a1 = {0, 0};
+    for (int p = 0; p < nparts; ++p) {
+        const longlong2 e = *reinterpret_cast<const longlong2 *>(ext + ((i64)p * rows + r) * N + j);
+        const i64 *kp = ksk + (i64)p * part_stride + (row_off + r) * N + j;
+        const longlong2 k0 = *reinterpret_cast<const longlong2 *>(kp);
+        const longlong2 k1 = *reinterpret_cast<const longlong2 *>(kp + comp_stride);
+        const i64 p0x = mm62s(e.x, k0.x, m.q, m.k), p0y = mm62s(e.y, k0.y, m.q, m.k);
+        const i64 p1x = mm62s(e.x, k1.x, m.q, m.k), p1y = mm62s(e.y, k1.y, m.q, m.k);
+        if (p == 0) {
+            a0.x = p0x; a0.y = p0y; a1.x = p1x; a1.y = p1y;
+        } else {
+            a0.x = csub(a0.x + p0x, m.q2); a0.y = csub(a0.y + p0y, m.q2);
+            a1.x = csub(a1.x + p1x, m.q2); a1.y = csub(a1.y + p1y, m.q2);
+        }
+    }
+    *reinterpret_cast<longlong2 *>(s0 + (i64)r * N + j) = a0;
+    *reinterpret_cast<longlong2 *>(s1 + (i64)r * N + j) = a1;
+}
+
+// ---- key-switch step 5: exact division by P = prod(special primes) (create_switcher, 850-901) ----
+// s: [ell + K][N] coefficient domain, canonical (after intt_exit_reduce).  Special primes are
+// eliminated last-first; PiR[P_ind][row] = P_j^-1 * R mod q_row.  Optional `addend` (relinearize's
+// d0/d1 or the rotated c0): out = reduce_q(result + addend)  (ckks_engine.py:1135-1140, 952-953).
+#define MD_ROWS 8
+__global__ void __launch_bounds__(256) ks_moddown_kernel(const i64 *__restrict__ s, i64 *__restrict__ out,
+                                                         const i64 *__restrict__ addend, int ell, int K, i64 N,
+                                                         const i64 *__restrict__ PiR, const i64 *__restrict__ Rs,
+                                                         const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                         const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    const int rows = ell + K;
+    i64 sp[KS_MAX_K], pv[KS_MAX_K];
+#pragma unroll
+    for (int t = 0; t < KS_MAX_K; ++t)
+        if (t < K) sp[t] = s[(i64)(ell + t) * N + j];
+    // special rows among themselves (plain form)
+#pragma unroll
+    for (int pi = 0; pi < KS_MAX_K; ++pi) {
+        if (pi < K) {
+            const int t = K - 1 - pi;
+            i64 P = 0;
+#pragma unroll
+            for (int u = 0; u < KS_MAX_K; ++u)
+                if (u == t) P = sp[u];
+            pv[pi] = P;
+#pragma unroll
+            for (int u = 0; u < KS_MAX_K; ++u) {
+                if (u < t) {
+                    const RowMod m = load_mod(ql, qh, kl, kh, ell + u);
+                    i64 d = csub(sp[u] + m.q2 - P, m.q2);
+                    d = mm62s(d, PiR[(i64)pi * rows + ell + u], m.q, m.k);
+                    sp[u] = d < (i64)m.q ? d : d - (i64)m.q;
+                }
+            }
+        }
+    }
+    const int r0 = blockIdx.y * MD_ROWS;
+    for (int r = r0; r < r0 + MD_ROWS && r < ell; ++r) {
+        const RowMod m = load_mod(ql, qh, kl, kh, r);
+        const i64 rs = Rs[r];
+        i64 d = mm62s(s[(i64)r * N + j], rs, m.q, m.k);
+#pragma unroll
+        for (int pi = 0; pi < KS_MAX_K; ++pi) {
+            if (pi < K) {
+                const i64 Q = mm62s(pv[pi], rs, m.q, m.k);
+                d = csub(d + m.q2 - Q, m.q2);
+                d = mm62s(d, PiR[(i64)pi * rows + r], m.q, m.k);
+                d = d < (i64)m.q ? d : d - (i64)m.q;
+            }
+        }
+        d = redc62(d, m.q, m.k);
+        d = d < (i64)m.q ? d : d - (i64)m.q;
+        if (addend) {
+            d += addend[(i64)r * N + j];
+            d = d < (i64)m.q ? d : d - (i64)m.q;
+        }
+        out[(i64)r * N + j] = d;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int lf_rescale(const int64_t *in, const int64_t *row0, int64_t *out, int rows, int64_t N, const int64_t *scales,
+               int64_t round_at, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+               void *stream) {
+    if (rows < 0 || N < 2 || (N & 1)) return LF_ERR_ARG;
+    if (rows == 0) return 0;
+    if (int e = lf_set_device(device)) return e;
+    dim3 grid((unsigned)((N / 2 + 255) / 256), (unsigned)rows);
+    hipLaunchKernelGGL(rescale_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const i64 *)in, (const i64 *)row0, (i64 *)out,
+                       (i64)N, (const i64 *)scales, (i64)round_at, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl,
+                       (const i64 *)kh);
+    return (int)hipGetLastError();
+}
+
+int lf_tensor(const int64_t *x0, const int64_t *x1, const int64_t *y0, const int64_t *y1, int64_t *d0, int64_t *d1,
+              int64_t *d2, int rows, int64_t N, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
+              int device, void *stream) {
+    if (rows < 0 || N < 2 || (N & 1)) return LF_ERR_ARG;
+    if (rows == 0) return 0;
+    if (int e = lf_set_device(device)) return e;
+    dim3 grid((unsigned)((N / 2 + 255) / 256), (unsigned)rows);
+    hipLaunchKernelGGL(tensor_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const i64 *)x0, (const i64 *)x1, (const i64 *)y0,
+                       (const i64 *)y1, (i64 *)d0, (i64 *)d1, (i64 *)d2, (i64)N, (const i64 *)ql, (const i64 *)qh,
+                       (const i64 *)kl, (const i64 *)kh);
+    return (int)hipGetLastError();
+}
+
+int lf_ks_digits(const int64_t *a, int64_t *state, int nparts, const int64_t *desc, const int64_t *tab, int64_t N,
+                 const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (nparts < 0 || N < 1) return LF_ERR_ARG;
+    if (nparts == 0) return 0;
+    if (int e = lf_set_device(device)) return e;
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)nparts);
+    hipLaunchKernelGGL(ks_digits_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const i64 *)a, (i64 *)state, (const i64 *)desc,
+                       (const i64 *)tab, (i64)N, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+    return (int)hipGetLastError();
+}
+
+int lf_ks_extend(const int64_t *state, int64_t *ext, int nparts, int rows, int64_t N, const int64_t *desc, const int64_t *E,
+                 const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (nparts < 0 || rows < 0 || N < 2 || (N & 1)) return LF_ERR_ARG;
+    if (nparts == 0 || rows == 0) return 0;
+    if (int e = lf_set_device(device)) return e;
+    dim3 grid((unsigned)((N / 2 + 255) / 256), (unsigned)rows, (unsigned)nparts);
+    hipLaunchKernelGGL(ks_extend_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const i64 *)state, (i64 *)ext, rows, (i64)N,
+                       (const i64 *)desc, (const i64 *)E, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+    return (int)hipGetLastError();
+}
+
+int lf_ks_inner(const int64_t *ext, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
+                int64_t *s0, int64_t *s1, int nparts, int rows, int64_t N, const int64_t *ql, const int64_t *qh,
+                const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (nparts < 1 || rows < 0 || N < 2 || (N & 1)) return LF_ERR_ARG;
+    if (rows == 0) return 0;
+    if (int e = lf_set_device(device)) return e;
+    dim3 grid((unsigned)((N / 2 + 255) / 256), (unsigned)rows);
+    hipLaunchKernelGGL(ks_inner_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const i64 *)ext, (const i64 *)ksk,
+                       (i64)part_stride, (i64)comp_stride, (i64)row_off, (i64 *)s0, (i64 *)s1, nparts, rows, (i64)N,
+                       (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+    return (int)hipGetLastError();
+}
+
+int lf_ks_moddown(const int64_t *s, int64_t *out, const int64_t *addend, int ell, int K, int64_t N, const int64_t *PiR,
+                  const int64_t *Rs, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+                  void *stream) {
+    if (ell < 0 || K < 1 || K > KS_MAX_K || N < 1) return LF_ERR_ARG;
+    if (ell == 0) return 0;
+    if (int e = lf_set_device(device)) return e;
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ell + MD_ROWS - 1) / MD_ROWS));
+    hipLaunchKernelGGL(ks_moddown_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const i64 *)s, (i64 *)out,
+                       (const i64 *)addend, ell, K, (i64)N, (const i64 *)PiR, (const i64 *)Rs, (const i64 *)ql,
+                       (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

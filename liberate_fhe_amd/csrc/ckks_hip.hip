@@ -13,68 +13,10 @@
 //    compact [limbs][N] table instead of the reference's [limbs][logN][N/2] per-stage table.
 //    N > 4096 splits the DAG into a column-strided pass and a contiguous pass.
 //  * No MFMA: this is 64-bit integer modular arithmetic.  No CUDA shims; gfx950 only.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
 #include "../../include/ckks_hip.h"
-
-typedef long long i64;
-typedef unsigned long long u64;
-typedef unsigned __int128 u128;
-typedef __int128 i128;
-
-#define M62 ((1ull << 62) - 1ull)
+#include "ckks_common.h"
 
 namespace {
-
-// ------------------------------------------------------------------------------------------------
-// Scalar arithmetic
-// ------------------------------------------------------------------------------------------------
-
-// REDC62 of a signed product (reference K.cu:12-59), any |a|,|b| < 2^62.
-__device__ __forceinline__ i64 mm62s(i64 a, i64 b, u64 q, u64 k) {
-    const i128 x = (i128)a * (i128)b;
-    const u64 lo = (u64)x;
-    const i64 hi = (i64)(x >> 64);
-    const u64 xl = lo & M62;
-    const i64 xh = (i64)(((u64)hi << 2) | (lo >> 62));
-    const u64 s = (xl * k) & M62;
-    return xh + (i64)__umul64hi(s << 2, q) + (i64)(xl != 0);
-}
-
-// Same for operands known to be non-negative (butterflies: both in [0, 2q)).
-__device__ __forceinline__ i64 mm62u(u64 a, u64 b, u64 q, u64 k) {
-    const u128 x = (u128)a * (u128)b;
-    const u64 lo = (u64)x;
-    const u64 hi = (u64)(x >> 64);
-    const u64 xl = lo & M62;
-    const u64 xh = (hi << 2) | (lo >> 62);
-    const u64 s = (xl * k) & M62;
-    return (i64)(xh + __umul64hi(s << 2, q) + (u64)(xl != 0));
-}
-
-// mont_redc body (K.cu:587-606): (x + ((x*k) mod R) * q) / R for signed x, |x| < 2^62.
-__device__ __forceinline__ i64 redc62(i64 x, u64 q, u64 k) {
-    const u64 xl = (u64)x & M62;
-    const i64 xh = x >> 62;
-    const u64 s = (xl * k) & M62;
-    return xh + (i64)__umul64hi(s << 2, q) + (i64)(xl != 0);
-}
-
-__device__ __forceinline__ i64 csub(i64 v, i64 m) { return v < m ? v : v - m; }
-
-struct RowMod {
-    u64 q, k;
-    i64 q2;
-};
-
-__device__ __forceinline__ RowMod load_mod(const i64 *ql, const i64 *qh, const i64 *kl, const i64 *kh, int i) {
-    RowMod m;
-    m.q = ((u64)qh[i] << 31) | (u64)ql[i];
-    m.k = ((u64)kh[i] << 31) | (u64)kl[i];
-    m.q2 = (i64)(m.q << 1);
-    return m;
-}
 
 // ------------------------------------------------------------------------------------------------
 // Elementwise kernels.  grid = (ceil(N / (256*2)), rows); two words (16 B) per lane.
@@ -176,7 +118,7 @@ __device__ __forceinline__ i64 tile_gaddr(const PassGeom &g, int tile, int L) {
 }
 
 // Forward radix-2^K step over local distances (dl << (K-1)), ..., dl at stages s, s+1, ..
-template <int K>
+template <int K, bool SIGNED>
 __device__ __forceinline__ void fwd_step(i64 *sm, int T, int log_dl, int s, int E, i64 base,
                                          const i64 *__restrict__ psi, const RowMod &m) {
     const int items = T >> K;
@@ -195,7 +137,7 @@ __device__ __forceinline__ void fwd_step(i64 *sm, int T, int log_dl, int s, int 
                 const i64 L = base + p + (e << log_dl);
                 const i64 S = psi[((i64)1 << st) + (L >> (E - st))];
                 const i64 U = x[e];
-                const i64 V = mm62u((u64)S, (u64)x[e + du], m.q, m.k);
+                const i64 V = SIGNED ? mm62s(S, x[e + du], m.q, m.k) : mm62u((u64)S, (u64)x[e + du], m.q, m.k);
                 x[e] = csub(U + V, m.q2);
                 x[e + du] = csub(U + m.q2 - V, m.q2);
             }
@@ -206,7 +148,7 @@ __device__ __forceinline__ void fwd_step(i64 *sm, int T, int log_dl, int s, int 
 }
 
 // Inverse radix-2^K step over local distances dl, 2dl, .. at stages s, s+1, ..
-template <int K>
+template <int K, bool SIGNED>
 __device__ __forceinline__ void inv_step(i64 *sm, int T, int log_dl, int s, int adj, int logN, i64 base,
                                          const i64 *__restrict__ ipsi, const RowMod &m) {
     const int items = T >> K;
@@ -226,7 +168,7 @@ __device__ __forceinline__ void inv_step(i64 *sm, int T, int log_dl, int s, int 
                 const i64 S = ipsi[((i64)1 << (logN - st - 1)) + (L >> (st + 1 - adj))];
                 const i64 U = x[e], V = x[e + du];
                 const i64 O = csub(U + m.q2 - V, m.q2);
-                x[e + du] = mm62u((u64)S, (u64)O, m.q, m.k);
+                x[e + du] = SIGNED ? mm62s(S, O, m.q, m.k) : mm62u((u64)S, (u64)O, m.q, m.k);
                 x[e] = csub(U + V, m.q2);
             }
         }
@@ -254,28 +196,35 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_fwd_pass(i64 *__restrict__ a,
     // load (two consecutive local indices per lane -> 16-byte accesses; C >= 2 always)
     const bool enter = (Rs != nullptr);
     const i64 rs = enter ? Rs[crow] : 0;
+    int odd_word = 0;  // any word outside [0, 2q): the rare signed-lazy inputs
     for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2) {
         longlong2 v = *reinterpret_cast<const longlong2 *>(row + tile_gaddr(g, tile, L));
         if (enter) {
             v.x = mm62s(v.x, rs, m.q, m.k);
             v.y = mm62s(v.y, rs, m.q, m.k);
         }
+        odd_word |= ((u64)v.x >= (u64)m.q2) | ((u64)v.y >= (u64)m.q2);
         *reinterpret_cast<longlong2 *>(sm + L) = v;
     }
-    __syncthreads();
+    // With every word in [0, 2q) all later words stay there and the unsigned product is exact;
+    // otherwise run the tile with the fully signed REDC, as the reference's scalar code does.
+    const bool sgn = __syncthreads_or(odd_word);
 
     const int E = g.strided ? g.tl : g.logN;
     const i64 base = g.strided ? 0 : ((i64)tile << g.tl);
     int s = g.s0, left = g.S, log_d = g.tl - 1;  // log2 of the current largest local distance
     while (left > 0) {
         if (left >= 3) {
-            fwd_step<3>(sm, T, log_d - 2, s, E, base, psi, m);
+            if (sgn) fwd_step<3, true>(sm, T, log_d - 2, s, E, base, psi, m);
+            else fwd_step<3, false>(sm, T, log_d - 2, s, E, base, psi, m);
             s += 3; left -= 3; log_d -= 3;
         } else if (left == 2) {
-            fwd_step<2>(sm, T, log_d - 1, s, E, base, psi, m);
+            if (sgn) fwd_step<2, true>(sm, T, log_d - 1, s, E, base, psi, m);
+            else fwd_step<2, false>(sm, T, log_d - 1, s, E, base, psi, m);
             s += 2; left -= 2; log_d -= 2;
         } else {
-            fwd_step<1>(sm, T, log_d, s, E, base, psi, m);
+            if (sgn) fwd_step<1, true>(sm, T, log_d, s, E, base, psi, m);
+            else fwd_step<1, false>(sm, T, log_d, s, E, base, psi, m);
             s += 1; left -= 1; log_d -= 1;
         }
         __syncthreads();
@@ -298,9 +247,13 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_inv_pass(i64 *__restrict__ a,
     i64 *row = a + ((i64)prow << g.logN);
     const i64 *ipsi = ipsi_br + ((i64)crow << g.logN);
 
-    for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2)
-        *reinterpret_cast<longlong2 *>(sm + L) = *reinterpret_cast<const longlong2 *>(row + tile_gaddr(g, tile, L));
-    __syncthreads();
+    int odd_word = 0;
+    for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2) {
+        const longlong2 v = *reinterpret_cast<const longlong2 *>(row + tile_gaddr(g, tile, L));
+        odd_word |= ((u64)v.x >= (u64)m.q2) | ((u64)v.y >= (u64)m.q2);
+        *reinterpret_cast<longlong2 *>(sm + L) = v;
+    }
+    const bool sgn = __syncthreads_or(odd_word);
 
     // local distances grow: contiguous pass starts at 1; strided pass starts at C.
     const int adj = g.strided ? (g.logN - g.S - g.logC) : 0;
@@ -308,13 +261,16 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_inv_pass(i64 *__restrict__ a,
     int s = g.s0, left = g.S, log_d = g.strided ? g.logC : 0;
     while (left > 0) {
         if (left >= 3) {
-            inv_step<3>(sm, T, log_d, s, adj, g.logN, base, ipsi, m);
+            if (sgn) inv_step<3, true>(sm, T, log_d, s, adj, g.logN, base, ipsi, m);
+            else inv_step<3, false>(sm, T, log_d, s, adj, g.logN, base, ipsi, m);
             s += 3; left -= 3; log_d += 3;
         } else if (left == 2) {
-            inv_step<2>(sm, T, log_d, s, adj, g.logN, base, ipsi, m);
+            if (sgn) inv_step<2, true>(sm, T, log_d, s, adj, g.logN, base, ipsi, m);
+            else inv_step<2, false>(sm, T, log_d, s, adj, g.logN, base, ipsi, m);
             s += 2; left -= 2; log_d += 2;
         } else {
-            inv_step<1>(sm, T, log_d, s, adj, g.logN, base, ipsi, m);
+            if (sgn) inv_step<1, true>(sm, T, log_d, s, adj, g.logN, base, ipsi, m);
+            else inv_step<1, false>(sm, T, log_d, s, adj, g.logN, base, ipsi, m);
             s += 1; left -= 1; log_d += 1;
         }
         __syncthreads();
@@ -357,14 +313,6 @@ __global__ void __launch_bounds__(256) galois_kernel(const i64 *__restrict__ a, 
         v = v < q ? v : v - q;
     }
     dst[((i64)row << logN) + (i64)(pn & (u64)(N - 1))] = v;
-}
-
-int set_device(int device) {
-    if (device >= 0) {
-        hipError_t e = hipSetDevice(device);
-        if (e != hipSuccess) return (int)e;
-    }
-    return 0;
 }
 
 }  // namespace
@@ -431,7 +379,7 @@ int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, con
     (void)_2q;
     if (batch < 0 || rows < 0 || logN < 1 || logN > 2 * NTT_TILE_LOG_MAX) return LF_ERR_ARG;
     if (batch == 0 || rows == 0) return 0;
-    if (int e = set_device(device)) return e;
+    if (int e = lf_set_device(device)) return e;
     const int tl = logN < NTT_TILE_LOG_MAX ? logN : NTT_TILE_LOG_MAX;
     const int S1 = logN - tl;  // stages of the strided pass
     const unsigned tiles = 1u << (logN - tl);
@@ -454,7 +402,7 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
     (void)_2q;
     if (batch < 0 || rows < 0 || logN < 1 || logN > 2 * NTT_TILE_LOG_MAX || tail < 0 || tail > 3) return LF_ERR_ARG;
     if (batch == 0 || rows == 0) return 0;
-    if (int e = set_device(device)) return e;
+    if (int e = lf_set_device(device)) return e;
     const int tl = logN < NTT_TILE_LOG_MAX ? logN : NTT_TILE_LOG_MAX;
     const int SB = logN - tl;  // stages of the strided (second) pass
     const unsigned tiles = 1u << (logN - tl);
@@ -475,7 +423,7 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
 int lf_galois(const int64_t *a, int64_t *dst, int rows, int logN, int64_t p, const int64_t *_2q, int device, void *stream) {
     if (rows < 0 || logN < 1 || logN > 30 || p < 1 || !(p & 1) || p >= ((int64_t)2 << logN) || a == dst) return LF_ERR_ARG;
     if (rows == 0) return 0;
-    if (int e = set_device(device)) return e;
+    if (int e = lf_set_device(device)) return e;
     const i64 N = (i64)1 << logN;
     dim3 grid((unsigned)((N + 255) / 256), (unsigned)rows);
     hipLaunchKernelGGL(galois_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const i64 *)a, (i64 *)dst, logN, (i64)p,

@@ -1,0 +1,90 @@
+"""Device arithmetic behind the engine: thin tensor-level wrappers over the C ABI (include/ckks_hip.h).
+
+`HipBackend` is the only backend in the package and it has no fallback — every method launches a HIP
+kernel through libckks_hip.so on the tensor's GPU and current torch stream.  The engine takes the
+backend as an object so that the multi-rank orchestration (which is backend-agnostic Python) can be
+exercised by the CPU test-suite with a checker backend that lives under tests/.
+"""
+from __future__ import annotations
+
+import torch
+
+from .._native import lib, check
+from ..ntt import ntt_cuda
+
+
+def _ds(t: torch.Tensor):
+    if t.device.type != "cuda":
+        raise RuntimeError(f"HipBackend: tensor on {t.device}; device memory required (no CPU fallback)")
+    idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    return idx, torch.cuda.current_stream(idx).cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return 0
+    assert t.dtype == torch.int64 and t.is_contiguous(), (t.dtype, t.is_contiguous())
+    return t.data_ptr()
+
+
+class Consts:
+    """Per-row Montgomery constants of a contiguous run of limbs on one device."""
+    __slots__ = ("ql", "qh", "kl", "kh", "_2q")
+
+    def __init__(self, ql, qh, kl, kh, _2q):
+        self.ql, self.qh, self.kl, self.kh, self._2q = ql, qh, kl, kh, _2q
+
+    def mont(self):
+        return _p(self.ql), _p(self.qh), _p(self.kl), _p(self.kh)
+
+
+class HipBackend:
+    name = "hip-gfx950"
+    ops = ntt_cuda  # the 15 reference-shaped primitives
+
+    # ---- NTT family over [batch][rows][N] stacks ------------------------------------------------
+    def ntt(self, buf, batch, rows, logN, psi, Rs, c: Consts):
+        dev, st = _ds(buf)
+        check(lib.lf_ntt(_p(buf), batch, rows, logN, _p(psi), _p(Rs), _p(c._2q), *c.mont(), dev, st), "lf_ntt")
+
+    def intt(self, buf, batch, rows, logN, ipsi, Ninv, tail, c: Consts):
+        dev, st = _ds(buf)
+        check(lib.lf_intt(_p(buf), batch, rows, logN, _p(ipsi), _p(Ninv), tail, _p(c._2q), *c.mont(), dev, st), "lf_intt")
+
+    def galois(self, a, dst, rows, logN, p, _2q):
+        dev, st = _ds(a)
+        check(lib.lf_galois(_p(a), _p(dst), rows, logN, p, _p(_2q), dev, st), "lf_galois")
+
+    # ---- fused engine ops ------------------------------------------------------------------------
+    def rescale(self, src, row0, out, rows, scales, round_at, c: Consts):
+        dev, st = _ds(out)
+        check(lib.lf_rescale(_p(src), _p(row0), _p(out), rows, out.size(-1), _p(scales), round_at, *c.mont(), dev, st),
+              "lf_rescale")
+
+    def tensor(self, x0, x1, y0, y1, d0, d1, d2, rows, c: Consts):
+        dev, st = _ds(d0)
+        check(lib.lf_tensor(_p(x0), _p(x1), _p(y0), _p(y1), _p(d0), _p(d1), _p(d2), rows, d0.size(-1), *c.mont(), dev, st),
+              "lf_tensor")
+
+    def ks_digits(self, a, state, nparts, desc, tab, c: Consts):
+        dev, st = _ds(a)
+        check(lib.lf_ks_digits(_p(a), _p(state), nparts, _p(desc), _p(tab), a.size(-1), *c.mont(), dev, st), "lf_ks_digits")
+
+    def ks_extend(self, state, ext, nparts, rows, desc, E, c: Consts):
+        dev, st = _ds(ext)
+        check(lib.lf_ks_extend(_p(state), _p(ext), nparts, rows, ext.size(-1), _p(desc), _p(E), *c.mont(), dev, st),
+              "lf_ks_extend")
+
+    def ks_inner(self, ext, key, first_part, row_off, s0, s1, nparts, rows, c: Consts):
+        """key: packed [parts, 2, rows0, N] tensor of this device."""
+        dev, st = _ds(ext)
+        N = ext.size(-1)
+        part_stride, comp_stride = key.stride(0), key.stride(1)
+        base = key.data_ptr() + first_part * part_stride * 8
+        check(lib.lf_ks_inner(_p(ext), base, part_stride, comp_stride, row_off, _p(s0), _p(s1), nparts, rows, N,
+                              *c.mont(), dev, st), "lf_ks_inner")
+
+    def ks_moddown(self, s, out, addend, ell, K, PiR, Rs, c: Consts):
+        dev, st = _ds(out)
+        check(lib.lf_ks_moddown(_p(s), _p(out), _p(addend), ell, K, out.size(-1), _p(PiR), _p(Rs), *c.mont(), dev, st),
+              "lf_ks_moddown")

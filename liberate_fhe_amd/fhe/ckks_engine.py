@@ -1,0 +1,991 @@
+"""`ckks_engine`: the RNS-CKKS evaluator, API mirror of the reference's src/liberate/fhe/ckks_engine.py.
+
+Same constructor, method names, argument meaning, state checks and exceptions as the reference class
+(`eng.py` below = that file), so code written against `liberate.fhe.ckks_engine` runs against this
+one.  What is different is underneath:
+
+  * the hot methods — `rescale`, `cc_mult`, `relinearize`, `create_switcher` / `switch_key`,
+    `rotate_single`, `conjugate` — do not replay the reference's ~100 tiny launches per key switch;
+    each is a handful of fused HIP kernels (include/ckks_hip.h, "engine-level fused ops") whose
+    per-word arithmetic is op-for-op the reference's, so results are bit-identical;
+  * key-switch keys live in ONE packed tensor per GPU ([parts, 2, rows, N]); the `data_struct`s the
+    reference API exposes are views into it, so the inner product streams the key with plain strides;
+  * RNS limbs shard over GPUs by the reference's `rns_partition`, but the two exchange steps
+    (rescale row broadcast eng.py:999-1011, key-switch digit gather eng.py:778-810) go through a
+    `comm` object — RCCL broadcast / all-gather over xGMI with one process per GPU — instead of
+    pinned-host staging.  With `comm=None` one process drives every listed device, as the reference does.
+
+Data lists (`data_struct.data[i]`) hold one tensor per LOCAL participating device, ordered by device id
+— identical to the reference's layout when one process owns all devices.
+"""
+from __future__ import annotations
+
+import math
+from hashlib import sha256
+
+import numpy as np
+import torch
+
+from ..csprng import Csprng
+from ..ntt import ntt_context
+from . import encdec
+from .backend import Consts
+from .context.ckks_context import ckks_context
+from .data_struct import data_struct
+from .presets import errors, types
+from .version import VERSION
+
+
+class ckks_engine:
+    @errors.log_error
+    def __init__(self, devices: list[int] = None, verbose: bool = False, bias_guard: bool = True,
+                 norm: str = "forward", backend=None, comm=None, **ctx_params):
+        if backend is None:
+            from .backend import HipBackend  # raises if libckks_hip.so is missing: no fallback
+            backend = HipBackend()
+        self.backend = backend
+        self.comm = comm
+        self.bias_guard = bias_guard
+        self.norm = norm
+        self.version = VERSION
+        self.ctx = ckks_context(**ctx_params)
+
+        if comm is not None and comm.world_size > 1:
+            local = devices[0] if devices else comm.local_device
+            logical, local_ids = [local] * comm.world_size, [comm.rank]
+        else:
+            logical, local_ids = devices, None
+        self.ntt = ntt_context(self.ctx, devices=logical, verbose=verbose, ops=backend.ops, local_ids=local_ids)
+        self.local_ids = self.ntt.local_ids
+        self.num_levels = self.ntt.num_levels - 1
+        self.num_slots = self.ctx.N // 2
+
+        shared_seed = None
+        if comm is not None and comm.world_size > 1:
+            shared_seed = comm.broadcast_int(int.from_bytes(np.random.bytes(7), "little"), src=0)
+        self.rng = Csprng(self.ctx.N, [len(di) for di in self.ntt.p.d], max(self.ntt.num_special_primes, 2),
+                          devices=self.ntt.devices, shared_seed=shared_seed, local_ids=self.local_ids)
+
+        self.int_scale = 2 ** self.ctx.scale_bits
+        self.scale = np.float64(self.int_scale)
+        qstr = ",".join(str(qi) for qi in self.ctx.q)
+        self.hash = sha256((self.ctx.generation_string + "_" + qstr).encode("utf-8")).hexdigest()
+
+        self.make_adjustments_and_corrections()
+        self.device0 = self.ntt.devices[0]
+        self.make_mont_PR()
+        self.create_ksk_rescales()
+        self.alloc_parts()
+        self.leveled_devices()
+        self.create_rescale_scales()
+        self.galois_deltas = [2 ** i for i in range(self.ctx.logN - 1)]
+        self._tables = {}
+        self._key_packs = {}
+        self._workspace = {}
+
+        ds, nd, ls = data_struct, np.ndarray, list
+        self.mult_dispatch_dict = {(ds, ds): self.auto_cc_mult}
+        self.add_dispatch_dict = {(ds, ds): self.auto_cc_add}
+        self.sub_dispatch_dict = {(ds, ds): self.auto_cc_sub}
+
+    # =============================================================================================
+    # small helpers
+    # =============================================================================================
+    def _t64(self, values, dev_id):
+        return torch.tensor(values, dtype=torch.int64, device=self.ntt.devices[dev_id])
+
+    def _loc(self, level, special=False):
+        """Local device ids that hold rows at `level` (ordinary rows unless special=True)."""
+        alive = range(self.ntt.num_devices) if special else range(self.len_devices[level])
+        return [d for d in alive if d in self.local_ids]
+
+    def _consts(self, dev, level, special):
+        """Montgomery constants of device `dev`'s row range at `level`."""
+        key = ("consts", dev, level, special)
+        if key not in self._tables:
+            a, b = self.ntt.starts[level][dev], self.ntt.stops[0 if special else 1][dev]
+            n = self.ntt
+            self._tables[key] = Consts(n.ql[dev][a:b], n.qh[dev][a:b], n.kl[dev][a:b], n.kh[dev][a:b], n._2q[dev][a:b])
+        return self._tables[key]
+
+    def _rows(self, dev, level, special):
+        return self.ntt.stops[0 if special else 1][dev] - self.ntt.starts[level][dev]
+
+    def _tw(self, dev, level, special, inverse=False):
+        a, b = self.ntt.starts[level][dev], self.ntt.stops[0 if special else 1][dev]
+        return (self.ntt.ipsi if inverse else self.ntt.psi)[dev][a:b]
+
+    def _vec(self, name, dev, level, special):
+        a, b = self.ntt.starts[level][dev], self.ntt.stops[0 if special else 1][dev]
+        return getattr(self.ntt, name)[dev][a:b]
+
+    def _ws(self, key, shape, dev_id):
+        """Reusable scratch tensor (never returned to the caller)."""
+        k = (key, tuple(shape), dev_id)
+        t = self._workspace.get(k)
+        if t is None:
+            t = torch.empty(shape, dtype=torch.int64, device=self.ntt.devices[dev_id])
+            self._workspace[k] = t
+        return t
+
+    # =============================================================================================
+    # pre-calculations (eng.py:123-263)
+    # =============================================================================================
+    def create_rescale_scales(self):
+        """rescale_scales[level][dev][i] = q_level^-1 * R mod q_i over the rows that survive (eng.py:123-146)."""
+        self.rescale_scales = []
+        for level in range(self.num_levels):
+            per_dev = []
+            m0 = self.ctx.q[level]
+            for dev, dest in enumerate(self.ntt.p.destination_arrays[level]):
+                rows = dest[1:] if dev == self.ntt.p.rescaler_loc[level] else dest
+                vals = [pow(m0, -1, self.ctx.q[i]) * self.ctx.R % self.ctx.q[i] for i in rows]
+                per_dev.append(self._t64(vals if dev in self.local_ids else [], dev))
+            self.rescale_scales.append(per_dev)
+
+    def leveled_devices(self):
+        self.len_devices = [len([a for a in self.ntt.p.p[level] if len(a) > 0]) for level in range(self.num_levels)]
+        self.neighbor_devices = [
+            [[d for d in range(n) if d != src] for src in range(n)] for n in self.len_devices
+        ]
+
+    def alloc_parts(self):
+        self.parts_alloc = []
+        for level in range(self.num_levels):
+            counts = [len(parts) for parts in self.ntt.p.p[level]]
+            self.parts_alloc.append(
+                [alloc[-counts[d] - 1:-1] for d, alloc in enumerate(self.ntt.p.part_allocations)])
+        self.stor_ids = []
+        for level in range(self.num_levels):
+            alloc = self.parts_alloc[level]
+            min_id = min(min(a) for a in alloc if len(a) > 0)
+            self.stor_ids.append([[i - min_id for i in a] for a in alloc])
+
+    def create_ksk_rescales(self):
+        """PiRs[level][P_ind][dev][row] = P_j^-1 * R mod q_row, specials last-first (eng.py:183-216)."""
+        R, K = self.ctx.R, self.ntt.num_special_primes
+        P = self.ctx.q[-K:][::-1]
+        self.PiRs = [[]]
+        for P_ind, Pj in enumerate(P):
+            per_dev = []
+            for dev in range(self.ntt.num_devices):
+                dest = self.ntt.p.destination_arrays_with_special[0][dev]
+                vals = [pow(Pj, -1, self.ctx.q[i]) * R % self.ctx.q[i] for i in dest[:-P_ind - 1]]
+                per_dev.append(self._t64(vals if dev in self.local_ids else [], dev))
+            self.PiRs[0].append(per_dev)
+        for level in range(1, self.num_levels):
+            self.PiRs.append([[self.PiRs[0][P_ind][dev][self.ntt.starts[level][dev]:]
+                               for dev in range(self.ntt.num_devices)] for P_ind in range(K)])
+
+    def make_mont_PR(self):
+        P = math.prod(self.ctx.q[-self.ntt.num_special_primes:])
+        PR = P * self.ctx.R
+        self.mont_PR = []
+        for dev in range(self.ntt.num_devices):
+            dest = self.ntt.p.destination_arrays[0][dev] if dev in self.local_ids else []
+            self.mont_PR.append(self._t64([PR % self.ctx.q[i] for i in dest], dev))
+
+    def make_adjustments_and_corrections(self):
+        q, ns = self.ctx.q, self.ctx.num_scales
+        self.alpha = [(self.scale / np.float64(qi)) ** 2 for qi in q[:ns]]
+        self.deviations = [1]
+        for al in self.alpha:
+            self.deviations.append(self.deviations[-1] ** 2 * al)
+        self.final_q_ind = [da[0][0] for da in self.ntt.p.destination_arrays[:-1]]
+        self.final_q = [q[i] for i in self.final_q_ind]
+        self.final_alpha = [self.scale / np.float64(x) for x in self.final_q]
+        self.corrections = [1 / (d * fa) for d, fa in zip(self.deviations, self.final_alpha)]
+        self.base_prime = q[self.ntt.p.base_prime_idx]
+        self.final_scalar = [self._t64([pow(x, -1, self.base_prime) * self.ctx.R % self.base_prime], 0)
+                             for x in self.final_q]
+
+    # =============================================================================================
+    # examples, encode / decode (eng.py:269-343)
+    # =============================================================================================
+    def absmax_error(self, x, y):
+        if type(x[0]) == np.complex128 and type(y[0]) == np.complex128:
+            return np.abs(x.real - y.real).max() + np.abs(x.imag - y.imag).max() * 1j
+        return np.abs(np.array(x) - np.array(y)).max()
+
+    def integral_bits_available(self):
+        return math.floor(math.log2(self.base_prime)) - self.ctx.scale_bits
+
+    @errors.log_error
+    def example(self, amin=None, amax=None, decimal_places: int = 10) -> np.array:
+        if amin is None:
+            amin = -(2 ** self.integral_bits_available())
+        if amax is None:
+            amax = 2 ** self.integral_bits_available()
+        base = 10 ** decimal_places
+        a = np.random.randint(amin * base, amax * base, self.ctx.N // 2) / base
+        b = np.random.randint(amin * base, amax * base, self.ctx.N // 2) / base
+        return a + b * 1j
+
+    def padding(self, m):
+        try:
+            return np.pad(m, (0, self.num_slots - len(m)), constant_values=(0, 0))
+        except TypeError:
+            return np.pad([m], (0, self.num_slots - 1), constant_values=(0, 0))
+        except Exception:
+            raise Exception("[Error] encoding Padding Error.")
+
+    def _replicate_plain(self, pt):
+        """The encoded polynomial on every local device (reference: pinned-host broadcast, eng.py:327-331).
+        Every rank encodes with the shared random stream, so no exchange is needed."""
+        return [pt.to(self.ntt.devices[d]) for d in self.local_ids]
+
+    @errors.log_error
+    def encode(self, m, level: int = 0, padding=True) -> list[torch.Tensor]:
+        if padding:
+            m = self.padding(m)
+        dev0 = self.ntt.devices[self.local_ids[0]]
+        pt = encdec.encode(m, scale=self.scale, rng=self.rng, device=dev0, deviation=self.deviations[level], norm=self.norm)
+        return self._replicate_plain(pt)
+
+    @errors.log_error
+    def decode(self, m, level=0, is_real: bool = False) -> list:
+        decoded = encdec.decode(m[0].squeeze(), scale=self.scale, correction=self.corrections[level], norm=self.norm)
+        out = decoded[:self.ctx.N // 2].cpu().numpy()
+        return out.real if is_real else out
+
+    # =============================================================================================
+    # keys (eng.py:350-411, 601-652, 1054-1070, 1157-1232, 1694-1716)
+    # =============================================================================================
+    def _new(self, data, origin, level=0, include_special=False, ntt_state=False, montgomery_state=False):
+        return data_struct(data=data, include_special=include_special, ntt_state=ntt_state,
+                           montgomery_state=montgomery_state, origin=origin, level=level, hash=self.hash,
+                           version=self.version)
+
+    def _live(self, xs):
+        return [x for x in xs if x is not None]
+
+    @errors.log_error
+    def create_secret_key(self, include_special: bool = True) -> data_struct:
+        ternary = self._live(self.rng.randint(amax=3, shift=-1, repeats=1))
+        mult_type = -2 if include_special else -1
+        sk = self.ntt.tile_unsigned(ternary, lvl=0, mult_type=mult_type)
+        self.ntt.enter_ntt(sk, 0, mult_type)
+        return self._new(sk, types.origins["sk"], include_special=include_special, ntt_state=True, montgomery_state=True)
+
+    @errors.log_error
+    def create_public_key(self, sk: data_struct, include_special: bool = False, a: list[torch.Tensor] = None) -> data_struct:
+        """pk = (e - a*sk, a) in NTT / Montgomery form (eng.py:369-411)."""
+        if sk.origin != types.origins["sk"]:
+            raise errors.NotMatchType(origin=sk.origin, to=types.origins["sk"])
+        if include_special and not sk.include_special:
+            raise errors.SecretKeyNotIncludeSpecialPrime()
+        mult_type = -2 if include_special else -1
+        e = self._live(self.rng.discrete_gaussian(repeats=1))
+        e = self.ntt.tile_unsigned(e, 0, mult_type)
+        self.ntt.enter_ntt(e, 0, mult_type)
+        repeats = self.ctx.num_special_primes if sk.include_special else 0
+        if a is None:
+            a = self._live(self.rng.randint(self._moduli(mult_type), repeats=repeats))
+        sa = self.ntt.mont_mult(a, sk.data, 0, mult_type)
+        pk0 = self.ntt.mont_sub(e, sa, 0, mult_type)
+        return self._new((pk0, a), types.origins["pk"], include_special=include_special, ntt_state=True, montgomery_state=True)
+
+    def _moduli(self, mult_type):
+        """Per-device moduli lists for the uniform sampler (all devices, so the shared stream lines up)."""
+        stop = self.ntt.stops[0 if mult_type == -2 else 1]
+        return [[self.ctx.q[i] for i in self.ntt.p.d_special[d][:stop[d]]] for d in range(self.ntt.num_devices)]
+
+    def create_key_switching_key(self, sk_from: data_struct, sk_to: data_struct, a=None) -> data_struct:
+        """ksk[part] = pk-like (e - a*sk_to + [P*sk_from on that part's rows], a), eng.py:601-652.
+        All parts of one device are stored in ONE packed tensor [parts, 2, rows, N]."""
+        if sk_from.origin != types.origins["sk"] or sk_to.origin != types.origins["sk"]:
+            raise errors.NotMatchType(origin="not a secret key", to=types.origins["sk"])
+        if (not sk_from.ntt_state) or (not sk_from.montgomery_state):
+            raise errors.NotMatchDataStructState(origin=sk_from.origin)
+        if (not sk_to.ntt_state) or (not sk_to.montgomery_state):
+            raise errors.NotMatchDataStructState(origin=sk_to.origin)
+
+        p = self.ntt.p
+        loc = self._loc(0, special=True)
+        stops = self.ntt.stops[-1]
+        Psk = [sk_from.data[i][:stops[d]].clone() for i, d in enumerate(loc)]
+        self.ntt.mont_enter_scalar(Psk, [self.mont_PR[d] for d in loc], 0)
+
+        nparts = p.num_partitions + 1
+        packs = [torch.empty((nparts, 2, self.ntt.stops[0][d], self.ctx.N), dtype=torch.int64,
+                             device=self.ntt.devices[d]) for d in loc]
+        ksk = [[] for _ in range(nparts)]
+        for owner in range(self.ntt.num_devices):
+            for part_id, part in enumerate(p.p[0][owner]):
+                gid = p.part_allocations[owner][part_id]
+                crs = a[gid] if a else None
+                pk = self.create_public_key(sk_to, include_special=True, a=crs)
+                b_views, a_views = [], []
+                for i, d in enumerate(loc):
+                    packs[i][gid, 0].copy_(pk.data[0][i])
+                    packs[i][gid, 1].copy_(pk.data[1][i])
+                    b_views.append(packs[i][gid, 0])
+                    a_views.append(packs[i][gid, 1])
+                if owner in loc:
+                    i = loc.index(owner)
+                    lo, hi = part[0], part[-1] + 1
+                    shard = b_views[i][lo:hi]
+                    _2q = self.ntt.parts_pack[owner][tuple(part)]["_2q"]
+                    shard.copy_(self.backend.ops.mont_add([shard], [Psk[i][lo:hi]], _2q)[0])
+                ksk[gid] = pk._replace(data=(b_views, a_views), origin=f"key switch key part index {gid}")
+        out = self._new(ksk, types.origins["ksk"], include_special=True, ntt_state=True, montgomery_state=True)
+        self._key_packs[id(out.data)] = (out.data, packs)
+        return out
+
+    def create_evk(self, sk: data_struct) -> data_struct:
+        if sk.origin != types.origins["sk"]:
+            raise errors.NotMatchType(origin=sk.origin, to=types.origins["sk"])
+        sk2 = self._new(self.ntt.mont_mult(sk.data, sk.data, 0, -2), types.origins["sk"], level=sk.level,
+                        include_special=True, ntt_state=True, montgomery_state=True)
+        return self.create_key_switching_key(sk2, sk)
+
+    def _permuted_secret(self, sk, exponent):
+        """sk(X^p) in NTT / Montgomery form (eng.py:1161-1164, 1701-1704)."""
+        loc = self._loc(0, special=True)
+        out = []
+        for i, d in enumerate(loc):
+            t = sk.data[i].clone()
+            rows = self._rows(d, 0, special=False)
+            c = self._consts(d, 0, False)
+            self.backend.intt(t, 1, rows, self.ctx.logN, self._tw(d, 0, False, True), self._vec("Ninv", d, 0, False), 0, c)
+            r = torch.zeros_like(t)
+            self.backend.galois(t, r, rows, self.ctx.logN, exponent, None)
+            self.backend.ntt(r, 1, rows, self.ctx.logN, self._tw(d, 0, False), None, c)
+            out.append(r)
+        return self._new(out, types.origins["sk"], ntt_state=True, montgomery_state=True)
+
+    def create_rotation_key(self, sk: data_struct, delta: int, a: list[torch.Tensor] = None) -> data_struct:
+        if sk.origin != types.origins["sk"]:
+            raise errors.NotMatchType(origin=sk.origin, to=types.origins["sk"])
+        sk_rot = self._permuted_secret(sk, encdec.galois_exponent(self.ctx.N, delta))
+        rotk = self.create_key_switching_key(sk_rot, sk, a=a)
+        out = rotk._replace(origin=types.origins["rotk"] + f"{delta}")
+        self._key_packs[id(out.data)] = self._key_packs[id(rotk.data)]
+        return out
+
+    def create_galois_key(self, sk: data_struct) -> data_struct:
+        if sk.origin != types.origins["sk"]:
+            raise errors.NotMatchType(origin=sk.origin, to=types.origins["sk"])
+        parts = [self.create_rotation_key(sk, delta) for delta in self.galois_deltas]
+        return self._new(parts, types.origins["galk"], include_special=True, ntt_state=True, montgomery_state=True)
+
+    def create_conjugation_key(self, sk: data_struct) -> data_struct:
+        if sk.origin != types.origins["sk"]:
+            raise errors.NotMatchType(origin=sk.origin, to=types.origins["sk"])
+        if (not sk.ntt_state) or (not sk.montgomery_state):
+            raise errors.NotMatchDataStructState(origin=sk.origin)
+        sk_conj = self._permuted_secret(sk, encdec.conjugation_exponent(self.ctx.N))
+        k = self.create_key_switching_key(sk_conj, sk)
+        out = k._replace(origin=types.origins["conjk"])
+        self._key_packs[id(out.data)] = self._key_packs[id(k.data)]
+        return out
+
+    def _key_pack(self, ksk):
+        """Packed per-device key tensors of a key-switch key; foreign (unpacked) keys are packed once."""
+        hit = self._key_packs.get(id(ksk.data))
+        if hit is not None and hit[0] is ksk.data:
+            return hit[1]
+        loc = self._loc(0, special=True)
+        packs = []
+        for i, d in enumerate(loc):
+            parts = [torch.stack([part.data[0][i], part.data[1][i]]) for part in ksk.data]
+            packs.append(torch.stack(parts).contiguous())
+        self._key_packs[id(ksk.data)] = (ksk.data, packs)
+        return packs
+
+    # =============================================================================================
+    # encrypt / decrypt (eng.py:417-595, 1472-1688)
+    # =============================================================================================
+    def _encrypt_poly(self, encoded, pk, level, dc_rns=None):
+        mult_type = -2 if pk.include_special else -1
+        e0e1 = self._live(self.rng.discrete_gaussian(repeats=2))
+        e0 = self.ntt.tile_unsigned([e[0] for e in e0e1], level, mult_type)
+        e1 = self.ntt.tile_unsigned([e[1] for e in e0e1], level, mult_type)
+        pt = self.ntt.tile_unsigned(encoded, level, mult_type)
+        if dc_rns is not None:
+            for t, dc in zip(pt, dc_rns):
+                t[:, 0] += dc
+        self.ntt.mont_enter_scale(pt, level, mult_type)
+        self.ntt.mont_redc(pt, level, mult_type)
+        pte0 = self.ntt.mont_add(pt, e0, level, mult_type)
+
+        loc = self._loc(level, special=pk.include_special)
+        start = self.ntt.starts[level]
+        pk0 = [pk.data[0][i][start[d]:] for i, d in enumerate(loc)]
+        pk1 = [pk.data[1][i][start[d]:] for i, d in enumerate(loc)]
+        v = self._live(self.rng.randint(amax=2, shift=0, repeats=1))
+        v = self.ntt.tile_unsigned(v, level, mult_type)
+        self.ntt.enter_ntt(v, level, mult_type)
+        vpk0 = self.ntt.mont_mult(v, pk0, level, mult_type)
+        vpk1 = self.ntt.mont_mult(v, pk1, level, mult_type)
+        self.ntt.intt_exit(vpk0, level, mult_type)
+        self.ntt.intt_exit(vpk1, level, mult_type)
+        ct0 = self.ntt.mont_add(vpk0, pte0, level, mult_type)
+        ct1 = self.ntt.mont_add(vpk1, e1, level, mult_type)
+        self.ntt.reduce_2q(ct0, level, mult_type)
+        self.ntt.reduce_2q(ct1, level, mult_type)
+        return self._new((ct0, ct1), types.origins["ct"], level=level, include_special=mult_type == -2)
+
+    @errors.log_error
+    def encrypt(self, pt: list[torch.Tensor], pk: data_struct, level: int = 0) -> data_struct:
+        if pk.origin != types.origins["pk"]:
+            raise errors.NotMatchType(origin=pk.origin, to=types.origins["pk"])
+        return self._encrypt_poly([p.clone() for p in pt], pk, level)
+
+    def encodecrypt(self, m, pk: data_struct, level: int = 0, padding=True) -> data_struct:
+        if pk.origin != types.origins["pk"]:
+            raise errors.NotMatchType(origin=pk.origin, to=types.origins["pk"])
+        if padding:
+            m = self.padding(m=m)
+        dev0 = self.ntt.devices[self.local_ids[0]]
+        pt = encdec.encode(m, scale=self.scale, device=dev0, norm=self.norm, deviation=self.deviations[level],
+                           rng=self.rng, return_without_scaling=self.bias_guard)
+        dc_rns = None
+        if self.bias_guard:
+            dc_integral = pt[0].item() // 1
+            pt[0] -= dc_integral
+            dc_scale = int(dc_integral) * int(self.scale)
+            dc_rns = [self._t64([dc_scale % self.ctx.q[i] for i in self.ntt.p.destination_arrays[level][d]], d)
+                      for d in self._loc(level)]
+            pt = self.rng.randround(pt * np.float64(self.scale))
+        return self._encrypt_poly(self._replicate_plain(pt), pk, level, dc_rns)
+
+    def _decrypt_rows(self, ct, sk):
+        """pt rows on device 0 (c0 + c1*s, or the triplet form), canonical; eng.py:481-566."""
+        level = ct.level
+        sk0 = sk.data[0][self.ntt.starts[level][0]:]
+        if ct.origin == types.origins["ct"]:
+            if ct.ntt_state or ct.montgomery_state:
+                raise errors.NotMatchDataStructState(origin=ct.origin)
+            a = ct.data[1][0].clone()
+            self.ntt.enter_ntt([a], level)
+            sa = self.ntt.mont_mult([a], [sk0], level)
+            self.ntt.intt_exit(sa, level)
+            pt = self.ntt.mont_add([ct.data[0][0]], sa, level)
+        elif ct.origin == types.origins["ctt"]:
+            if not ct.ntt_state or not ct.montgomery_state:
+                raise errors.NotMatchDataStructState(origin=ct.origin)
+            d0 = [ct.data[0][0].clone()]
+            self.ntt.intt_exit_reduce(d0, level)
+            d1_s = self.ntt.mont_mult([ct.data[1][0]], [sk0], level)
+            s2 = self.ntt.mont_mult([sk0], [sk0], level)
+            d2_s2 = self.ntt.mont_mult([ct.data[2][0]], s2, level)
+            self.ntt.intt_exit(d1_s, level)
+            self.ntt.intt_exit(d2_s2, level)
+            pt = self.ntt.mont_add(d0, d1_s, level)
+            pt = self.ntt.mont_add(pt, d2_s2, level)
+        else:
+            raise errors.NotMatchType(origin=ct.origin, to=f"{types.origins['ct']} or {types.origins['ctt']}")
+        self.ntt.reduce_2q(pt, level)
+        return pt
+
+    def _final_scale(self, base, scaler, level, final_round):
+        """(base - scaler) * q_l^-1 mod base prime, centred, + rounding bit (eng.py:517-533)."""
+        scaled = self.ntt.mont_sub([base], [scaler], -1)
+        self.ntt.mont_enter_scalar(scaled, [self.final_scalar[level]], -1)
+        self.ntt.reduce_2q(scaled, -1)
+        self.ntt.make_signed(scaled, -1)
+        if final_round:
+            rounding_prime = self.ntt.qlists[0][-self.ctx.num_special_primes - 2]
+            scaled[0] += (scaler[0] > (rounding_prime // 2)) * 1
+        return scaled
+
+    def decrypt(self, ct: data_struct, sk: data_struct, final_round=True) -> list[torch.Tensor]:
+        if sk.origin != types.origins["sk"]:
+            raise errors.NotMatchType(origin=sk.origin, to=types.origins["sk"])
+        if not sk.ntt_state or not sk.montgomery_state:
+            raise errors.NotMatchDataStructState(origin=sk.origin)
+        if 0 not in self.local_ids:
+            return None  # the base-prime row lives on device 0
+        pt = self._decrypt_rows(ct, sk)
+        base_at = -self.ctx.num_special_primes - 1 if ct.include_special else -1
+        return self._final_scale(pt[0][base_at][None, :], pt[0][0][None, :], ct.level, final_round)
+
+    def decrypt_double(self, ct, sk, final_round=True):
+        if ct.origin != types.origins["ct"]:
+            raise errors.NotMatchType(origin=ct.origin, to=types.origins["ct"])
+        return self.decrypt(ct, sk, final_round)
+
+    def decrypt_triplet(self, ct_mult, sk, final_round=True):
+        if ct_mult.origin != types.origins["ctt"]:
+            raise errors.NotMatchType(origin=ct_mult.origin, to=types.origins["ctt"])
+        return self.decrypt(ct_mult, sk, final_round)
+
+    def decryptcode(self, ct: data_struct, sk: data_struct, is_real=False, final_round=True):
+        if (not sk.ntt_state) or (not sk.montgomery_state):
+            raise errors.NotMatchDataStructState(origin=sk.origin)
+        if 0 not in self.local_ids:
+            return None
+        level = ct.level
+        pt = self._decrypt_rows(ct, sk)
+        base_at = -self.ctx.num_special_primes - 1 if ct.include_special else -1
+        base = pt[0][base_at][None, :]
+        scaler = pt[0][0][None, :]
+        dest0 = self.ntt.p.destination_arrays[level][0]
+        guard = len(dest0) >= 3 and self.bias_guard
+        if guard:
+            # the DC coefficient is rebuilt from three residues by CRT in Python ints (eng.py:1616-1646)
+            dc0, dc1, dc2 = base[0][0].item(), scaler[0][0].item(), pt[0][1][0].item()
+            base[0][0] = 0
+            scaler[0][0] = 0
+            q0, q1, q2 = (self.ctx.q[dest0[base_at]], self.ctx.q[dest0[0]], self.ctx.q[dest0[1]])
+            Q, Q0, Q1, Q2 = q0 * q1 * q2, q1 * q2, q0 * q2, q0 * q1
+            dc = (dc0 * pow(Q0, -1, q0) * Q0 + dc1 * pow(Q1, -1, q1) * Q1 + dc2 * pow(Q2, -1, q2) * Q2) % Q
+            dc = dc if dc <= Q // 2 else dc - Q
+            dc = (dc + (q1 - 1)) // q1
+        scaled = self._final_scale(base, scaler, level, final_round)
+        correction = self.corrections[level]
+        decoded = encdec.decode(scaled[0][-1], scale=self.scale, correction=correction, norm=self.norm,
+                                return_without_scaling=self.bias_guard)
+        decoded = decoded[:self.ctx.N // 2].cpu().numpy()
+        decoded = decoded / self.scale * correction
+        if guard:
+            decoded += dc / self.scale * correction
+        return decoded.real if is_real else decoded
+
+    def encorypt(self, m, pk: data_struct, level: int = 0, padding=True):
+        return self.encodecrypt(m, pk=pk, level=level, padding=padding)
+
+    def decrode(self, ct: data_struct, sk: data_struct, is_real=False, final_round=True):
+        return self.decryptcode(ct=ct, sk=sk, is_real=is_real, final_round=final_round)
+
+    # =============================================================================================
+    # exchange steps
+    # =============================================================================================
+    def _share_rows(self, rows_by_owner, owner, targets, shape):
+        """Row block held by `owner` -> {device: tensor} on every local target device.
+        Reference: GPU -> pinned host -> GPU copies (eng.py:999-1011); here RCCL broadcast, or a
+        device-to-device copy when one process drives all devices."""
+        if self.comm is not None and self.comm.world_size > 1:
+            buf = rows_by_owner if owner in self.local_ids else None
+            buf = self.comm.broadcast(buf, src=owner, shape=shape, device=self.ntt.devices[self.local_ids[0]])
+            return {d: buf for d in targets if d in self.local_ids}
+        out = {}
+        for d in targets:
+            dev = self.ntt.devices[d]
+            out[d] = rows_by_owner if str(rows_by_owner.device) == dev else rows_by_owner.to(dev)
+        return out
+
+    # =============================================================================================
+    # rescale (eng.py:967-1052)
+    # =============================================================================================
+    def _rescale_into(self, ct, outs):
+        """Rescale ct (level l) writing component c of local device d into outs[c][d] ([rows, N] views)."""
+        level = ct.level
+        nxt = level + 1
+        owner = self.ntt.p.rescaler_loc[level]
+        loc_before = self._loc(level)
+        N = self.ctx.N
+        if owner in loc_before:
+            i = loc_before.index(owner)
+            row0 = torch.stack([ct.data[0][i][0], ct.data[1][i][0]])
+        else:
+            row0 = None
+        shared = self._share_rows(row0, owner, list(range(self.len_devices[nxt])), (2, N))
+        round_at = self.ctx.q[self.ntt.p.destination_arrays[level][owner][0]] // 2
+        for d in self._loc(nxt):
+            i = loc_before.index(d)
+            rows = self._rows(d, nxt, False)
+            c = self._consts(d, nxt, False)
+            for comp in range(2):
+                src = ct.data[comp][i]
+                src = src[1:] if d == owner else src
+                self.backend.rescale(src, shared[d][comp], outs[comp][d], rows, self.rescale_scales[level][d], round_at, c)
+
+    def rescale(self, ct: data_struct, exact_rounding=True) -> data_struct:
+        if ct.origin != types.origins["ct"]:
+            raise errors.NotMatchType(origin=ct.origin, to=types.origins["ct"])
+        nxt = ct.level + 1
+        if nxt >= self.num_levels:
+            raise errors.MaximumLevelError(level=ct.level, level_max=self.num_levels)
+        if not exact_rounding:
+            raise NotImplementedError("rescale without exact rounding is not provided (the reference default is exact)")
+        loc = self._loc(nxt)
+        outs = [{d: torch.empty((self._rows(d, nxt, False), self.ctx.N), dtype=torch.int64, device=self.ntt.devices[d])
+                 for d in loc} for _ in range(2)]
+        self._rescale_into(ct, outs)
+        return self._new(([outs[0][d] for d in loc], [outs[1][d] for d in loc]), types.origins["ct"], level=nxt)
+
+    # =============================================================================================
+    # multiplication (eng.py:1072-1151)
+    # =============================================================================================
+    def cc_mult(self, a: data_struct, b: data_struct, evk: data_struct, relin=True) -> data_struct:
+        if a.origin != types.origins["ct"]:
+            raise errors.NotMatchType(origin=a.origin, to=types.origins["sk"])
+        if b.origin != types.origins["ct"]:
+            raise errors.NotMatchType(origin=b.origin, to=types.origins["sk"])
+        level = a.level + 1
+        if level >= self.num_levels:
+            raise errors.MaximumLevelError(level=a.level, level_max=self.num_levels)
+        loc = self._loc(level)
+        N, logN = self.ctx.N, self.ctx.logN
+        d0, d1, d2 = [], [], []
+        stacks = {d: self._ws("mult4", (4, self._rows(d, level, False), N), d) for d in loc}
+        # x0, x1, y0, y1 are written by the two rescales straight into one [4, rows, N] stack per device
+        self._rescale_into(a, [{d: stacks[d][0] for d in loc}, {d: stacks[d][1] for d in loc}])
+        self._rescale_into(b, [{d: stacks[d][2] for d in loc}, {d: stacks[d][3] for d in loc}])
+        for d in loc:
+            rows = self._rows(d, level, False)
+            c = self._consts(d, level, False)
+            x = stacks[d]
+            self.backend.ntt(x, 4, rows, logN, self._tw(d, level, False), self._vec("Rs", d, level, False), c)
+            out = torch.empty((3, rows, N), dtype=torch.int64, device=self.ntt.devices[d])
+            self.backend.tensor(x[0], x[1], x[2], x[3], out[0], out[1], out[2], rows, c)
+            d0.append(out[0]); d1.append(out[1]); d2.append(out[2])
+        ct_mult = self._new((d0, d1, d2), types.origins["ctt"], level=level, ntt_state=True, montgomery_state=True)
+        return self.relinearize(ct_triplet=ct_mult, evk=evk) if relin else ct_mult
+
+    def relinearize(self, ct_triplet: data_struct, evk: data_struct) -> data_struct:
+        if ct_triplet.origin != types.origins["ctt"]:
+            raise errors.NotMatchType(origin=ct_triplet.origin, to=types.origins["ctt"])
+        if not ct_triplet.ntt_state or not ct_triplet.montgomery_state:
+            raise errors.NotMatchDataStructState(origin=ct_triplet.origin)
+        d0, d1, d2 = ct_triplet.data
+        level = ct_triplet.level
+        # the three inverse transforms mutate the triplet in place, as the reference does (eng.py:1127-1129)
+        for i, d in enumerate(self._loc(level)):
+            rows, c = self._rows(d, level, False), self._consts(d, level, False)
+            tw, ninv = self._tw(d, level, False, True), self._vec("Ninv", d, level, False)
+            stacked = self._as_stack([d0[i], d1[i], d2[i]])
+            if stacked is not None:
+                self.backend.intt(stacked, 3, rows, self.ctx.logN, tw, ninv, 2, c)
+            else:
+                for t in (d0[i], d1[i], d2[i]):
+                    self.backend.intt(t, 1, rows, self.ctx.logN, tw, ninv, 2, c)
+        c0, c1 = self.create_switcher(d2, evk, level, addends=(d0, d1))
+        return self._new((c0, c1), types.origins["ct"], level=level)
+
+    @staticmethod
+    def _as_stack(ts):
+        """The [k, rows, N] tensor whose slices are `ts`, if they are laid out back to back."""
+        t0 = ts[0]
+        step = t0.numel() * t0.element_size()
+        if all(t.is_contiguous() and t.shape == t0.shape and t.data_ptr() == t0.data_ptr() + i * step
+               and t.untyped_storage().data_ptr() == t0.untyped_storage().data_ptr() for i, t in enumerate(ts)):
+            return torch.as_strided(t0, (len(ts),) + tuple(t0.shape), (t0.numel(),) + tuple(t0.stride()))
+        return None
+
+    # =============================================================================================
+    # hybrid key switching (eng.py:654-961)
+    # =============================================================================================
+    def _ks_tables(self, level):
+        """Per-level descriptor tables of the fused key-switch kernels (built once, cached)."""
+        key = ("ks", level)
+        if key in self._tables:
+            return self._tables[key]
+        p, ctx = self.ntt.p, self.ctx
+        n_alive = self.len_devices[level]
+        # digits in storage order: (owner device, level-local rows, prime indices)
+        digits = {}
+        for d in range(n_alive):
+            for i, rows in enumerate(p.parts[level][d][:-1]):
+                digits[self.stor_ids[level][d][i]] = (d, rows, p.destination_parts[level][d][i])
+        order = [digits[s] for s in range(len(digits))]
+        row_start, acc = [], 0
+        for _, rows, _ in order:
+            row_start.append(acc)
+            acc += len(rows)
+        tabs = {"order": order, "row_start": row_start, "total_rows": acc, "first_part": min(
+            min(a) for a in self.parts_alloc[level] if len(a) > 0)}
+
+        for d in self._loc(level):
+            # (1) Garner constants of this device's own digits
+            desc, flat = [], []
+            for i, rows in enumerate(p.parts[level][d][:-1]):
+                Y, Ls, _ = self.ntt.digit_constants(p.destination_parts[level][d][i])
+                y_off = len(flat); flat += Y
+                l_off = len(flat); flat += [x for row in Ls for x in row]
+                desc.append([rows[0], len(rows), y_off, l_off])
+            tabs[("digits", d)] = (len(desc), self._t64(desc, d), self._t64(flat if flat else [0], d))
+            # (2) extension constants of EVERY digit onto this device's rows
+            dest = p.destination_arrays_with_special[level][d]
+            desc, flat = [], []
+            for s, (_, rows, primes) in enumerate(order):
+                m = [ctx.q[i] for i in primes]
+                e_off = len(flat)
+                L = 1
+                for i in range(len(m)):
+                    flat += [L * ctx.R_square[r] % ctx.q[r] for r in dest]
+                    L *= m[i]
+                desc.append([row_start[s], len(rows), e_off])
+            tabs[("extend", d)] = (self._t64(desc, d), self._t64(flat, d))
+            # (3) P_j^-1 R table, [K][rows]
+            K, nrows = self.ntt.num_special_primes, len(dest)
+            pir = torch.zeros((K, nrows), dtype=torch.int64, device=self.ntt.devices[d])
+            for P_ind in range(K):
+                v = self.PiRs[level][P_ind][d]
+                pir[P_ind, :len(v)] = v
+            tabs[("pir", d)] = pir
+        # (4) gather map for the digit all-gather (multi-device): row of the stacked per-device states
+        if n_alive > 1:
+            max_rows = max(self._rows(d, level, False) for d in range(n_alive))
+            idx = []
+            for d, rows, _ in order:
+                idx += [d * max_rows + r for r in rows]
+            tabs["gather"] = (max_rows, idx)
+        self._tables[key] = tabs
+        return tabs
+
+    def _gather_digits(self, states, level, tabs):
+        """Every alive device receives every digit (eng.py:778-810: the reference stages through pinned
+        host memory; here one RCCL all-gather, or peer copies inside one process).  Returns
+        {local device: [total_rows, N] digits in storage order}."""
+        n_alive = self.len_devices[level]
+        loc = self._loc(level)
+        if n_alive == 1:
+            return {loc[0]: states[loc[0]]} if loc else {}
+        max_rows, idx = tabs["gather"]
+        N = self.ctx.N
+        if self.comm is not None and self.comm.world_size > 1:
+            dev = self.ntt.devices[self.local_ids[0]]
+            mine = torch.zeros((max_rows, N), dtype=torch.int64, device=dev)
+            if loc:
+                mine[:states[loc[0]].size(0)] = states[loc[0]]
+            stacked = torch.cat(self.comm.all_gather(mine)[:n_alive])
+            index = torch.tensor(idx, dtype=torch.int64, device=dev)
+            return {d: stacked.index_select(0, index) for d in loc}
+        out = {}
+        for t in loc:
+            dev = self.ntt.devices[t]
+            pieces = []
+            for d, rows, _ in tabs["order"]:
+                pieces.append(states[d][rows[0]:rows[-1] + 1].to(dev))
+            out[t] = torch.cat(pieces)
+        return out
+
+    def create_switcher(self, a: list[torch.Tensor], ksk: data_struct, level, exit_ntt=False, addends=None) -> tuple:
+        """Key-switch the coefficient-domain polynomial `a` (one tensor per local device) under `ksk`.
+        Returns (c0, c1) lists of canonical [rows, N] tensors.  `addends` = optional (list, list) added
+        to (c0, c1) inside the last kernel (relinearize's d0/d1, switch_key's rotated c0)."""
+        tabs = self._ks_tables(level)
+        loc = self._loc(level)
+        N, logN, K = self.ctx.N, self.ctx.logN, self.ntt.num_special_primes
+        packs = self._key_pack(ksk)
+        loc0 = self._loc(0, special=True)
+
+        # 1. mixed-radix digits of the local parts
+        states = {}
+        for i, d in enumerate(loc):
+            src = a[i]
+            rows = self._rows(d, level, False)
+            if exit_ntt:
+                src = src.clone()
+                self.backend.intt(src, 1, rows, logN, self._tw(d, level, False, True), self._vec("Ninv", d, level, False),
+                                  2, self._consts(d, level, False))
+            st = self._ws("ks_state", (rows, N), d)
+            nparts, desc, tab = tabs[("digits", d)]
+            self.backend.ks_digits(src, st, nparts, desc, tab, self._consts(d, level, False))
+            states[d] = st
+        # 2. digit gather
+        digits = self._gather_digits(states, level, tabs)
+
+        nparts = len(tabs["order"])
+        c0, c1 = [], []
+        for i, d in enumerate(loc):
+            rows, ell = self._rows(d, level, True), self._rows(d, level, False)
+            cs = self._consts(d, level, True)
+            # 3. extend every digit to this device's rows, forward NTT
+            ext = self._ws("ks_ext", (nparts, rows, N), d)
+            desc, E = tabs[("extend", d)]
+            self.backend.ks_extend(digits[d], ext, nparts, rows, desc, E, cs)
+            self.backend.ntt(ext, nparts, rows, logN, self._tw(d, level, True), None, cs)
+            # 4. inner product with the key (streams the key once), inverse NTT
+            s = self._ws("ks_sum", (2, rows, N), d)
+            self.backend.ks_inner(ext, packs[loc0.index(d)], tabs["first_part"], self.ntt.starts[level][d], s[0], s[1],
+                                  nparts, rows, cs)
+            self.backend.intt(s, 2, rows, logN, self._tw(d, level, True, True), self._vec("Ninv", d, level, True), 2, cs)
+            # 5. divide by P (+ optional addend)
+            out = torch.empty((2, ell, N), dtype=torch.int64, device=self.ntt.devices[d])
+            rs = self._vec("Rs", d, level, True)
+            for comp in range(2):
+                add = addends[comp][i] if addends is not None and addends[comp] is not None else None
+                if add is not None and not add.is_contiguous():
+                    add = add.contiguous()
+                self.backend.ks_moddown(s[comp], out[comp], add, ell, K, tabs[("pir", d)], rs, cs)
+            c0.append(out[0]); c1.append(out[1])
+        return c0, c1
+
+    def switch_key(self, ct: data_struct, ksk: data_struct) -> data_struct:
+        if ct.origin != types.origins["ct"]:
+            raise errors.NotMatchType(origin=ct.origin, to=types.origins["ct"])
+        level = ct.level
+        c0, c1 = self.create_switcher(ct.data[1], ksk, level, exit_ntt=ct.ntt_state, addends=(ct.data[0], None))
+        return data_struct(data=(c0, c1), include_special=ct.include_special, ntt_state=ct.ntt_state,
+                           montgomery_state=ct.montgomery_state, origin=types.origins["ct"], level=level, hash=self.hash)
+
+    # =============================================================================================
+    # rotation / conjugation (eng.py:1180-1263, 1718-1734)
+    # =============================================================================================
+    def _automorphism(self, ct, exponent, key, canonical):
+        """X -> X^exponent on both components, then key-switch back.  `canonical`: fold the reference's
+        make_unsigned + reduce_2q (rotate_single does that, eng.py:1198-1200; conjugate does not and
+        key-switches the signed words, eng.py:1718-1734)."""
+        level = ct.level
+        loc = self._loc(level, special=ct.include_special)
+        rot0, rot1 = [], []
+        for i, d in enumerate(loc):
+            rows = ct.data[0][i].size(0)
+            r = torch.empty((2, rows, self.ctx.N), dtype=torch.int64, device=self.ntt.devices[d])
+            _2q = self._vec("_2q", d, level, ct.include_special) if canonical else None
+            for comp in range(2):
+                src = ct.data[comp][i]
+                self.backend.galois(src if src.is_contiguous() else src.contiguous(), r[comp], rows, self.ctx.logN,
+                                    exponent, _2q)
+            rot0.append(r[0]); rot1.append(r[1])
+        permuted = data_struct(data=(rot0, rot1), include_special=ct.include_special, ntt_state=ct.ntt_state,
+                               montgomery_state=ct.montgomery_state, origin=types.origins["ct"], level=level,
+                               hash=self.hash, version=self.version)
+        return self.switch_key(permuted, key)
+
+    def rotate_single(self, ct: data_struct, rotk: data_struct) -> data_struct:
+        if ct.origin != types.origins["ct"]:
+            raise errors.NotMatchType(origin=ct.origin, to=types.origins["ct"])
+        if types.origins["rotk"] not in rotk.origin:
+            raise errors.NotMatchType(origin=rotk.origin, to=types.origins["rotk"])
+        delta = int(rotk.origin.split(":")[-1])
+        return self._automorphism(ct, encdec.galois_exponent(self.ctx.N, delta), rotk, canonical=True)
+
+    def rotate_galois(self, ct: data_struct, gk: data_struct, delta: int, return_circuit=False) -> data_struct:
+        if ct.origin != types.origins["ct"]:
+            raise errors.NotMatchType(origin=ct.origin, to=types.origins["ct"])
+        if gk.origin != types.origins["galk"]:
+            raise errors.NotMatchType(origin=gk.origin, to=types.origins["galk"])
+        remaining = delta % (self.ctx.N // 2)
+        circuit = []
+        while remaining:
+            ind = int(math.log2(remaining))
+            circuit.append(ind)
+            remaining -= self.galois_deltas[ind]
+        out = ct
+        for ind in circuit:
+            out = self.rotate_single(out, gk.data[ind])
+        return (out, circuit) if return_circuit else out
+
+    def conjugate(self, ct: data_struct, conjk: data_struct):
+        return self._automorphism(ct, encdec.conjugation_exponent(self.ctx.N), conjk, canonical=False)
+
+    # =============================================================================================
+    # add / sub (eng.py:1268-1405)
+    # =============================================================================================
+    def _cc_linear(self, a, b, op, want):
+        if a.origin != types.origins[want] or b.origin != types.origins[want]:
+            raise errors.NotMatchType(origin=f"{a.origin} and {b.origin}", to=types.origins[want])
+        lazy = want == "ctt"
+        for x in (a, b):
+            if (x.ntt_state, x.montgomery_state) != (lazy, lazy):
+                raise errors.NotMatchDataStructState(origin=x.origin)
+        level = a.level
+        fn = self.ntt.mont_add if op == "add" else self.ntt.mont_sub
+        data = []
+        for xa, xb in zip(a.data, b.data):
+            c = fn(xa, xb, level)
+            self.ntt.reduce_2q(c, level)
+            data.append(c)
+        return self._new(data, types.origins[want], level=level, ntt_state=lazy, montgomery_state=lazy)
+
+    def cc_add_double(self, a, b):
+        return self._cc_linear(a, b, "add", "ct")
+
+    def cc_add_triplet(self, a, b):
+        return self._cc_linear(a, b, "add", "ctt")
+
+    def cc_sub_double(self, a, b):
+        return self._cc_linear(a, b, "sub", "ct")
+
+    def cc_sub_triplet(self, a, b):
+        return self._cc_linear(a, b, "sub", "ctt")
+
+    def cc_add(self, a: data_struct, b: data_struct) -> data_struct:
+        if a.origin == types.origins["ct"] and b.origin == types.origins["ct"]:
+            return self.cc_add_double(a, b)
+        if a.origin == types.origins["ctt"] and b.origin == types.origins["ctt"]:
+            return self.cc_add_triplet(a, b)
+        raise errors.DifferentTypeError(a=a.origin, b=b.origin)
+
+    def cc_sub(self, a: data_struct, b: data_struct) -> data_struct:
+        if a.origin != b.origin:
+            raise Exception("[Error] triplet error")
+        if a.origin == types.origins["ct"]:
+            return self.cc_sub_double(a, b)
+        if a.origin == types.origins["ctt"]:
+            return self.cc_sub_triplet(a, b)
+        raise errors.DifferentTypeError(a=a.origin, b=b.origin)
+
+    def cc_subtract(self, a, b):
+        return self.cc_sub(a, b)
+
+    # =============================================================================================
+    # level management and type-dispatched operators (eng.py:1410-1467, 2225-2283)
+    # =============================================================================================
+    def level_up(self, ct: data_struct, dst_level: int):
+        if types.origins["ct"] != ct.origin:
+            raise errors.NotMatchType(origin=ct.origin, to=types.origins["ct"])
+        new_ct = self.rescale(ct)
+        src_level = ct.level + 1
+        delta = round(self.scale * (self.deviations[dst_level] / np.sqrt(self.deviations[src_level])))
+        loc_src, loc_dst = self._loc(src_level), self._loc(dst_level)
+        data = []
+        for comp in range(2):
+            rows = []
+            for d in loc_dst:
+                t = new_ct.data[comp][loc_src.index(d)]
+                rows.append(t[t.size(0) - self._rows(d, dst_level, False):].clone())
+            data.append(rows)
+        mult = [self._t64([delta * self.ctx.R % self.ctx.q[i] for i in self.ntt.p.destination_arrays[dst_level][d]], d)
+                for d in loc_dst]
+        for comp in range(2):
+            self.ntt.mont_enter_scalar(data[comp], mult, dst_level)
+            self.ntt.reduce_2q(data[comp], dst_level)
+        return self._new(tuple(data), types.origins["ct"], level=dst_level)
+
+    def auto_level(self, ct0, ct1):
+        l0, l1 = ct0.level, ct1.level
+        if l0 < l1:
+            return self.level_up(ct0, l1), ct1
+        if l0 > l1:
+            return ct0, self.level_up(ct1, l0)
+        return ct0, ct1
+
+    def auto_cc_mult(self, ct0, ct1, evk, relin=True):
+        a, b = self.auto_level(ct0, ct1)
+        return self.cc_mult(a, b, evk, relin=relin)
+
+    def auto_cc_add(self, ct0, ct1):
+        a, b = self.auto_level(ct0, ct1)
+        return self.cc_add(a, b)
+
+    def auto_cc_sub(self, ct0, ct1):
+        a, b = self.auto_level(ct0, ct1)
+        return self.cc_sub(a, b)
+
+    def mult(self, a, b, evk=None, relin=True):
+        fn = self.mult_dispatch_dict.get((type(a), type(b)))
+        if fn is None:
+            raise NotImplementedError(f"mult for ({type(a).__name__}, {type(b).__name__}) is outside this build's scope")
+        return fn(a, b, evk, relin=relin)
+
+    def add(self, a, b):
+        fn = self.add_dispatch_dict.get((type(a), type(b)))
+        if fn is None:
+            raise NotImplementedError(f"add for ({type(a).__name__}, {type(b).__name__}) is outside this build's scope")
+        return fn(a, b)
+
+    def sub(self, a, b):
+        fn = self.sub_dispatch_dict.get((type(a), type(b)))
+        if fn is None:
+            raise NotImplementedError(f"sub for ({type(a).__name__}, {type(b).__name__}) is outside this build's scope")
+        return fn(a, b)
+
+    def square(self, ct: data_struct, evk: data_struct, relin=True) -> data_struct:
+        return self.cc_mult(ct, ct, evk, relin=relin)
+
+    def clone(self, text):
+        def rec(x):
+            if isinstance(x, torch.Tensor):
+                return x.clone()
+            if hasattr(x, "_replace") and hasattr(x, "data"):   # data_struct (this package's or a foreign one)
+                return x._replace(data=rec(x.data))
+            if isinstance(x, (list, tuple)):
+                return type(x)(rec(y) for y in x)
+            return x
+        return rec(text)

@@ -1,0 +1,1 @@
+from .ckks_context import ckks_context

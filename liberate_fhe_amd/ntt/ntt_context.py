@@ -34,14 +34,19 @@ from .rns_partition import rns_partition
 
 class ntt_context:
     @errors.log_error
-    def __init__(self, ctx, index_type=torch.int32, devices=None, verbose=False):
+    def __init__(self, ctx, index_type=torch.int32, devices=None, verbose=False, ops=None, local_ids=None):
+        """`ops`: module/object exposing the 15 `ntt_cuda` functions (default: the HIP shim).
+        `local_ids`: logical device ids whose rows this process materialises (default: all) — with one
+        process per GPU each rank passes its own id and the other devices' constant tensors stay empty."""
         t0 = time.time()
+        self.ops = ntt_cuda if ops is None else ops
         if devices is None:
             devices = [f"cuda:{i}" for i in range(torch.cuda.device_count())]
         self.devices = [f"cuda:{d}" if isinstance(d, int) else d for d in devices]
         if len(self.devices) == 0:
             raise RuntimeError("ntt_context: no GPU device given/visible; the HIP path has no CPU fallback")
         self.num_devices = len(self.devices)
+        self.local_ids = list(range(self.num_devices)) if local_ids is None else list(local_ids)
         self.index_type = index_type
         self.verbose = verbose
         self.ctx = ctx
@@ -75,8 +80,11 @@ class ntt_context:
     def partition_variable(self, variable):
         """Rows of `variable` (one per prime) gathered per GPU in that GPU's level-0 row order."""
         v = np.asarray(variable, dtype=np.int64)
-        return [torch.from_numpy(np.ascontiguousarray(v[rows])).to(dev)
-                for rows, dev in zip(self.p.d_special, self.devices)]
+        out = []
+        for dev_id, (rows, dev) in enumerate(zip(self.p.d_special, self.devices)):
+            rows = rows if dev_id in self.local_ids else []
+            out.append(torch.from_numpy(np.ascontiguousarray(v[rows])).to(dev))
+        return out
 
     def prepare_parameters(self):
         c = self.ctx
@@ -97,8 +105,9 @@ class ntt_context:
         # compact twiddle tables, entered into Montgomery form on device
         self.psi = self.partition_variable(c.psi_br)
         self.ipsi = self.partition_variable(c.ipsi_br)
-        ntt_cuda.mont_enter(self.psi, self.Rs, self.ql, self.qh, self.kl, self.kh)
-        ntt_cuda.mont_enter(self.ipsi, self.Rs, self.ql, self.qh, self.kl, self.kh)
+        live = lambda xs: [xs[i] for i in self.local_ids]
+        self.ops.mont_enter(live(self.psi), live(self.Rs), live(self.ql), live(self.qh), live(self.kl), live(self.kh))
+        self.ops.mont_enter(live(self.ipsi), live(self.Rs), live(self.ql), live(self.qh), live(self.kl), live(self.kh))
 
         self.mont_pack0 = [self.ql, self.qh, self.kl, self.kh]
         self.ntt_pack0 = [self.even, self.odd, self.psi, self._2q, self.ql, self.qh, self.kl, self.kh]
@@ -111,16 +120,16 @@ class ntt_context:
         pack = [param[dev][astart[dev]:astop[dev]] for dev in range(self.num_devices)]
         return [x for x in pack if len(x) > 0] if remove_empty else pack
 
-    def _alive(self, astart, astop):
-        return [dev for dev in range(self.num_devices) if astop[dev] > astart[dev]]
-
     def mont_pack(self, astart, astop, remove_empty=True):
         return [self.param_pack(x, astart, astop, remove_empty) for x in self.mont_pack0]
 
     def _transform_pack(self, pack0, astart, astop, remove_empty):
-        alive = self._alive(astart, astop) if remove_empty else range(self.num_devices)
-        tables = [[tab[dev] for dev in alive] for tab in pack0[:2]]
-        rest = [self.param_pack(x, astart, astop, remove_empty) for x in pack0[2:]]
+        rest = [self.param_pack(x, astart, astop, remove_empty=False) for x in pack0[2:]]
+        tables = [list(tab) for tab in pack0[:2]]
+        if remove_empty:
+            keep = [dev for dev in range(self.num_devices) if len(rest[0][dev]) > 0]
+            tables = [[tab[dev] for dev in keep] for tab in tables]
+            rest = [[x[dev] for dev in keep] for x in rest]
         return tables + rest
 
     def ntt_pack(self, astart, astop, remove_empty=True):
@@ -197,7 +206,8 @@ class ntt_context:
                     Y_scalar, L_scalar, L_enter = self.digit_constants(primes_idx)
                     if Y_scalar:
                         item["Y_scalar"] = t64(Y_scalar, dev)
-                        item["L_enter"] = [[t64(Li, tdev) for Li in L_enter[tdev]] for tdev in range(D)]
+                        item["L_enter"] = [[t64(Li, tdev) for Li in L_enter[tdev]] if tdev in self.local_ids else None
+                                           for tdev in range(D)]
                     else:
                         item["Y_scalar"] = None
                         item["L_enter"] = [None] * D
@@ -246,52 +256,52 @@ class ntt_context:
     # op wrappers (ntt_context.py:532-599)
     # ---------------------------------------------------------------------------------------------
     def mont_enter(self, a, lvl=0, mult_type=-1, part=0):
-        ntt_cuda.mont_enter(a, self.Rs_prepack[mult_type][lvl][part], *self.mont_prepack[mult_type][lvl][part])
+        self.ops.mont_enter(a, self.Rs_prepack[mult_type][lvl][part], *self.mont_prepack[mult_type][lvl][part])
 
     def mont_enter_scale(self, a, lvl=0, mult_type=-1, part=0):
-        ntt_cuda.mont_enter(a, self.Rs_scale_prepack[mult_type][lvl][part], *self.mont_prepack[mult_type][lvl][part])
+        self.ops.mont_enter(a, self.Rs_scale_prepack[mult_type][lvl][part], *self.mont_prepack[mult_type][lvl][part])
 
     def mont_enter_scalar(self, a, b, lvl=0, mult_type=-1, part=0):
-        ntt_cuda.mont_enter(a, b, *self.mont_prepack[mult_type][lvl][part])
+        self.ops.mont_enter(a, b, *self.mont_prepack[mult_type][lvl][part])
 
     def mont_mult(self, a, b, lvl=0, mult_type=-1, part=0):
-        return ntt_cuda.mont_mult(a, b, *self.mont_prepack[mult_type][lvl][part])
+        return self.ops.mont_mult(a, b, *self.mont_prepack[mult_type][lvl][part])
 
     def ntt(self, a, lvl=0, mult_type=-1, part=0):
-        ntt_cuda.ntt(a, *self.ntt_prepack[mult_type][lvl][part])
+        self.ops.ntt(a, *self.ntt_prepack[mult_type][lvl][part])
 
     def enter_ntt(self, a, lvl=0, mult_type=-1, part=0):
-        ntt_cuda.enter_ntt(a, self.Rs_prepack[mult_type][lvl][part], *self.ntt_prepack[mult_type][lvl][part])
+        self.ops.enter_ntt(a, self.Rs_prepack[mult_type][lvl][part], *self.ntt_prepack[mult_type][lvl][part])
 
     def intt(self, a, lvl=0, mult_type=-1, part=0):
-        ntt_cuda.intt(a, *self.intt_prepack[mult_type][lvl][part])
+        self.ops.intt(a, *self.intt_prepack[mult_type][lvl][part])
 
     def mont_redc(self, a, lvl=0, mult_type=-1, part=0):
-        ntt_cuda.mont_redc(a, *self.mont_prepack[mult_type][lvl][part])
+        self.ops.mont_redc(a, *self.mont_prepack[mult_type][lvl][part])
 
     def intt_exit(self, a, lvl=0, mult_type=-1, part=0):
-        ntt_cuda.intt_exit(a, *self.intt_prepack[mult_type][lvl][part])
+        self.ops.intt_exit(a, *self.intt_prepack[mult_type][lvl][part])
 
     def intt_exit_reduce(self, a, lvl=0, mult_type=-1, part=0):
-        ntt_cuda.intt_exit_reduce(a, *self.intt_prepack[mult_type][lvl][part])
+        self.ops.intt_exit_reduce(a, *self.intt_prepack[mult_type][lvl][part])
 
     def intt_exit_reduce_signed(self, a, lvl=0, mult_type=-1, part=0):
-        ntt_cuda.intt_exit_reduce_signed(a, *self.intt_prepack[mult_type][lvl][part])
+        self.ops.intt_exit_reduce_signed(a, *self.intt_prepack[mult_type][lvl][part])
 
     def reduce_2q(self, a, lvl=0, mult_type=-1, part=0):
-        ntt_cuda.reduce_2q(a, self._2q_prepack[mult_type][lvl][part])
+        self.ops.reduce_2q(a, self._2q_prepack[mult_type][lvl][part])
 
     def make_signed(self, a, lvl=0, mult_type=-1, part=0):
-        ntt_cuda.make_signed(a, self._2q_prepack[mult_type][lvl][part])
+        self.ops.make_signed(a, self._2q_prepack[mult_type][lvl][part])
 
     def make_unsigned(self, a, lvl=0, mult_type=-1, part=0):
-        ntt_cuda.make_unsigned(a, self._2q_prepack[mult_type][lvl][part])
+        self.ops.make_unsigned(a, self._2q_prepack[mult_type][lvl][part])
 
     def mont_add(self, a, b, lvl=0, mult_type=-1, part=0):
-        return ntt_cuda.mont_add(a, b, self._2q_prepack[mult_type][lvl][part])
+        return self.ops.mont_add(a, b, self._2q_prepack[mult_type][lvl][part])
 
     def mont_sub(self, a, b, lvl=0, mult_type=-1, part=0):
-        return ntt_cuda.mont_sub(a, b, self._2q_prepack[mult_type][lvl][part])
+        return self.ops.mont_sub(a, b, self._2q_prepack[mult_type][lvl][part])
 
     def tile_unsigned(self, a, lvl=0, mult_type=-1, part=0):
-        return ntt_cuda.tile_unsigned(a, self._2q_prepack[mult_type][lvl][part])
+        return self.ops.tile_unsigned(a, self._2q_prepack[mult_type][lvl][part])

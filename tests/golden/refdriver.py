@@ -31,132 +31,12 @@ def reference_available() -> bool:
     return os.path.isdir(os.path.join(REFERENCE_SRC, "liberate"))
 
 
-def _oracle():
-    if REPO not in sys.path:
-        sys.path.insert(0, REPO)
-    from oracle import oracle as orc
-    return orc
-
-
 def _make_ntt_cuda_standin():
     """`ntt_cuda` stand-in: reference signatures (ntt.cpp:8-113, 421-437), oracle arithmetic."""
-    orc = _oracle()
-    m = types.ModuleType("liberate.ntt.ntt_cuda")
-
-    def npv(t):
-        assert t.dtype in (torch.int64, torch.int32) and t.is_contiguous(), (t.dtype, t.is_contiguous())
-        return t.numpy()
-
-    def mont_mult(a, b, ql, qh, kl, kh):
-        out = []
-        for ai, bi, l, h, kl_, kh_ in zip(a, b, ql, qh, kl, kh):
-            c = torch.empty_like(ai)
-            rows = ai.size(0)
-            bb = bi if bi.is_contiguous() else bi.contiguous()
-            orc.mont_mult(npv(ai.contiguous()), npv(bb), npv(c), rows, npv(l), npv(h), npv(kl_), npv(kh_))
-            out.append(c)
-        return out
-
-    def _inplace(ai):
-        # the reference mutates views in place; numpy() of a contiguous view aliases the storage
-        if ai.is_contiguous():
-            return ai, None
-        tmp = ai.contiguous()
-        return tmp, ai
-
-    def mont_enter(a, Rs, ql, qh, kl, kh):
-        for ai, r, l, h, kl_, kh_ in zip(a, Rs, ql, qh, kl, kh):
-            w, back = _inplace(ai)
-            orc.mont_enter(npv(w), npv(r.contiguous()), w.size(0), npv(l), npv(h), npv(kl_), npv(kh_))
-            if back is not None:
-                back.copy_(w)
-
-    def ntt(a, even, odd, psi, _2q, ql, qh, kl, kh):
-        for ai, e, o, p, q2, l, h, kl_, kh_ in zip(a, even, odd, psi, _2q, ql, qh, kl, kh):
-            w, back = _inplace(ai)
-            orc.ntt_tab(npv(w), npv(e), npv(o), npv(p.contiguous()), l.size(0), npv(q2), npv(l), npv(h), npv(kl_), npv(kh_))
-            if back is not None:
-                back.copy_(w)
-
-    def enter_ntt(a, Rs, even, odd, psi, _2q, ql, qh, kl, kh):
-        for ai, r, e, o, p, q2, l, h, kl_, kh_ in zip(a, Rs, even, odd, psi, _2q, ql, qh, kl, kh):
-            w, back = _inplace(ai)
-            orc.enter_ntt_tab(npv(w), npv(r.contiguous()), npv(e), npv(o), npv(p.contiguous()), l.size(0),
-                              npv(q2), npv(l), npv(h), npv(kl_), npv(kh_))
-            if back is not None:
-                back.copy_(w)
-
-    def _intt_chain(a, even, odd, psi, Ninv, _2q, ql, qh, kl, kh, redc, reduce, signed):
-        for ai, e, o, p, ni, q2, l, h, kl_, kh_ in zip(a, even, odd, psi, Ninv, _2q, ql, qh, kl, kh):
-            w, back = _inplace(ai)
-            rows = l.size(0)
-            orc.intt_tab(npv(w), npv(e), npv(o), npv(p.contiguous()), npv(ni.contiguous()), rows,
-                         npv(q2), npv(l), npv(h), npv(kl_), npv(kh_))
-            # chains (K.cu:709-973) run their elementwise tails over the first `rows` rows
-            view = npv(w)[:rows]
-            if redc:
-                orc.mont_redc(view, rows, npv(l), npv(h), npv(kl_), npv(kh_))
-            if reduce:
-                orc.reduce_2q(view, rows, npv(q2))
-            if signed:
-                orc.make_signed(view, rows, npv(q2))
-            if back is not None:
-                back.copy_(w)
-
-    def intt(a, *args):
-        _intt_chain(a, *args, redc=False, reduce=False, signed=False)
-
-    def intt_exit(a, *args):
-        _intt_chain(a, *args, redc=True, reduce=False, signed=False)
-
-    def intt_exit_reduce(a, *args):
-        _intt_chain(a, *args, redc=True, reduce=True, signed=False)
-
-    def intt_exit_reduce_signed(a, *args):
-        _intt_chain(a, *args, redc=True, reduce=True, signed=True)
-
-    def mont_redc(a, ql, qh, kl, kh):
-        for ai, l, h, kl_, kh_ in zip(a, ql, qh, kl, kh):
-            w, back = _inplace(ai)
-            orc.mont_redc(npv(w), w.size(0), npv(l), npv(h), npv(kl_), npv(kh_))
-            if back is not None:
-                back.copy_(w)
-
-    def _fix(fn):
-        def op(a, _2q):
-            for ai, q2 in zip(a, _2q):
-                w, back = _inplace(ai)
-                fn(npv(w), w.size(0), npv(q2.contiguous()))
-                if back is not None:
-                    back.copy_(w)
-        return op
-
-    def _bin(fn):
-        def op(a, b, _2q):
-            out = []
-            for ai, bi, q2 in zip(a, b, _2q):
-                c = torch.empty_like(ai, memory_format=torch.contiguous_format)
-                fn(npv(ai.contiguous()), npv(bi.contiguous()), npv(c), ai.size(0), npv(q2.contiguous()))
-                out.append(c)
-            return out
-        return op
-
-    def tile_unsigned(a, _2q):
-        out = []
-        for ai, q2 in zip(a, _2q):
-            ai.squeeze_()
-            c = ai.new_empty((q2.size(0), ai.size(0)))
-            orc.tile_unsigned(npv(ai.contiguous()), npv(c), q2.size(0), npv(q2.contiguous()))
-            out.append(c)
-        return out
-
-    m.mont_mult, m.mont_enter, m.ntt, m.enter_ntt = mont_mult, mont_enter, ntt, enter_ntt
-    m.intt, m.intt_exit, m.intt_exit_reduce, m.intt_exit_reduce_signed = intt, intt_exit, intt_exit_reduce, intt_exit_reduce_signed
-    m.mont_redc = mont_redc
-    m.reduce_2q, m.make_signed, m.make_unsigned = _fix(orc.reduce_2q), _fix(orc.make_signed), _fix(orc.make_unsigned)
-    m.mont_add, m.mont_sub = _bin(orc.mont_add), _bin(orc.mont_sub)
-    m.tile_unsigned = tile_unsigned
-    return m
+    if REPO not in sys.path:
+        sys.path.insert(0, REPO)
+    from tests.oracle_backend import make_ops
+    return make_ops("liberate.ntt.ntt_cuda")
 
 
 class SeededCsprng:

@@ -1,0 +1,106 @@
+"""Engine hot path against the golden digests captured from the reference engine
+(tests/golden/engine_digests.json, generator tests/golden/make_golden.py).
+
+CPU leg: orchestration + checker backend (pins the composition-level oracle to the reference).
+GPU leg: the product — HIP kernels through the C ABI — on the same seeded inputs, bit-exact.
+"""
+import hashlib
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from liberate_fhe_amd.utils import synth
+
+warnings.filterwarnings("ignore", category=UserWarning)
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "engine_digests.json")))
+
+
+def digest(ct):
+    out = []
+    for comp in ct.data:
+        h = hashlib.sha256()
+        for t in comp:
+            h.update(np.ascontiguousarray(t.cpu().numpy()).tobytes())
+        out.append({"sha256": h.hexdigest(), "shape": [list(t.shape) for t in comp],
+                    "head": [int(x) for x in comp[0][0, :4].cpu()], "tail": [int(x) for x in comp[0][-1, -4:].cpu()]})
+    return out
+
+
+def check_config(engine, rec):
+    assert [int(x) for x in engine.ctx.q] == rec["q"] and engine.hash == rec["hash"]
+    s = rec["seeds"]
+    a, b = synth.ciphertext(engine, s["ct_a"], 0), synth.ciphertext(engine, s["ct_b"], 0)
+    evk = synth.key_switch_key(engine, s["evk"])
+    rotk = synth.key_switch_key(engine, s["rotk"], origin=f"rotation key:{s['rot_delta']}")
+    ops = rec["ops"]
+    assert digest(engine.rescale(a)) == ops["rescale(a)"]
+    prod = engine.cc_mult(a, b, evk)
+    assert digest(prod) == ops["cc_mult(a,b,evk)"]
+    assert digest(engine.rotate_single(a, rotk)) == ops["rotate_single(a,rotk)"]
+    assert digest(engine.rotate_single(prod, rotk)) == ops["rotate_single(cc_mult,rotk)"]
+    assert digest(engine.cc_add(a, b)) == ops["cc_add(a,b)"]
+    if "cc_mult(prod,prod,evk)" in ops:
+        assert digest(engine.cc_mult(prod, prod, evk)) == ops["cc_mult(prod,prod,evk)"]
+
+
+@pytest.mark.parametrize("name", ["small", "small_x2", "bronze", "silver"])
+def test_checker_engine_reproduces_reference_digests(name):
+    from liberate_fhe_amd.fhe import ckks_engine
+    from tests.oracle_backend import OracleBackend
+    rec = GOLD[name]
+    eng = ckks_engine(devices=["cpu"] * rec["n_devices"], backend=OracleBackend(), **rec["params"])
+    check_config(eng, rec)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small", "small_x2", "bronze", "silver", "gold"])
+def test_hip_engine_reproduces_reference_digests(name):
+    from liberate_fhe_amd.fhe import ckks_engine
+    rec = GOLD[name]
+    eng = ckks_engine(devices=["cuda:0"] * rec["n_devices"], **rec["params"])
+    check_config(eng, rec)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,n_dev", [("small", 1), ("small", 3), ("silver", 1), ("silver", 2)])
+def test_hip_engine_equals_checker_engine_on_fresh_seeds(name, n_dev):
+    """Seeds and device counts the fixtures do not cover: HIP engine vs the oracle composition."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    from tests.oracle_backend import OracleBackend
+    params = GOLD[name]["params"]
+    hip = ckks_engine(devices=["cuda:0"] * n_dev, **params)
+    chk = ckks_engine(devices=["cpu"] * n_dev, backend=OracleBackend(), **params)
+    outs = []
+    for eng in (hip, chk):
+        a, b = synth.ciphertext(eng, 101, 0), synth.ciphertext(eng, 102, 0)
+        evk, rotk = synth.key_switch_key(eng, 103), synth.key_switch_key(eng, 104, origin="rotation key:129")
+        conjk = synth.key_switch_key(eng, 105, origin="conjugation key")
+        prod = eng.cc_mult(a, b, evk)
+        deep = eng.cc_mult(prod, a if False else eng.level_up(a, 1), evk)
+        outs.append([digest(x) for x in (prod, deep, eng.rotate_single(deep, rotk), eng.conjugate(a, conjk),
+                                         eng.rescale(a), eng.cc_sub(a, b), eng.cc_mult(a, b, evk, relin=False))])
+    assert outs[0] == outs[1]
+
+
+@pytest.mark.gpu
+def test_hip_engine_end_to_end_decode_error():
+    """configs[2]: silver cc_mult + relinearize with real keys; decoded product within the reference's
+    own accuracy (~5e-8 on +-1 data) and identical across device splits."""
+    from liberate_fhe_amd.fhe import ckks_engine, presets
+    eng = ckks_engine(**{**presets.params["silver"], "devices": ["cuda:0"]})
+    sk = eng.create_secret_key()
+    pk = eng.create_public_key(sk)
+    evk = eng.create_evk(sk)
+    rotk = eng.create_rotation_key(sk, 11)
+    np.random.seed(3)
+    m1, m2 = eng.example(-1, 1), eng.example(-1, 1)
+    c1, c2 = eng.encorypt(m1, pk), eng.encorypt(m2, pk)
+    assert np.abs(eng.decrode(c1, sk) - m1).max() < 1e-8
+    prod = eng.cc_mult(c1, c2, evk)
+    assert np.abs(eng.decrode(prod, sk) - m1 * m2).max() < 2e-7
+    assert np.abs(eng.decrode(eng.rotate_single(prod, rotk), sk) - np.roll(m1 * m2, 11)).max() < 2e-7
+    assert np.abs(eng.decrode(eng.cc_add(c1, c2), sk) - (m1 + m2)).max() < 1e-8
