@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: NTTs/sec/GPU at logN=16, L=30 limbs (+ cc_mult_evk ops/sec), % of HBM roofline.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+One "step" = one forward negacyclic NTT (ntt_cuda.ntt semantics, bit-exact lazy outputs) of a batch of
+B polynomials x 30 RNS limbs at logN = 16 — the gold preset's with-special row set at level 9 (25 scale
+primes + base + 4 special primes).  B is sized so the working set (B x 30 MiB) exceeds the 256 MiB
+Infinity Cache.  Inputs are synthetic (splitmix64 -> mod 2q), resident in HBM before the timed region.
+Polynomials are independent, so ranks shard them with no data-path collective: weak scaling.
+
+The JSON line also carries
+  roofline     : the dominant kernel (ntt_fwd_pass, 2 launches per step) against the 8 TB/s HBM peak;
+                 algorithmic bytes per launch = 8*N*limbs (each pass streams the stack once; a transform
+                 is 16*N bytes per limb), duration from HIP events on the launch stream;
+  cpu_baseline : the C oracle (strict reference-kernel semantics) on this box's host cores, same workload,
+                 bounded sample;
+  extra        : cc_mult(+relinearize) ops/s for silver and gold on this rank, rotate ops/s, limb-NTT/s.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+L_LIMBS = 30
+LOGN = 16
+
+
+def event_time_ms(fn, iters):
+    """Average duration of fn() over `iters` calls, HIP events on torch's current stream (the stream
+    every C-ABI launch in this process uses)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def cpu_baseline(ctx, rows_idx, batch, budget_s=12.0):
+    """The oracle's NTT on the host cores over the same [batch*30, N] stack (OpenMP over rows)."""
+    from oracle import oracle as orc
+    h = lambda v: np.ascontiguousarray(np.tile(np.asarray([v[i] for i in rows_idx], dtype=np.int64), batch))
+    ql, qh, kl, kh = h(ctx.q_lower_bits), h(ctx.q_higher_bits), h(ctx.k_lower_bits), h(ctx.k_higher_bits)
+    q2, Rs = h(ctx.q_double), h(ctx.R_square)
+    psi = np.ascontiguousarray(np.tile(ctx.psi_br[rows_idx], (batch, 1)))
+    n = len(rows_idx) * batch
+    orc.mont_enter(psi, Rs, n, ql, qh, kl, kh)
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 1 << 40, size=(n, ctx.N), dtype=np.int64)
+    orc.ntt(x, psi, n, ctx.logN, q2, ql, qh, kl, kh)   # warm (page-in, thread pool)
+    t0, reps = time.time(), 0
+    while True:
+        orc.ntt(x, psi, n, ctx.logN, q2, ql, qh, kl, kh)
+        reps += 1
+        if time.time() - t0 > budget_s or reps >= 50:
+            break
+    dt = (time.time() - t0) / reps
+    threads = min(os.cpu_count() or 1, n)
+    return {"value": batch / dt, "unit": "poly-NTT(L=30,logN=16)/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} x forward NTT of {batch} polys x {len(rows_idx)} limbs, N=65536, C oracle + OpenMP over limb rows"}
+
+
+def engine_rates(dev, quick):
+    """cc_mult(+relinearize) and rotate_single ops/s on this rank for silver and gold (1 GPU each)."""
+    from liberate_fhe_amd.fhe import ckks_engine, presets
+    from liberate_fhe_amd.utils import synth
+    out = {}
+    for name in ("silver", "gold"):
+        eng = ckks_engine(**{**presets.params[name], "devices": [dev]})
+        a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
+        evk = synth.key_switch_key(eng, 5)
+        rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
+        for _ in range(2):
+            eng.cc_mult(a, b, evk)
+            eng.rotate_single(a, rotk)
+        torch.cuda.synchronize()
+        n = 5 if quick else 20
+        ms = event_time_ms(lambda: eng.cc_mult(a, b, evk), n)
+        out[f"cc_mult_evk_{name}_ops_per_s"] = 1e3 / ms
+        ms = event_time_ms(lambda: eng.rotate_single(a, rotk), n)
+        out[f"rotate_single_{name}_ops_per_s"] = 1e3 / ms
+        del eng, a, b, evk, rotk
+        torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=16, help="polynomials per step per GPU")
+    ap.add_argument("--no-extra", action="store_true", help="skip the cc_mult / rotate / CPU legs")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    import __graft_entry__ as g
+    if rank == 0:
+        g.build()
+    if world > 1:
+        dist.barrier()
+
+    from liberate_fhe_amd._native import lib, check
+    from liberate_fhe_amd.fhe.context.ckks_context import ckks_context
+    from liberate_fhe_amd.ntt import ntt_context
+    from liberate_fhe_amd.utils import synth
+
+    ctx = ckks_context(logN=LOGN, num_special_primes=4)          # gold
+    ntt = ntt_context(ctx, devices=[dev])
+    total = len(ctx.q)
+    rows_idx = list(range(total - L_LIMBS, total))
+    lo = total - L_LIMBS
+    N, B = ctx.N, args.batch
+    x = torch.empty((B, L_LIMBS, N), dtype=torch.int64, device=dev)
+    for b in range(B):
+        x[b] = torch.from_numpy(synth.uniform_rows(1000 * rank + b, rows_idx, ctx.q, N, lazy=True)).to(dev)
+    sl = lambda t: t[0][lo:]
+    psi, q2, ql, qh, kl, kh = (sl(t) for t in (ntt.psi, ntt._2q, ntt.ql, ntt.qh, ntt.kl, ntt.kh))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        check(lib.lf_ntt(x.data_ptr(), B, L_LIMBS, LOGN, psi.data_ptr(), 0, q2.data_ptr(), ql.data_ptr(), qh.data_ptr(),
+                         kl.data_ptr(), kh.data_ptr(), local_rank, stream), "lf_ntt")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1) / args.steps
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+    ms_per_step = wall / args.steps * 1e3
+
+    value = world * B / (wall / args.steps)                         # poly-NTT(30)/s, whole job
+    launches = 2                                                    # strided pass + contiguous pass
+    alg_bytes_per_launch = 8 * N * L_LIMBS * B
+    achieved = alg_bytes_per_launch / (dev_ms / launches * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("ntt_fwd_pass_bytes_per_launch")
+
+    result = {
+        "metric": "NTTs/sec (forward negacyclic poly-NTT, logN=16, L=30 limbs, bit-exact vs reference semantics)",
+        "value": value, "unit": "poly-NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int64", "data": "synthetic",
+        "config": {"workload": f"gold preset (logN=16), rows {lo}..{total - 1} of the prime chain (25 scale + base + 4 special"
+                               f" primes = 30 limbs), {B} polynomials per GPU per step, forward NTT via lf_ntt (C ABI)",
+                   "batch_per_gpu": B, "limbs": L_LIMBS, "logN": LOGN, "parallelism": f"replicas x{world} (independent polynomials)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "ntt_fwd_pass", "launches_per_step": launches, "avg_launch_ms": dev_ms / launches,
+                     "algorithmic_bytes_per_launch": alg_bytes_per_launch},
+    }
+    extra = {"limb_ntt_per_s": value * L_LIMBS, "device_ms_per_step": dev_ms}
+    if rank == 0 and world == 1 and not args.no_extra:
+        extra.update(engine_rates(dev, quick=False))
+        result["cpu_baseline"] = cpu_baseline(ctx, rows_idx, batch=B)
+    else:
+        result["cpu_baseline"] = None   # reported by the N=1 run only
+    result["extra"] = extra
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

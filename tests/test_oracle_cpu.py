@@ -1,0 +1,108 @@
+"""The CPU oracle against independent big-integer definitions (no GPU, no reference needed)."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests.helpers import Limbs, pick_primes, i64, R, LB
+from liberate_fhe_amd.fhe.context.ckks_context import bit_reverse_indices, stage_butterfly_indices
+
+
+def consts(q):
+    k = (R * pow(R, -1, q) - 1) // q
+    return q & LB, q >> 31, k & LB, k >> 31, k
+
+
+@pytest.mark.parametrize("q", [1099510054913, 1152921504606584833, 1152921504598720513])
+def test_mm_is_exact_redc_for_signed_inputs(q):
+    """mm(a,b) == (a*b + ((a*b*k) mod R)*q) / R exactly, for signed lazy operands."""
+    ql, qh, kl, kh, k = consts(q)
+    assert (k * q + 1) % R == 0
+    rnd = random.Random(q)
+    for _ in range(20000):
+        a, b = rnd.randrange(-2 * q + 1, 2 * q), rnd.randrange(-2 * q + 1, 2 * q)
+        x = a * b
+        want = (x + ((x * k) % R) * q) // R
+        assert (x + ((x * k) % R) * q) % R == 0
+        assert orc.mm_scalar(a, b, ql, qh, kl, kh) == want
+        if 0 <= a < 2 * q and 0 <= b < 2 * q:
+            assert 0 <= want < 2 * q and (want * R - a * b) % q == 0
+    for x in [0, 1, q - 1, q, 2 * q - 1] + [rnd.randrange(0, 2 * q) for _ in range(2000)]:
+        want = (x + ((x * k) % R) * q) // R
+        assert orc.redc_scalar(x, ql, qh, kl, kh) == want and 0 <= want <= q
+    assert orc.redc_scalar(q, ql, qh, kl, kh) == q   # redc(q) = q, not 0
+
+
+def test_rescale_known_answer():
+    """the signed REDC keeps the negative representative."""
+    q_l, q_i, d, s = 1099510054913, 1099515691009, 49326798554, 1033533601499
+    ql, qh, kl, kh, _ = consts(q_i)
+    scale = pow(q_l, -1, q_i) * R % q_i
+    got = orc.mm_scalar(d - s, scale, ql, qh, kl, kh)
+    assert got == -20459 and (got - (d - s) * pow(q_l, -1, q_i)) % q_i == 0
+
+
+@pytest.mark.parametrize("logN", [3, 6, 10])
+def test_ntt_is_evaluation_at_odd_powers_and_inverts(logN):
+    lim = Limbs(logN, pick_primes(logN, 2, 1))
+    psi, ipsi = lim.mont_tables()
+    N = lim.N
+    x = lim.uniform(1)
+    y = x.copy()
+    orc.mont_enter(y, lim.Rs, lim.rows, *lim.mont_args())
+    orc.ntt(y, psi, lim.rows, logN, lim._2q, *lim.mont_args())
+    brev = bit_reverse_indices(logN)
+    for r, q in enumerate(lim.q):
+        g = lim.root[r]
+        coeffs = [int(v) for v in x[r]]
+        for kk in range(0, N, max(1, N // 16)):
+            w = pow(g, 2 * int(brev[kk]) + 1, q)
+            val = 0
+            for c in reversed(coeffs):
+                val = (val * w + c) % q
+            assert 0 <= y[r, kk] < 2 * q and (int(y[r, kk]) - val * R) % q == 0
+    orc.intt(y, ipsi, lim.Ninv, lim.rows, logN, lim._2q, *lim.mont_args())
+    orc.mont_redc(y, lim.rows, *lim.mont_args())
+    orc.reduce_2q(y, lim.rows, lim._2q)
+    assert (y == x).all()
+
+
+@pytest.mark.parametrize("logN", [1, 2, 5, 9])
+def test_compact_and_table_driven_ntt_agree(logN):
+    """The formula-indexed oracle == the literal table-driven restatement of the reference launches."""
+    lim = Limbs(logN, pick_primes(logN, 2, 1))
+    psi, ipsi = lim.mont_tables()
+    ev, od, tw = stage_butterfly_indices(logN, False)
+    iev, iod, itw = stage_butterfly_indices(logN, True)
+    x = lim.uniform(3, lazy=True)
+    a, b = x.copy(), x.copy()
+    orc.ntt(a, psi, lim.rows, logN, lim._2q, *lim.mont_args())
+    orc.ntt_tab(b, ev, od, np.ascontiguousarray(psi[:, tw]), lim.rows, lim._2q, *lim.mont_args())
+    assert (a == b).all()
+    orc.intt(a, ipsi, lim.Ninv, lim.rows, logN, lim._2q, *lim.mont_args())
+    orc.intt_tab(b, iev, iod, np.ascontiguousarray(ipsi[:, itw]), lim.Ninv, lim.rows, lim._2q, *lim.mont_args())
+    assert (a == b).all()
+
+
+def test_stage_indices_cover_every_coefficient_once():
+    for logN in (1, 4, 7):
+        for inv in (False, True):
+            ev, od, tw = stage_butterfly_indices(logN, inv)
+            N = 1 << logN
+            for s in range(logN):
+                assert sorted(list(ev[s]) + list(od[s])) == list(range(N))
+                t = (1 << s) if inv else (N >> (s + 1))
+                assert ((od[s] - ev[s]) == t).all()
+
+
+def test_galois_matches_definition():
+    N, rows = 64, 2
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 1 << 40, size=(rows, N), dtype=np.int64)
+    for p in (3, 5, 27, 2 * N - 1):
+        dst = np.zeros_like(a)
+        orc.galois(a, dst, rows, p)
+        for n in range(N):
+            e = p * n % (2 * N)
+            assert (dst[:, e % N] == (-a[:, n] if e >= N else a[:, n])).all()

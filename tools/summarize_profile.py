@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 result databases written by tools/profile_bench.sh into the small text / JSON
+summaries kept under profiles/ (the .db files themselves stay in gpurun_out/, which is scratch).
+
+    python tools/summarize_profile.py r01
+"""
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out_dir = os.path.join(ROOT, "profiles")
+src = os.path.join(ROOT, "gpurun_out")
+
+
+def q(db, sql):
+    con = sqlite3.connect(db)
+    try:
+        return con.execute(sql).fetchall()
+    finally:
+        con.close()
+
+
+lines = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-extra --steps 20 --warmup 5   ({tag})",
+         "# columns: kernel | calls | total_us | avg_us | % of GPU time", ""]
+for name, calls, total, avg, pct in q(os.path.join(src, f"prof_{tag}", "stats_results.db"),
+                                      "select name,total_calls,total_duration,average,percentage from top_kernels"):
+    lines.append(f"{name[:110]:110s} | {calls:6d} | {total:12.1f} | {avg:10.2f} | {pct:6.2f}")
+open(os.path.join(out_dir, f"{tag}_bench_kernel_stats.txt"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+
+# HBM traffic from the PMC passes.  Units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.
+# gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts a 16 B/lane coalesced read at
+# half its bytes -> doubled here.  Calibrated in the same run on ew_kernel<1> (in-place mont_enter of a
+# 39 x 65536 x 8 B tensor = 20,447,232 B): FETCH_SIZE*1024*2 and WRITE_SIZE*1024 both reproduce it.
+pm = [f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --no-extra --steps 5 --warmup 2   ({tag})",
+      "# per-dispatch values for the NTT pass kernel, in KiB as reported; bytes = KiB*1024 (x2 for FETCH_SIZE on gfx950)", ""]
+per = {}
+for counter, sub, stem in (("FETCH_SIZE", f"pmc_fetch_{tag}", "fetch"), ("WRITE_SIZE", f"pmc_write_{tag}", "write")):
+    db = os.path.join(src, sub, f"{stem}_results.db")
+    rows = q(db, "select kernel_name, grid_size_x, count(*), avg(value), min(value), max(value), avg(duration) "
+                 "from counters_collection group by kernel_name")
+    for r in rows:
+        pm.append(f"{counter:10s} | {r[0][:70]:70s} | n={r[2]:4d} | avg={r[3]:12.1f} | min={r[4]:12.1f} | max={r[5]:12.1f} | avg_ns={r[6]:10.0f}")
+    disp = q(db, "select dispatch_id, value, duration from counters_collection where kernel_name like '%ntt_fwd_pass%' order by dispatch_id")
+    per[counter] = disp
+    pm.append("")
+pm.append("# ntt_fwd_pass dispatches alternate: strided pass (4 stages) / contiguous pass (12 stages + twiddles)")
+for (d, v, ns), (_, w, _) in zip(per["FETCH_SIZE"], per["WRITE_SIZE"]):
+    pm.append(f"dispatch {d}: FETCH_SIZE={v:10.1f} KiB -> {2 * v * 1024 / 1e6:7.1f} MB read (corrected) | WRITE_SIZE={w:10.1f} KiB -> {w * 1024 / 1e6:7.1f} MB | {ns / 1e3:7.1f} us")
+open(os.path.join(out_dir, f"{tag}_bench_pmc_hbm.txt"), "w").write("\n".join(pm) + "\n")
+
+fetch = sum(v for _, v, _ in per["FETCH_SIZE"]) / len(per["FETCH_SIZE"])
+write = sum(v for _, v, _ in per["WRITE_SIZE"]) / len(per["WRITE_SIZE"])
+traffic = {"ntt_fwd_pass_bytes_per_launch": (2 * fetch + write) * 1024,
+           "fetch_kib_avg_raw": fetch, "write_kib_avg": write,
+           "note": "average over the two passes of one transform; FETCH_SIZE doubled per the gfx950 1/2-count caveat"}
+json.dump(traffic, open(os.path.join(out_dir, f"traffic_{tag}.json"), "w"), indent=1)
+print(traffic)
