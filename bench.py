@@ -126,6 +126,7 @@ def main():
         dist.barrier()
 
     from liberate_fhe_amd._native import lib, check
+    from liberate_fhe_amd.ntt import twiddles
     from liberate_fhe_amd.fhe.context.ckks_context import ckks_context
     from liberate_fhe_amd.ntt import ntt_context
     from liberate_fhe_amd.utils import synth
@@ -142,10 +143,12 @@ def main():
     sl = lambda t: t[0][lo:]
     psi, q2, ql, qh, kl, kh = (sl(t) for t in (ntt.psi, ntt._2q, ntt.ql, ntt.qh, ntt.kl, ntt.kh))
     stream = torch.cuda.current_stream().cuda_stream
+    psi_dp = twiddles.dp_pointer(psi, ql, qh, kl, kh, local_rank, stream)
+    q_host = np.array([ctx.q[i] for i in rows_idx], dtype=np.int64)
 
     def step():
-        check(lib.lf_ntt(x.data_ptr(), B, L_LIMBS, LOGN, psi.data_ptr(), 0, q2.data_ptr(), ql.data_ptr(), qh.data_ptr(),
-                         kl.data_ptr(), kh.data_ptr(), local_rank, stream), "lf_ntt")
+        check(lib.lf_ntt(x.data_ptr(), B, L_LIMBS, LOGN, psi.data_ptr(), psi_dp, q_host.ctypes.data, 0, 0, q2.data_ptr(), ql.data_ptr(),
+                         qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), local_rank, stream), "lf_ntt")
 
     for _ in range(args.warmup):
         step()

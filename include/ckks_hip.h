@@ -34,7 +34,7 @@ extern "C" {
 
 #define LF_ERR_ARG 10001
 
-/* Library / device probe: returns the ABI version (currently 1). */
+/* Library probe: returns the ABI version (currently 2). */
 int lf_abi_version(void);
 
 /* ---- elementwise family --------------------------------------------------------------------- */
@@ -71,21 +71,37 @@ int lf_mont_sub(const int64_t *a, const int64_t *b, int64_t *c, int rows, int64_
 
 /* ---- NTT family -------------------------------------------------------------------------------
  * `batch` polynomials of `rows` limbs each, stored back to back ([batch][rows][N]); limb i of every
- * polynomial uses constant/twiddle row i.  The reference API is batch = 1. */
+ * polynomial uses constant/twiddle row i.  The reference API is batch = 1.
+ *
+ * psi_dp / ipsi_dp (optional, may be NULL): the same compact twiddle table as plain canonical residues
+ * stored as doubles (fill it with lf_twiddle_dp).  When given, limbs whose prime is below 2^41 run the
+ * fp64-FMA butterfly path; results are bit-identical to the integer path.
+ * q_host (optional, may be NULL): HOST array of the `rows` primes, used only to split the rows into the
+ * two arithmetic classes at launch time (each class has its own kernel instantiation); with NULL every
+ * row runs the integer class.
+ * flags: LF_NTT_RELAXED = the caller only needs the result modulo q (outputs are then canonical
+ * residues instead of the reference's lazy representatives) — for fused internal use, never for the
+ * drop-in ops. */
+#define LF_NTT_RELAXED 1
+
+/* plain twiddles as doubles from the Montgomery-form compact table: out = reduce_q(redc(mont)). */
+int lf_twiddle_dp(const int64_t *mont, double *out, int rows, int64_t N, const int64_t *ql, const int64_t *qh,
+                  const int64_t *kl, const int64_t *kh, int device, void *stream);
 
 /* ntt_cuda.ntt (ntt.cpp:166-188, K.cu:236-342): forward negacyclic NTT, natural in -> bit-reversed out.
  * ntt_cuda.enter_ntt (ntt.cpp:191-216, K.cu:349-423) when Rs != NULL: mont_enter(Rs) first. */
-int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, const int64_t *Rs,
-           const int64_t *_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
-           int device, void *stream);
+int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
+           const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *_2q, const int64_t *ql,
+           const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 
 /* ntt_cuda.intt / intt_exit / intt_exit_reduce / intt_exit_reduce_signed
  * (ntt.cpp:219-345, K.cu:433-548, 709-973): inverse NTT, bit-reversed in -> natural out, then
  * x Ninv (= N^-1 * R mod q); `tail` selects the fused chain:
- *   0 intt, 1 + mont_redc, 2 + reduce (canonical [0,q)), 3 + make_signed. */
-int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, const int64_t *Ninv, int tail,
-            const int64_t *_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
-            int device, void *stream);
+ *   0 intt, 1 + mont_redc, 2 + reduce (canonical [0,q)), 3 + make_signed.
+ * LF_NTT_RELAXED requires tail >= 2 (whose outputs are canonical anyway). */
+int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, const double *ipsi_dp,
+            const int64_t *q_host, const int64_t *Ninv, int tail, int flags, const int64_t *_2q,
+            const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 
 /* Galois automorphism of coefficient-domain rows (reference: encdec.py:224-270 `rotate`/`conjugate`,
  * done there with torch advanced indexing): dst[i][(p*n mod 2N) mod N] = +/- a[i][n], sign - iff

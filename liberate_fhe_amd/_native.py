@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libckks_hip.so")
+LIB_PATH = os.environ.get("LF_HIP_LIB") or os.path.join(_HERE, "csrc", "libckks_hip.so")  # env override: kernel experiments
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -35,8 +35,9 @@ _SIGNATURES = {
     "lf_tile_unsigned": [_P, _P, _I, _L, _P, _I, _P],
     "lf_mont_add": [_P, _P, _P, _I, _L, _P, _I, _P],
     "lf_mont_sub": [_P, _P, _P, _I, _L, _P, _I, _P],
-    "lf_ntt": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
-    "lf_intt": [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P],
+    "lf_twiddle_dp": [_P, _P, _I, _L, _P, _P, _P, _P, _I, _P],
+    "lf_ntt": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P],
+    "lf_intt": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     "lf_galois": [_P, _P, _I, _I, _L, _P, _I, _P],
     "lf_rescale": [_P, _P, _P, _I, _L, _P, _L, _P, _P, _P, _P, _I, _P],
     "lf_tensor": [_P, _P, _P, _P, _P, _P, _P, _I, _L, _P, _P, _P, _P, _I, _P],
@@ -62,3 +63,4 @@ def check(code: int, what: str):
 
 
 EXPORTED = tuple(_SIGNATURES)
+LF_NTT_RELAXED = 1

@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 
 from .._native import lib, check
-from ..ntt import ntt_cuda
+from ..ntt import ntt_cuda, twiddles
 
 
 def _ds(t: torch.Tensor):
@@ -29,10 +29,14 @@ def _p(t):
 
 class Consts:
     """Per-row Montgomery constants of a contiguous run of limbs on one device."""
-    __slots__ = ("ql", "qh", "kl", "kh", "_2q")
+    __slots__ = ("ql", "qh", "kl", "kh", "_2q", "q_host")
 
-    def __init__(self, ql, qh, kl, kh, _2q):
+    def __init__(self, ql, qh, kl, kh, _2q, q_host=None):
         self.ql, self.qh, self.kl, self.kh, self._2q = ql, qh, kl, kh, _2q
+        self.q_host = q_host   # numpy int64 copy of the primes (launch-time row classification)
+
+    def qptr(self):
+        return 0 if self.q_host is None else self.q_host.ctypes.data
 
     def mont(self):
         return _p(self.ql), _p(self.qh), _p(self.kl), _p(self.kh)
@@ -43,13 +47,18 @@ class HipBackend:
     ops = ntt_cuda  # the 15 reference-shaped primitives
 
     # ---- NTT family over [batch][rows][N] stacks ------------------------------------------------
-    def ntt(self, buf, batch, rows, logN, psi, Rs, c: Consts):
+    def ntt(self, buf, batch, rows, logN, psi, Rs, c: Consts, relaxed=False):
+        """relaxed: the caller only needs residues mod q (internal transforms whose consumers reduce)."""
         dev, st = _ds(buf)
-        check(lib.lf_ntt(_p(buf), batch, rows, logN, _p(psi), _p(Rs), _p(c._2q), *c.mont(), dev, st), "lf_ntt")
+        dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
+        check(lib.lf_ntt(_p(buf), batch, rows, logN, _p(psi), dp, c.qptr(), _p(Rs), 1 if relaxed else 0, _p(c._2q),
+                         *c.mont(), dev, st), "lf_ntt")
 
-    def intt(self, buf, batch, rows, logN, ipsi, Ninv, tail, c: Consts):
+    def intt(self, buf, batch, rows, logN, ipsi, Ninv, tail, c: Consts, relaxed=False):
         dev, st = _ds(buf)
-        check(lib.lf_intt(_p(buf), batch, rows, logN, _p(ipsi), _p(Ninv), tail, _p(c._2q), *c.mont(), dev, st), "lf_intt")
+        dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
+        check(lib.lf_intt(_p(buf), batch, rows, logN, _p(ipsi), dp, c.qptr(), _p(Ninv), tail,
+                          1 if relaxed and tail >= 2 else 0, _p(c._2q), *c.mont(), dev, st), "lf_intt")
 
     def galois(self, a, dst, rows, logN, p, _2q):
         dev, st = _ds(a)

@@ -105,7 +105,9 @@ class ckks_engine:
         if key not in self._tables:
             a, b = self.ntt.starts[level][dev], self.ntt.stops[0 if special else 1][dev]
             n = self.ntt
-            self._tables[key] = Consts(n.ql[dev][a:b], n.qh[dev][a:b], n.kl[dev][a:b], n.kh[dev][a:b], n._2q[dev][a:b])
+            primes = np.array([self.ctx.q[i] for i in n.p.d_special[dev][a:b]], dtype=np.int64)
+            self._tables[key] = Consts(n.ql[dev][a:b], n.qh[dev][a:b], n.kl[dev][a:b], n.kh[dev][a:b], n._2q[dev][a:b],
+                                       q_host=primes)
         return self._tables[key]
 
     def _rows(self, dev, level, special):

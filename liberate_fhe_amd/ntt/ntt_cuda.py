@@ -16,9 +16,12 @@ table.  The HIP kernels index a compact [rows, N] table.  `psi` may therefore be
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from .._native import lib, check
+from . import twiddles
 
 __all__ = [
     "mont_mult", "mont_enter", "ntt", "enter_ntt", "intt", "mont_redc", "intt_exit", "intt_exit_reduce",
@@ -56,10 +59,10 @@ _compact_cache = {}
 def _compact(psi: torch.Tensor, inverse: bool) -> torch.Tensor:
     if psi.dim() == 2:
         return psi
-    key = (psi.data_ptr(), tuple(psi.shape), psi._version, inverse, psi.device)
+    key = (id(psi), inverse)
     hit = _compact_cache.get(key)
-    if hit is not None:
-        return hit
+    if hit is not None and hit[0]() is psi and hit[1] == psi._version:
+        return hit[2]
     rows, logN, half = psi.shape
     N = 2 * half
     out = torch.zeros((rows, N), dtype=psi.dtype, device=psi.device)
@@ -67,9 +70,8 @@ def _compact(psi: torch.Tensor, inverse: bool) -> torch.Tensor:
         t = (1 << s) if inverse else (N >> (s + 1))
         m = (N >> (s + 1)) if inverse else (1 << s)
         out[:, m:2 * m] = psi[:, s, ::t]
-    if len(_compact_cache) > 256:
-        _compact_cache.clear()
-    _compact_cache[key] = out
+    _compact_cache[key] = (weakref.ref(psi), psi._version, out)
+    weakref.finalize(psi, _compact_cache.pop, key, None)
     return out
 
 
@@ -119,8 +121,10 @@ def _forward(a, Rs, psi, _2q, ql, qh, kl, kh, what):
         w, back = _inplace(ai)
         table = _compact(psi[i], inverse=False)
         rs = 0 if Rs is None else _ptr(Rs[i].contiguous())
+        dp = twiddles.dp_pointer(table, ql[i], qh[i], kl[i], kh[i], dev, st)
+        _, qhost = twiddles.host_primes(ql[i], qh[i])
         # extent = ql.size(0) rows (K.cu:298, 371)
-        check(lib.lf_ntt(_ptr(w), 1, ql[i].size(0), _logN(w), _ptr(table), rs, _ptr(_2q[i]),
+        check(lib.lf_ntt(_ptr(w), 1, ql[i].size(0), _logN(w), _ptr(table), dp, qhost, rs, 0, _ptr(_2q[i]),
                          _ptr(ql[i]), _ptr(qh[i]), _ptr(kl[i]), _ptr(kh[i]), dev, st), what)
         if back is not None:
             back.copy_(w)
@@ -139,7 +143,9 @@ def _inverse(a, psi, Ninv, _2q, ql, qh, kl, kh, tail, what):
         dev, st = _dev_stream(ai)
         w, back = _inplace(ai)
         table = _compact(psi[i], inverse=True)
-        check(lib.lf_intt(_ptr(w), 1, ql[i].size(0), _logN(w), _ptr(table), _ptr(Ninv[i].contiguous()), tail,
+        dp = twiddles.dp_pointer(table, ql[i], qh[i], kl[i], kh[i], dev, st)
+        _, qhost = twiddles.host_primes(ql[i], qh[i])
+        check(lib.lf_intt(_ptr(w), 1, ql[i].size(0), _logN(w), _ptr(table), dp, qhost, _ptr(Ninv[i].contiguous()), tail, 0,
                           _ptr(_2q[i]), _ptr(ql[i]), _ptr(qh[i]), _ptr(kl[i]), _ptr(kh[i]), dev, st), what)
         if back is not None:
             back.copy_(w)

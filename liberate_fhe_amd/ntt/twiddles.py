@@ -1,0 +1,58 @@
+"""fp64 copies of the compact twiddle tables (plain residues as doubles) for the fp64 butterfly path.
+
+A table the kernels see may be a row-slice of a bigger per-device tensor (ntt_context hands out views per
+level / per key-switch digit).  The fp64 copy therefore mirrors the whole underlying storage and rows are
+filled on first use with `lf_twiddle_dp`, so every view of one table shares one copy.
+"""
+from __future__ import annotations
+
+import weakref
+
+import torch
+
+from .._native import lib, check
+
+_tables = {}   # id(base tensor) -> entry; entries die with their tensor (a freed tensor's address can be reused)
+
+
+def dp_pointer(table: torch.Tensor, ql, qh, kl, kh, dev: int, stream: int) -> int:
+    """Device address of the fp64 twin of `table` ([rows, N] int64 Montgomery-form compact twiddles)."""
+    assert table.dim() == 2 and table.is_contiguous() and table.dtype == torch.int64
+    N = table.size(1)
+    base = table._base if table._base is not None else table
+    key = id(base)
+    entry = _tables.get(key)
+    if entry is None or entry["ref"]() is not base or entry["version"] != base._version:
+        entry = {"dp": torch.empty(base.untyped_storage().nbytes() // 8, dtype=torch.float64, device=table.device),
+                 "built": set(), "ref": weakref.ref(base), "version": base._version}
+        _tables[key] = entry
+        weakref.finalize(base, _tables.pop, key, None)
+    off = table.storage_offset()
+    if off % N:
+        raise ValueError("twiddle view must start on a row boundary of its storage")
+    r0 = off // N
+    rows = min(table.size(0), ql.size(0))
+    missing = [r for r in range(rows) if (r0 + r) not in entry["built"]]
+    if missing:
+        lo, hi = missing[0], missing[-1] + 1
+        check(lib.lf_twiddle_dp(table.data_ptr() + lo * N * 8, entry["dp"].data_ptr() + (r0 + lo) * N * 8, hi - lo, N,
+                                ql.data_ptr() + lo * 8, qh.data_ptr() + lo * 8, kl.data_ptr() + lo * 8,
+                                kh.data_ptr() + lo * 8, dev, stream), "lf_twiddle_dp")
+        entry["built"].update(range(r0 + lo, r0 + hi))
+    return entry["dp"].data_ptr() + off * 8
+
+
+_host_q = {}
+
+
+def host_primes(ql: torch.Tensor, qh: torch.Tensor):
+    """HOST int64 array of the primes behind device vectors ql/qh (one blocking copy per tensor pair, cached).
+    Returns (numpy array kept alive by the cache, its address)."""
+    key = (id(ql), id(qh))
+    hit = _host_q.get(key)
+    if hit is None or hit[0]() is not ql or hit[1]() is not qh or hit[2] != ql._version:
+        q = ((qh.cpu() << 31) | ql.cpu()).numpy().copy()
+        hit = (weakref.ref(ql), weakref.ref(qh), ql._version, q)
+        _host_q[key] = hit
+        weakref.finalize(ql, _host_q.pop, key, None)
+    return hit[3], hit[3].ctypes.data

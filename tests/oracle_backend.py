@@ -155,7 +155,7 @@ class OracleBackend:
         return _np(c.ql), _np(c.qh), _np(c.kl), _np(c.kh)
 
     # ---- NTT family ----
-    def ntt(self, buf, batch, rows, logN, psi, Rs, c):
+    def ntt(self, buf, batch, rows, logN, psi, Rs, c, relaxed=False):
         v = _np(buf).reshape(batch, -1, buf.size(-1))
         for b in range(batch):
             x = v[b][:rows]
@@ -163,7 +163,7 @@ class OracleBackend:
                 orc.mont_enter(x, _np(Rs), rows, *self._m(c))
             orc.ntt(x, _np(psi), rows, logN, _np(c._2q), *self._m(c))
 
-    def intt(self, buf, batch, rows, logN, ipsi, Ninv, tail, c):
+    def intt(self, buf, batch, rows, logN, ipsi, Ninv, tail, c, relaxed=False):
         v = _np(buf).reshape(batch, -1, buf.size(-1))
         for b in range(batch):
             x = v[b][:rows]
