@@ -149,6 +149,22 @@ int lf_ks_moddown(const int64_t *s, int64_t *out, const int64_t *addend, int ell
                   const int64_t *PiR, const int64_t *Rs, const int64_t *ql, const int64_t *qh, const int64_t *kl,
                   const int64_t *kh, int device, void *stream);
 
+/* Fused key-switch core for two-pass ring degrees (logN >= 13): extend + NTT + inner product with the key +
+ * sum over digits + inverse NTT to canonical coefficients, i.e. lf_ks_extend -> lf_ntt -> lf_ks_inner ->
+ * lf_intt(tail 2) (ckks_engine.py:707-743, 919, 931-934, 832-848) without materialising the extended digits.
+ *   state      [*, N] Garner digits in storage order (output of lf_ks_digits, gathered)
+ *   desc, E    as for lf_ks_extend (alpha field: bit 8 set = the digit's words exceed 53 bits, i.e. a digit of
+ *              60-bit primes; lf_ks_extend ignores the flag); Ed = the same constants as PLAIN residues in doubles
+ *              (Ed[e_off + i*rows + r] = L_{i-1} mod q_r, i = 0: 1.0) for the fp64 class
+ *   ksk        key, addressed as in lf_ks_inner
+ *   tmp        scratch [nparts][rows][N]; s out [2][rows][N]
+ *   q_host     HOST primes of the `rows` limbs (required: selects the arithmetic class per limb) */
+int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,
+               const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
+               int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
+               const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
+               const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) ks_extend_kernel(const i64 *__restrict__ 
     const int r = blockIdx.y, p = blockIdx.z;
     const i64 j = ((i64)blockIdx.x * 256 + threadIdx.x) * 2;
     if (j >= N) return;
-    const int row_start = (int)desc[p * 3 + 0], alpha = (int)desc[p * 3 + 1];
+    const int row_start = (int)desc[p * 3 + 0], alpha = (int)desc[p * 3 + 1] & 0xff;   // bit 8: lf_ks_core's wide flag
     const i64 *e = E + desc[p * 3 + 2] + r;
     const RowMod m = load_mod(ql, qh, kl, kh, r);
     longlong2 acc;

@@ -1,0 +1,264 @@
+// ckks_ks.hip — fused hybrid key-switch core: lf_ks_core.
+//
+// Replaces, for ring degrees with a two-pass NTT (logN >= 13), the chain
+//     lf_ks_extend -> lf_ntt(batch = parts) -> lf_ks_inner -> lf_intt(batch = 2, tail 2)
+// (reference: ckks_engine.py extend 707-743, ntt 919, mont_mult x2 931-934, sum over parts 832-840,
+// intt_exit_reduce 847-848) by a pipeline that never materialises the extended digits in the
+// coefficient domain and does every 40-bit-limb product with one fp64 modular multiplication:
+//
+//   K2  ks_ext_pass1     : every (digit p, target limb r, column tile): the tile's coefficients are
+//                          computed on the fly from the digit's Garner words (extend), taken through the
+//                          strided NTT pass and written once                [parts x rows x N words out]
+//   P2  ntt_fwd_pass     : the stock contiguous pass, in place
+//   K3  ks_inner2_kernel : per coefficient, the digits' products with the two key polynomials accumulated
+//                          in registers; the key is streamed exactly once
+//   K4  ntt_inv_pass_io  : the stock inverse passes (relaxed, tail 2) -> canonical coefficients
+// (A variant that also fused P2 with K3 — transform a tile in LDS, multiply, accumulate over the digits in
+// registers — was measured 1.6x SLOWER: too few, too long blocks; see DESIGN.md.)
+//
+// All of it is "relaxed" arithmetic: only residues matter because the consumer (mod-down) needs the
+// canonical coefficients, which the inverse chain's tail produces.  For limbs with a prime below 2^41
+// the extension and the inner product are done in the PLAIN domain with fp64 FMAs — ext = sum y_i L_{i-1}
+// (no Montgomery factor), NTT with plain twiddles, times the key word k*R gives (ext*k)*R, exactly the
+// Montgomery-form residue the reference's REDC(ext*R * k*R) yields — so each product is ONE fp64
+// modular multiplication.  60-bit limbs keep the reference's Montgomery integer arithmetic.
+#include "../../include/ckks_hip.h"
+#include "ckks_ntt_core.h"
+
+#define KS_MAX_ALPHA 8
+#define KS_WORDS ((1 << NTT_TILE_LOG_MAX) / NTT_THREADS)   // tile words owned by one thread (8)
+
+namespace {
+
+struct KsGeom {
+    int logN, tl, S1;
+    int rows;        // target limbs on this device (with special)
+    int nparts;      // digits
+    int groups;      // part groups (partial sums) of the inner product
+    i64 N;
+};
+
+// ---- K2: extend + strided NTT pass -----------------------------------------------------------------
+// desc[p] = {row_start, alpha, e_off}; E (Montgomery consts, int class) / Ed (plain consts as doubles,
+// fp64 class) hold, at [e_off + i*rows + r], L_{i-1} R^2 mod q_r resp. L_{i-1} mod q_r (i = 0: R^2, 1).
+template <bool DP>
+__global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ks_ext_pass1(const i64 *__restrict__ state, i64 *__restrict__ tmp,
+                                                                          KsGeom kg, RowList rl, const i64 *__restrict__ desc,
+                                                                          const i64 *__restrict__ E, const double *__restrict__ Ed,
+                                                                          const i64 *__restrict__ psi_br,
+                                                                          const double *__restrict__ psi_dp,
+                                                                          const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                          const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT_LDS_WORDS + 1];
+    const int T = 1 << kg.tl;
+    const int tiles = 1 << (kg.logN - kg.tl);
+    // consecutive blocks share (digit, tile) and differ in the target limb: they re-read the same digit
+    // columns, which stay in L2
+    const int b = blockIdx.x;
+    const int ri = b % rl.n;
+    const int pt = b / rl.n;
+    const int tile = pt % tiles, p = pt / tiles;
+    const int crow = rl.id[ri];
+    const PassGeom g{kg.logN, kg.tl, 1, kg.S1, 0, kg.tl - kg.S1, kg.rows, kg.nparts, 1, 0, 1, 0};
+
+    Ctx c;
+    c.m = load_mod(ql, qh, kl, kh, crow);
+    c.d = make_dp(c.m);
+    c.tw_mont = psi_br + ((i64)crow << kg.logN);
+    c.tw_dp = DP ? psi_dp + ((i64)crow << kg.logN) : nullptr;
+    c.relaxed = 1;
+    c.inv_off = 0.0;
+    c.inv_reduce = 0;
+    // desc[p] = {row_start, alpha | wide << 8, e_off}; wide = the digit's words exceed 53 bits (a digit made of
+    // 60-bit primes, i.e. the base-prime digit): they are split into 31-bit halves before entering fp64
+    const int row_start = (int)desc[p * 3 + 0], alpha = (int)desc[p * 3 + 1] & 0xff;
+    const bool wide = ((int)desc[p * 3 + 1] >> 8) & 1;
+    const i64 e_off = desc[p * 3 + 2] + crow;
+    i64 *row = tmp + ((i64)(p * kg.rows + crow) << kg.logN);
+
+    if (DP) {
+        double *smd = reinterpret_cast<double *>(sm);
+        double cst[KS_MAX_ALPHA], cst31[KS_MAX_ALPHA];
+#pragma unroll
+        for (int i = 0; i < KS_MAX_ALPHA; ++i) {
+            cst[i] = i < alpha ? Ed[e_off + (i64)i * kg.rows] : 0.0;
+            cst31[i] = wide ? dp_mulmod(cst[i], 2147483648.0, c.d) : 0.0;
+        }
+        for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2) {
+            const i64 j = tile_gaddr(g, tile, L);
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < KS_MAX_ALPHA; ++i) {
+                if (i < alpha) {
+                    const longlong2 y = *reinterpret_cast<const longlong2 *>(state + (i64)(row_start + i) * kg.N + j);
+                    if (!wide) {
+                        a0 += dp_mulmod((double)y.x, cst[i], c.d);    // signed digit words: the formula is sign-agnostic
+                        a1 += dp_mulmod((double)y.y, cst[i], c.d);
+                    } else {
+                        a0 += dp_mulmod((double)(y.x >> 31), cst31[i], c.d) + dp_mulmod((double)(y.x & 0x7fffffffll), cst[i], c.d);
+                        a1 += dp_mulmod((double)(y.y >> 31), cst31[i], c.d) + dp_mulmod((double)(y.y & 0x7fffffffll), cst[i], c.d);
+                    }
+                }
+            }
+            smd[PAD(L)] = a0;        // < 2 * alpha * q
+            smd[PAD(L + 1)] = a1;
+        }
+        lds_barrier();
+        run_fwd_stages<ArithDp, true>(smd, g, tile, c);
+        for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2) {
+            longlong2 o;
+            o.x = dp_to_word(dp_reduce(smd[PAD(L)], c.d.q, c.d.qinv));
+            o.y = dp_to_word(dp_reduce(smd[PAD(L + 1)], c.d.q, c.d.qinv));
+            *reinterpret_cast<longlong2 *>(row + tile_gaddr(g, tile, L)) = o;
+        }
+    } else {
+        i64 cst[KS_MAX_ALPHA];
+#pragma unroll
+        for (int i = 0; i < KS_MAX_ALPHA; ++i) cst[i] = i < alpha ? E[e_off + (i64)i * kg.rows] : 0;
+        for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2) {
+            const i64 j = tile_gaddr(g, tile, L);
+            i64 a0 = 0, a1 = 0;
+#pragma unroll
+            for (int i = 0; i < KS_MAX_ALPHA; ++i) {
+                if (i < alpha) {
+                    const longlong2 y = *reinterpret_cast<const longlong2 *>(state + (i64)(row_start + i) * kg.N + j);
+                    const i64 t0 = mm62s(y.x, cst[i], c.m.q, c.m.k), t1 = mm62s(y.y, cst[i], c.m.q, c.m.k);
+                    a0 = i == 0 ? t0 : csub(a0 + t0, c.m.q2);
+                    a1 = i == 0 ? t1 : csub(a1 + t1, c.m.q2);
+                }
+            }
+            sm[PAD(L)] = a0 < 0 ? a0 + c.m.q2 : a0;       // residues only: fold the signed-lazy words
+            sm[PAD(L + 1)] = a1 < 0 ? a1 + c.m.q2 : a1;
+        }
+        lds_barrier();
+        run_fwd_stages<ArithInt<false>, true>(sm, g, tile, c);
+        store_tile_raw(sm, row, g, tile);
+    }
+}
+
+// ---- K3: inner product with the key, summed over digits, on the relaxed NTT-domain words --------------
+// fp64 rows: words are plain canonical residues x; x * (k R) mod q is the Montgomery-form product the
+// reference's REDC(xR * kR) yields, one fp64 modular multiplication each.  Integer rows: REDC as the reference.
+// grid = (N / 1024, rows); the digits' products are accumulated in registers, the key is read exactly once.
+__global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ ext, const i64 *__restrict__ ksk,
+                                                        i64 part_stride, i64 comp_stride, i64 row_off, i64 *__restrict__ s,
+                                                        int nparts, int rows, i64 N, const i64 *__restrict__ ql,
+                                                        const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                                        const i64 *__restrict__ kh) {
+    const int r = blockIdx.y;
+    const i64 j = ((i64)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (j >= N) return;
+    const RowMod m = load_mod(ql, qh, kl, kh, r);
+    const RowDp d = make_dp(m);
+    const i64 *e = ext + (i64)r * N + j;
+    const i64 *k = ksk + (row_off + r) * N + j;
+    longlong2 o0, o1;
+    if (m.q < SMALL_PRIME_LIMIT) {
+        double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+        for (int p = 0; p < nparts; ++p) {
+            const longlong2 x = *reinterpret_cast<const longlong2 *>(e + (i64)p * rows * N);
+            const longlong2 k0 = *reinterpret_cast<const longlong2 *>(k + (i64)p * part_stride);
+            const longlong2 k1 = *reinterpret_cast<const longlong2 *>(k + (i64)p * part_stride + comp_stride);
+            const double x0 = dp_from_word(x.x), x1 = dp_from_word(x.y);
+            a00 += dp_mulmod(x0, dp_from_word(k0.x), d);
+            a01 += dp_mulmod(x1, dp_from_word(k0.y), d);
+            a10 += dp_mulmod(x0, dp_from_word(k1.x), d);
+            a11 += dp_mulmod(x1, dp_from_word(k1.y), d);
+        }
+        o0.x = dp_to_word(dp_reduce(a00, d.q, d.qinv));
+        o0.y = dp_to_word(dp_reduce(a01, d.q, d.qinv));
+        o1.x = dp_to_word(dp_reduce(a10, d.q, d.qinv));
+        o1.y = dp_to_word(dp_reduce(a11, d.q, d.qinv));
+    } else {
+        i64 a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+        for (int p = 0; p < nparts; ++p) {
+            const longlong2 x = *reinterpret_cast<const longlong2 *>(e + (i64)p * rows * N);
+            const longlong2 k0 = *reinterpret_cast<const longlong2 *>(k + (i64)p * part_stride);
+            const longlong2 k1 = *reinterpret_cast<const longlong2 *>(k + (i64)p * part_stride + comp_stride);
+            a00 = csub(a00 + mm62u((u64)x.x, (u64)k0.x, m.q, m.k), m.q2);
+            a01 = csub(a01 + mm62u((u64)x.y, (u64)k0.y, m.q, m.k), m.q2);
+            a10 = csub(a10 + mm62u((u64)x.x, (u64)k1.x, m.q, m.k), m.q2);
+            a11 = csub(a11 + mm62u((u64)x.y, (u64)k1.y, m.q, m.k), m.q2);
+        }
+        o0.x = a00; o0.y = a01; o1.x = a10; o1.y = a11;
+    }
+    *reinterpret_cast<longlong2 *>(s + (i64)r * N + j) = o0;
+    *reinterpret_cast<longlong2 *>(s + ((i64)rows + r) * N + j) = o1;
+}
+
+void classify_rows(int rows, const int64_t *q_host, RowList &dp, RowList &in) {
+    dp.n = in.n = 0;
+    for (int r = 0; r < rows; ++r) {
+        RowList &dst = (q_host && (uint64_t)q_host[r] < SMALL_PRIME_LIMIT) ? dp : in;
+        dst.id[dst.n++] = (unsigned short)r;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,
+               const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
+               int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
+               const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
+               const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (nparts < 1 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
+        !q_host || !psi_dp || !ipsi_dp || !Ed)
+        return LF_ERR_ARG;
+    if (int e = lf_set_device(device)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    const int tl = NTT_TILE_LOG_MAX, S1 = logN - tl;
+    const KsGeom kg{logN, tl, S1, rows, nparts, 1, (i64)1 << logN};
+    RowList dp, in;
+    classify_rows(rows, q_host, dp, in);
+    const unsigned tiles = 1u << (logN - tl);
+
+    // K2: extend + strided pass
+    if (dp.n)
+        hipLaunchKernelGGL(ks_ext_pass1<true>, dim3(tiles * dp.n * nparts), dim3(NTT_THREADS), 0, st, (const i64 *)state,
+                           (i64 *)tmp, kg, dp, (const i64 *)desc, (const i64 *)E, Ed, (const i64 *)psi_br, psi_dp,
+                           (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+    if (in.n)
+        hipLaunchKernelGGL(ks_ext_pass1<false>, dim3(tiles * in.n * nparts), dim3(NTT_THREADS), 0, st, (const i64 *)state,
+                           (i64 *)tmp, kg, in, (const i64 *)desc, (const i64 *)E, Ed, (const i64 *)psi_br, psi_dp,
+                           (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+    // contiguous forward pass, in place on tmp (relaxed)
+    {
+        const PassGeom g{logN, tl, 0, tl, S1, 0, rows, nparts, 1, 1, 1, 0};
+        const unsigned per_row = (unsigned)nparts << (logN - tl);
+        if (dp.n)
+            hipLaunchKernelGGL(ntt_fwd_pass<true>, dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, (i64 *)tmp, g, dp,
+                               (const i64 *)psi_br, psi_dp, (const i64 *)nullptr, (const i64 *)ql, (const i64 *)qh,
+                               (const i64 *)kl, (const i64 *)kh);
+        if (in.n)
+            hipLaunchKernelGGL(ntt_fwd_pass<false>, dim3(per_row * in.n), dim3(NTT_THREADS), 0, st, (i64 *)tmp, g, in,
+                               (const i64 *)psi_br, psi_dp, (const i64 *)nullptr, (const i64 *)ql, (const i64 *)qh,
+                               (const i64 *)kl, (const i64 *)kh);
+    }
+    // K3: inner product with the key, summed over the digits
+    {
+        const i64 N = (i64)1 << logN;
+        dim3 grid((unsigned)((N / 2 + 255) / 256), (unsigned)rows);
+        hipLaunchKernelGGL(ks_inner2_kernel, grid, dim3(256), 0, st, (const i64 *)tmp, (const i64 *)ksk, (i64)part_stride,
+                           (i64)comp_stride, (i64)row_off, (i64 *)s, nparts, rows, N, (const i64 *)ql, (const i64 *)qh,
+                           (const i64 *)kl, (const i64 *)kh);
+    }
+    // K4: inverse transform -> canonical coefficients (relaxed, tail 2), in place on s
+    const unsigned per_row2 = 2u << (logN - tl);
+    for (int pass = 0; pass < 2; ++pass) {
+        PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, 2, 1, 0, 1, 0}
+                               : PassGeom{logN, tl, 1, S1, tl, tl - S1, rows, 2, 1, 1, 1, 0};
+        if (dp.n)
+            hipLaunchKernelGGL(ntt_inv_pass_io<true>, dim3(per_row2 * dp.n), dim3(NTT_THREADS), 0, st, (const i64 *)s, (i64 *)s,
+                               g, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, pass == 1 ? 2 : TAIL_NONE,
+                               (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+        if (in.n)
+            hipLaunchKernelGGL(ntt_inv_pass_io<false>, dim3(per_row2 * in.n), dim3(NTT_THREADS), 0, st, (const i64 *)s, (i64 *)s,
+                               g, in, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, pass == 1 ? 2 : TAIL_NONE,
+                               (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

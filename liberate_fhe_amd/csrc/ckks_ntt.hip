@@ -31,592 +31,11 @@
 //   * LF_NTT_RELAXED transforms are for callers that only need the result modulo q (the fused key
 //     switch): negative input words are folded, outputs are canonical residues.
 #include "../../include/ckks_hip.h"
-#include "ckks_common.h"
+#include "ckks_ntt_core.h"
 #include <stdlib.h>
-
-#define NTT_THREADS 512
-#define NTT_TILE_LOG_MAX 12
-#define NTT_LDS_WORDS ((1 << NTT_TILE_LOG_MAX) + (1 << (NTT_TILE_LOG_MAX - 3)))
-#define TAIL_NONE (-1)
-#define SMALL_PRIME_LIMIT (1ull << 41)
-#define LAZY_FIX_LIMIT 4194304.0   // 2^22 > (2q)^2 / 2^62 for q < 2^41
-#define MAX_LIST_ROWS 250
-
-#define PAD(L) ((L) + ((L) >> 3))
-#define NTT_FLAG_WORD NTT_LDS_WORDS          // two flag words live behind the tile in the same LDS array
+#include <mutex>
 
 namespace {
-
-// Workgroup barrier that waits for LDS traffic only.  __syncthreads() also drains the vector-memory
-// queue (s_waitcnt vmcnt(0)), which would serialise the register prefetch of the next tile behind
-// every barrier of the current one.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-// block-wide OR through an LDS flag word (double-buffered by `parity`, so no reset barrier is needed)
-__device__ __forceinline__ bool block_or(i64 *sm, int pred, int parity) {
-    int *flags = reinterpret_cast<int *>(sm + NTT_FLAG_WORD);
-    if (threadIdx.x == 0) flags[parity ^ 1] = 0;
-    if (__builtin_amdgcn_ballot_w64(pred != 0) != 0 && (threadIdx.x & 63) == 0) flags[parity] = 1;
-    lds_barrier();
-    return flags[parity] != 0;
-}
-
-struct RowList {
-    int n;
-    unsigned short id[MAX_LIST_ROWS];
-};
-
-struct PassGeom {
-    int logN;
-    int tl;        // log2 of tile size
-    int strided;   // 0 contiguous, 1 strided
-    int S;         // stages in this pass
-    int s0;        // global index of the first stage of this pass
-    int logC;      // strided: log2 of columns per tile row
-    int rows;      // limbs per polynomial
-    int batch;     // polynomials
-    int relaxed;   // 1: result only needed modulo q
-    int last;      // 1: last pass of the transform
-};
-
-// tile-local index -> coefficient index of the row
-__device__ __forceinline__ int tile_gaddr(const PassGeom &g, int tile, int L) {
-    if (!g.strided) return (tile << g.tl) + L;
-    const int r = L >> g.logC, c = L & ((1 << g.logC) - 1);
-    return (r << (g.logN - g.S)) + (tile << g.logC) + c;
-}
-
-// block id -> (polynomial, limb, tile): the `batch` polynomials of one (limb, tile) pair are
-// consecutive on one XCD (block b runs on XCD b % 8) so they share the pair's twiddles in that L2.
-__device__ __forceinline__ void block_coords(const PassGeom &g, const RowList &rl, int &poly, int &limb, int &tile) {
-    const int tiles = 1 << (g.logN - g.tl);
-    const int pairs = rl.n * tiles;
-    const int b = blockIdx.x;
-    int pair;
-    if ((pairs & 7) == 0) {
-        const int x = b & 7, r = b >> 3;
-        poly = r % g.batch;
-        pair = (r / g.batch) * 8 + x;
-    } else {
-        pair = b / g.batch;
-        poly = b % g.batch;
-    }
-    limb = rl.id[pair / tiles];
-    tile = pair % tiles;
-}
-
-#define NTT_PRE ((1 << NTT_TILE_LOG_MAX) / (NTT_THREADS * 2))   // 16-byte prefetch registers per thread
-
-// issue the global loads of one tile into registers (16 B per lane); consumed by stash_tile()
-__device__ __forceinline__ void prefetch_tile(longlong2 (&pre)[NTT_PRE], const i64 *row, const PassGeom &g, int tile) {
-    const int T = 1 << g.tl;
-#pragma unroll
-    for (int v = 0; v < NTT_PRE; ++v) {
-        const int L = (threadIdx.x + v * NTT_THREADS) * 2;
-        if (L < T) pre[v] = *reinterpret_cast<const longlong2 *>(row + tile_gaddr(g, tile, L));
-    }
-}
-
-// prefetched words -> LDS (padded layout); returns whether any word lies outside [0, 2q)
-__device__ __forceinline__ int stash_tile(i64 *sm, const longlong2 (&pre)[NTT_PRE], const PassGeom &g, i64 q2) {
-    const int T = 1 << g.tl;
-    int odd_word = 0;
-#pragma unroll
-    for (int v = 0; v < NTT_PRE; ++v) {
-        const int L = (threadIdx.x + v * NTT_THREADS) * 2;
-        if (L < T) {
-            longlong2 w = pre[v];
-            if (g.relaxed) {   // residues only: fold the signed-lazy words
-                w.x = w.x < 0 ? w.x + q2 : w.x;
-                w.y = w.y < 0 ? w.y + q2 : w.y;
-            }
-            odd_word |= ((u64)w.x >= (u64)q2) | ((u64)w.y >= (u64)q2);
-            sm[PAD(L)] = w.x;
-            sm[PAD(L + 1)] = w.y;
-        }
-    }
-    return odd_word;
-}
-
-// ------------------------------------------------------------------------------------------------
-// fp64 modular arithmetic for q < 2^41 (operands: non-negative integers held exactly in doubles)
-// ------------------------------------------------------------------------------------------------
-struct RowDp {
-    double q, q2, qinv, q2inv;
-};
-
-// r < 0 ? r + m : r, with the select done on the sign bit by 32-bit integer ops (full rate)
-__device__ __forceinline__ double dp_addmask(double r, double m) {
-    const i64 mask = __double_as_longlong(r) >> 63;
-    return r + __longlong_as_double(__double_as_longlong(m) & mask);
-}
-
-// exact int <-> double for 0 <= x < 2^52 with one OR/AND on the high word and one fp64 add
-// (the compiler's generic 64-bit conversions cost 4-10 instructions each)
-#define DP_MAGIC 4503599627370496.0   // 2^52
-__device__ __forceinline__ double dp_from_word(i64 x) {
-    return __longlong_as_double(x | 0x4330000000000000ll) - DP_MAGIC;
-}
-__device__ __forceinline__ i64 dp_to_word(double d) {
-    return __double_as_longlong(d + DP_MAGIC) & 0x000FFFFFFFFFFFFFll;
-}
-
-// (a * w) mod q, canonical, for a < 2^52, w < q: exact via the FMA low part.
-__device__ __forceinline__ double dp_mulmod(double a, double w, const RowDp &m) {
-    const double hi = a * w;
-    const double lo = __builtin_fma(a, w, -hi);
-    const double quo = __builtin_rint(hi * m.qinv);
-    const double r = __builtin_fma(-quo, m.q, hi) + lo;
-    return dp_addmask(r, m.q);
-}
-
-// x mod m for 0 <= x < 2^52 (m = q or 2q, minv its reciprocal)
-__device__ __forceinline__ double dp_reduce(double x, double m, double minv) {
-    const double quo = __builtin_rint(x * minv);
-    const double r = __builtin_fma(-quo, m, x);
-    return dp_addmask(r, m);
-}
-
-// The reference's lazy representative of REDC62(A*B) given its canonical value t0 (< 2^22):
-// t0 + q iff t0 * 2^62 < A*B (integer operands A, B as the reference multiplies them).
-__device__ __noinline__ double dp_lazy_fix(double t0, u64 A, u64 B, double q) {
-    const u128 x = (u128)A * (u128)B;
-    const u64 xh = (u64)(x >> 62);
-    const u64 xl = (u64)x & M62;
-    const u64 t = (u64)t0;
-    return ((xh > t) || (xh == t && xl != 0)) ? t0 + q : t0;
-}
-
-struct Ctx {
-    RowMod m;
-    RowDp d;
-    const i64 *tw_mont;     // compact Montgomery twiddles of this limb (always valid)
-    const double *tw_dp;    // compact plain twiddles as doubles (fp64 class)
-    int relaxed;
-    double inv_off;         // fp64 inverse steps: offset keeping U - V non-negative (multiple of 2q)
-    int inv_reduce;         // fp64 inverse steps: reduce mod 2q at the end of this step
-};
-
-// ------------------------------------------------------------------------------------------------
-// Arithmetic policies
-// ------------------------------------------------------------------------------------------------
-template <bool SIGNED>
-struct ArithInt {
-    typedef i64 T;
-    typedef i64 W;
-    static __device__ __forceinline__ W tw(const Ctx &c, int idx) { return c.tw_mont[(unsigned)idx]; }
-    static __device__ __forceinline__ T mul(const Ctx &c, W S, T O) {
-        return SIGNED ? mm62s(S, O, c.m.q, c.m.k) : mm62u((u64)S, (u64)O, c.m.q, c.m.k);
-    }
-    static __device__ __forceinline__ void fwd(const Ctx &c, T &a, T &b, W S, int) {
-        const T U = a, V = mul(c, S, b);
-        a = csub(U + V, c.m.q2);
-        b = csub(U + c.m.q2 - V, c.m.q2);
-    }
-    static __device__ __forceinline__ void inv(const Ctx &c, T &a, T &b, W S, int) {
-        const T U = a, V = b;
-        const T O = csub(U + c.m.q2 - V, c.m.q2);
-        b = mul(c, S, O);
-        a = csub(U + V, c.m.q2);
-    }
-    template <int NN>
-    static __device__ __forceinline__ void fwd_end(const Ctx &, T (&)[NN]) {}
-    template <int NN>
-    static __device__ __forceinline__ void inv_end(const Ctx &, T (&)[NN]) {}
-};
-
-// fp64 class.  Words are representatives (< 2^52) of the reference's lazy values mod 2q.  Forward sums
-// grow by at most 2q per stage and are reduced mod 2q once, when the pass stores its tile; inverse sums
-// double per stage and are reduced at the end of every second step.
-struct ArithDp {
-    typedef double T;
-    typedef double W;
-    static __device__ __forceinline__ W tw(const Ctx &c, int idx) { return c.tw_dp[(unsigned)idx]; }
-    // lazy REDC62(S * O) for O = o (any representative < 2^52 of the lazy word mod 2q)
-    static __device__ __forceinline__ T mul(const Ctx &c, W w, T o, int idx) {
-        T v = dp_mulmod(o, w, c.d);
-        if (!c.relaxed && v < LAZY_FIX_LIMIT)
-            v = dp_lazy_fix(v, (u64)c.tw_mont[idx], (u64)dp_reduce(o, c.d.q2, c.d.q2inv), c.d.q);
-        return v;
-    }
-    static __device__ __forceinline__ void fwd(const Ctx &c, T &a, T &b, W w, int idx) {
-        const T U = a, V = mul(c, w, b, idx);      // V in [0, 2q)
-        a = U + V;
-        b = U + (c.d.q2 - V);
-    }
-    static __device__ __forceinline__ void inv(const Ctx &c, T &a, T &b, W w, int idx) {
-        const T U = a, V = b;                       // both < c.inv_off (a multiple of 2q) inside a step
-        b = mul(c, w, U - V + c.inv_off, idx);
-        a = U + V;
-    }
-    template <int NN>
-    static __device__ __forceinline__ void fwd_end(const Ctx &, T (&)[NN]) {}
-    template <int NN>
-    static __device__ __forceinline__ void inv_end(const Ctx &c, T (&x)[NN]) {
-        if (c.inv_reduce) {
-#pragma unroll
-            for (int e = 0; e < NN; ++e) x[e] = dp_reduce(x[e], c.d.q2, c.d.q2inv);
-        }
-    }
-};
-
-// Forward radix-2^K step over local distances (dl << (K-1)), ..., dl at stages s, s+1, ..
-//   twiddle index of stage st at tile-local index L: (1 << st) + ((base + L) >> (E - st));
-//   the 2^u groups of stage u each share one twiddle.
-template <int K, class A, int LOGDL = -1>
-__device__ __forceinline__ void fwd_step(typename A::T *sm, int T, int log_dl_rt, int s, int E, int base, const Ctx &c) {
-    const int log_dl = LOGDL >= 0 ? LOGDL : log_dl_rt;   // compile-time in the hot 4096-word schedules
-    const int items = T >> K;
-    for (int w = threadIdx.x; w < items; w += NTT_THREADS) {
-        const int p = ((w >> log_dl) << (log_dl + K)) | (w & ((1 << log_dl) - 1));
-        typename A::T x[1 << K];
-#pragma unroll
-        for (int e = 0; e < (1 << K); ++e) x[e] = sm[PAD(p + (e << log_dl))];
-#pragma unroll
-        for (int u = 0; u < K; ++u) {
-            const int du = 1 << (K - 1 - u);
-            const int st = s + u;
-#pragma unroll
-            for (int j = 0; j < (1 << u); ++j) {
-                const int e0 = j << (K - u);
-                const int idx = (1 << st) + ((base + p + (e0 << log_dl)) >> (E - st));
-                const typename A::W wv = A::tw(c, idx);
-#pragma unroll
-                for (int t = 0; t < du; ++t) A::fwd(c, x[e0 + t], x[e0 + t + du], wv, idx);
-            }
-        }
-        A::fwd_end(c, x);
-#pragma unroll
-        for (int e = 0; e < (1 << K); ++e) sm[PAD(p + (e << log_dl))] = x[e];
-    }
-}
-
-// Inverse radix-2^K step over local distances dl, 2dl, .. at stages s, s+1, ..
-//   twiddle index: (N >> (st+1)) + ((base + L) >> (st + 1 - adj))
-template <int K, class A, int LOGDL = -1>
-__device__ __forceinline__ void inv_step(typename A::T *sm, int T, int log_dl_rt, int s, int adj, int logN, int base,
-                                         const Ctx &c) {
-    const int log_dl = LOGDL >= 0 ? LOGDL : log_dl_rt;
-    const int items = T >> K;
-    for (int w = threadIdx.x; w < items; w += NTT_THREADS) {
-        const int p = ((w >> log_dl) << (log_dl + K)) | (w & ((1 << log_dl) - 1));
-        typename A::T x[1 << K];
-#pragma unroll
-        for (int e = 0; e < (1 << K); ++e) x[e] = sm[PAD(p + (e << log_dl))];
-#pragma unroll
-        for (int u = 0; u < K; ++u) {
-            const int du = 1 << u;
-            const int st = s + u;
-#pragma unroll
-            for (int h = 0; h < (1 << (K - 1 - u)); ++h) {
-                const int e0 = h << (u + 1);
-                const int idx = (1 << (logN - st - 1)) + ((base + p + (e0 << log_dl)) >> (st + 1 - adj));
-                const typename A::W wv = A::tw(c, idx);
-#pragma unroll
-                for (int t = 0; t < du; ++t) A::inv(c, x[e0 + t], x[e0 + t + du], wv, idx);
-            }
-        }
-        A::inv_end(c, x);
-#pragma unroll
-        for (int e = 0; e < (1 << K); ++e) sm[PAD(p + (e << log_dl))] = x[e];
-    }
-}
-
-template <class A, bool FAST>
-__device__ __forceinline__ void run_fwd_stages(typename A::T *sm, const PassGeom &g, int tile, const Ctx &c) {
-    const int T = 1 << g.tl;
-    const int E = g.strided ? g.tl : g.logN;
-    const int base = g.strided ? 0 : (tile << g.tl);
-    int s = g.s0, left = g.S, log_d = g.tl - 1;
-    if (FAST && g.tl == 12 && g.S == 12) {   // contiguous 4096-word pass: distances known at compile time
-        fwd_step<3, A, 9>(sm, T, 9, s, E, base, c); lds_barrier();
-        fwd_step<3, A, 6>(sm, T, 6, s + 3, E, base, c); lds_barrier();
-        fwd_step<3, A, 3>(sm, T, 3, s + 6, E, base, c); lds_barrier();
-        fwd_step<3, A, 0>(sm, T, 0, s + 9, E, base, c); lds_barrier();
-        return;
-    }
-    if (FAST && g.tl == 12 && left >= 3) {   // strided pass of a 4096-word tile: first step at distance 2^11
-        fwd_step<3, A, 9>(sm, T, 9, s, E, base, c); lds_barrier();
-        s += 3; left -= 3; log_d -= 3;
-    }
-    while (left > 0) {
-        if (FAST && left >= 3) {
-            fwd_step<3, A>(sm, T, log_d - 2, s, E, base, c);
-            s += 3; left -= 3; log_d -= 3;
-        } else if (FAST && left == 2) {
-            fwd_step<2, A>(sm, T, log_d - 1, s, E, base, c);
-            s += 2; left -= 2; log_d -= 2;
-        } else {
-            fwd_step<1, A>(sm, T, log_d, s, E, base, c);
-            s += 1; left -= 1; log_d -= 1;
-        }
-        lds_barrier();
-    }
-}
-
-template <class A, bool FAST>
-__device__ __forceinline__ void run_inv_stages(typename A::T *sm, const PassGeom &g, int tile, const Ctx &c) {
-    const int T = 1 << g.tl;
-    const int adj = g.strided ? (g.logN - g.S - g.logC) : 0;
-    const int base = g.strided ? 0 : (tile << g.tl);
-    int s = g.s0, left = g.S, log_d = g.strided ? g.logC : 0;
-    Ctx cc = c;
-    // fp64 class: words start < 2q; each step multiplies the bound by 2^K; reduce every second step
-    double bound = c.d.q2;
-    int nstep = 0;
-    auto arm = [&](int K) {
-        cc.inv_off = bound * (double)(1 << K);
-        bound = cc.inv_off;
-        ++nstep;
-        cc.inv_reduce = ((nstep & 1) == 0) || (left - K <= 0);
-        if (cc.inv_reduce) bound = c.d.q2;
-    };
-    if (FAST && g.tl == 12 && g.S == 12) {
-        arm(3); inv_step<3, A, 0>(sm, T, 0, s, adj, g.logN, base, cc); left -= 3; lds_barrier();
-        arm(3); inv_step<3, A, 3>(sm, T, 3, s + 3, adj, g.logN, base, cc); left -= 3; lds_barrier();
-        arm(3); inv_step<3, A, 6>(sm, T, 6, s + 6, adj, g.logN, base, cc); left -= 3; lds_barrier();
-        arm(3); inv_step<3, A, 9>(sm, T, 9, s + 9, adj, g.logN, base, cc); lds_barrier();
-        return;
-    }
-    while (left > 0) {
-        if (FAST && left >= 3) {
-            arm(3);
-            inv_step<3, A>(sm, T, log_d, s, adj, g.logN, base, cc);
-            s += 3; left -= 3; log_d += 3;
-        } else if (FAST && left == 2) {
-            arm(2);
-            inv_step<2, A>(sm, T, log_d, s, adj, g.logN, base, cc);
-            s += 2; left -= 2; log_d += 2;
-        } else {
-            arm(1);
-            inv_step<1, A>(sm, T, log_d, s, adj, g.logN, base, cc);
-            s += 1; left -= 1; log_d += 1;
-        }
-        lds_barrier();
-    }
-}
-
-__device__ __forceinline__ RowDp make_dp(const RowMod &m) {
-    RowDp d;
-    d.q = (double)m.q;
-    d.q2 = 2.0 * d.q;
-    d.qinv = 1.0 / d.q;
-    d.q2inv = 0.5 * d.qinv;
-    return d;
-}
-
-// LDS tile -> global, 16 B per lane
-__device__ __forceinline__ void store_tile_raw(const i64 *sm, i64 *row, const PassGeom &g, int tile) {
-    const int T = 1 << g.tl;
-    for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2) {
-        longlong2 v;
-        v.x = sm[PAD(L)];
-        v.y = sm[PAD(L + 1)];
-        *reinterpret_cast<longlong2 *>(row + tile_gaddr(g, tile, L)) = v;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// forward pass.  DP = true: fp64 class rows; false: integer class rows.
-// ------------------------------------------------------------------------------------------------
-template <bool DP>
-__global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_fwd_pass(i64 *__restrict__ a, PassGeom g, RowList rl,
-                                                            const i64 *__restrict__ psi_br, const double *__restrict__ psi_dp,
-                                                            const i64 *__restrict__ Rs, const i64 *__restrict__ ql,
-                                                            const i64 *__restrict__ qh, const i64 *__restrict__ kl,
-                                                            const i64 *__restrict__ kh) {
-    __shared__ i64 sm[NTT_LDS_WORDS + 1];
-    const int T = 1 << g.tl;
-    const bool enter = (Rs != nullptr);
-    // persistent block: a contiguous run of work items; the next tile's global loads are in flight
-    // while the current tile is transformed out of LDS
-    if (threadIdx.x == 0) sm[NTT_FLAG_WORD] = 0;   // both block_or flag words
-    lds_barrier();
-    longlong2 pre[NTT_PRE];
-    int poly, crow, tile;
-    block_coords(g, rl, poly, crow, tile);
-    prefetch_tile(pre, a + ((i64)(poly * g.rows + crow) << g.logN), g, tile);
-
-    {
-        const int item = 0;
-        Ctx c;
-        c.m = load_mod(ql, qh, kl, kh, crow);
-        c.d = make_dp(c.m);
-        c.tw_mont = psi_br + ((i64)crow << g.logN);
-        c.tw_dp = DP ? psi_dp + ((i64)crow << g.logN) : nullptr;
-        c.relaxed = g.relaxed;
-        i64 *row = a + ((i64)(poly * g.rows + crow) << g.logN);
-        const int cur_tile = tile;
-        const i64 rs = enter ? Rs[crow] : 0;
-
-        const int odd_raw = stash_tile(sm, pre, g, c.m.q2);
-        // relaxed fp64 tiles accept any non-negative residue representative
-        const bool odd = block_or(sm, odd_raw, item & 1) && !(DP && g.relaxed);
-
-        if (DP && !odd) {
-            double *smd = reinterpret_cast<double *>(sm);
-            // words -> doubles (+ optional Montgomery entry, emulated exactly: REDC62(a * R^2))
-            const double r1 = enter ? (double)((1ull << 62) % c.m.q) : 0.0;
-            for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2) {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const i64 raw = sm[PAD(L + e)];
-                    double v = dp_from_word(raw);
-                    if (enter) {
-                        v = dp_mulmod(v, r1, c.d);
-                        if (!g.relaxed && v < LAZY_FIX_LIMIT) v = dp_lazy_fix(v, (u64)raw, (u64)rs, c.d.q);
-                    }
-                    smd[PAD(L + e)] = v;
-                }
-            }
-            lds_barrier();
-            run_fwd_stages<ArithDp, true>(smd, g, cur_tile, c);
-            // the pass accumulated without subtractions: back to the lazy word in [0, 2q)
-            // (relaxed: the canonical residue)
-            const double md = g.relaxed ? c.d.q : c.d.q2, mi = g.relaxed ? c.d.qinv : c.d.q2inv;
-            for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2) {
-                longlong2 o;
-                o.x = dp_to_word(dp_reduce(smd[PAD(L)], md, mi));
-                o.y = dp_to_word(dp_reduce(smd[PAD(L + 1)], md, mi));
-                *reinterpret_cast<longlong2 *>(row + tile_gaddr(g, cur_tile, L)) = o;
-            }
-        } else {
-            // integer class (or a signed-lazy tile of the fp64 class)
-            int odd2 = 0;
-            if (enter) {
-                for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const i64 v = mm62s(sm[PAD(L + e)], rs, c.m.q, c.m.k);
-                        odd2 |= ((u64)v >= (u64)c.m.q2);
-                        sm[PAD(L + e)] = v;
-                    }
-                }
-            }
-            lds_barrier();
-            const bool sgn = block_or(sm, odd2, item & 1) || odd;
-            if (sgn || DP) run_fwd_stages<ArithInt<true>, false>(sm, g, cur_tile, c);   // rare: compact stage-by-stage loop
-            else run_fwd_stages<ArithInt<false>, true>(sm, g, cur_tile, c);
-            store_tile_raw(sm, row, g, cur_tile);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// inverse pass (+ fused chain tail on the last pass)
-// ------------------------------------------------------------------------------------------------
-template <bool DP>
-__global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_inv_pass(i64 *__restrict__ a, PassGeom g, RowList rl,
-                                                            const i64 *__restrict__ ipsi_br,
-                                                            const double *__restrict__ ipsi_dp, const i64 *__restrict__ Ninv,
-                                                            int tail, const i64 *__restrict__ ql, const i64 *__restrict__ qh,
-                                                            const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
-    __shared__ i64 sm[NTT_LDS_WORDS + 1];
-    const int T = 1 << g.tl;
-    if (threadIdx.x == 0) sm[NTT_FLAG_WORD] = 0;   // both block_or flag words
-    lds_barrier();
-    longlong2 pre[NTT_PRE];
-    int poly, crow, tile;
-    block_coords(g, rl, poly, crow, tile);
-    prefetch_tile(pre, a + ((i64)(poly * g.rows + crow) << g.logN), g, tile);
-
-    {
-        const int item = 0;
-        Ctx c;
-        c.m = load_mod(ql, qh, kl, kh, crow);
-        c.d = make_dp(c.m);
-        c.tw_mont = ipsi_br + ((i64)crow << g.logN);
-        c.tw_dp = DP ? ipsi_dp + ((i64)crow << g.logN) : nullptr;
-        c.relaxed = g.relaxed;
-        c.inv_off = 0.0;
-        c.inv_reduce = 0;
-        i64 *row = a + ((i64)(poly * g.rows + crow) << g.logN);
-        const int cur_tile = tile, cur_row = crow;
-        const i64 qq = (i64)c.m.q;
-
-        const int odd_raw = stash_tile(sm, pre, g, c.m.q2);
-        const bool odd = block_or(sm, odd_raw, item & 1);
-
-        if (DP && !odd) {
-            double *smd = reinterpret_cast<double *>(sm);
-            for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2) {
-                smd[PAD(L)] = dp_from_word(sm[PAD(L)]);
-                smd[PAD(L + 1)] = dp_from_word(sm[PAD(L + 1)]);
-            }
-            lds_barrier();
-            run_inv_stages<ArithDp, true>(smd, g, cur_tile, c);
-
-            // chain tail: z = REDC(t * Ninv); [redc]; [reduce]; [signed]    (K.cu:527-529, 754-902)
-            const double ninv_plain = c.d.q - (double)((c.m.q - 1) >> g.logN);                  // N^-1 mod q
-            const double rinv = (double)(u64)((((u128)c.m.k * (u128)c.m.q) + 1) >> 62);         // R^-1 mod q
-            const double c2 = dp_mulmod(ninv_plain, rinv, c.d);                                 // N^-1 R^-1 mod q
-            const i64 ninv_mont = (tail != TAIL_NONE) ? Ninv[cur_row] : 0;
-            for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2) {
-                i64 o[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const double t = smd[PAD(L + e)];
-                    double z;
-                    if (tail == TAIL_NONE) {
-                        z = t;
-                    } else if (tail >= 2) {
-                        // redc then reduce yield the canonical residue of t * N^-1 * R^-1 whatever lazy
-                        // representatives the intermediate steps took (redc(q) = q reduces to 0)
-                        z = dp_mulmod(t, c2, c.d);
-                        if (tail >= 3) z = z <= (double)(qq >> 1) ? z : z - c.d.q;
-                    } else {
-                        z = dp_mulmod(t, ninv_plain, c.d);
-                        if (z < LAZY_FIX_LIMIT) z = dp_lazy_fix(z, (u64)t, (u64)ninv_mont, c.d.q);
-                        if (tail == 1) z = (z == c.d.q) ? c.d.q : dp_mulmod(z, rinv, c.d);   // redc(q) = q (K.cu:587-606)
-                    }
-                    o[e] = (tail >= 3) ? (i64)z : dp_to_word(z);
-                }
-                longlong2 ov;
-                ov.x = o[0];
-                ov.y = o[1];
-                *reinterpret_cast<longlong2 *>(row + tile_gaddr(g, cur_tile, L)) = ov;
-            }
-        } else {
-            if (odd || DP) run_inv_stages<ArithInt<true>, false>(sm, g, cur_tile, c);   // rare: compact stage-by-stage loop
-            else run_inv_stages<ArithInt<false>, true>(sm, g, cur_tile, c);
-            const i64 ninv = (tail != TAIL_NONE) ? Ninv[cur_row] : 0;
-            for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2) {
-                i64 t[2] = {sm[PAD(L)], sm[PAD(L + 1)]};
-                if (tail != TAIL_NONE) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        i64 z = mm62s(t[e], ninv, c.m.q, c.m.k);
-                        if (tail >= 1) z = redc62(z, c.m.q, c.m.k);
-                        if (tail >= 2) z = z < qq ? z : z - qq;
-                        if (tail >= 3) z = z <= (qq >> 1) ? z : z - qq;
-                        t[e] = z;
-                    }
-                }
-                longlong2 v;
-                v.x = t[0];
-                v.y = t[1];
-                *reinterpret_cast<longlong2 *>(row + tile_gaddr(g, cur_tile, L)) = v;
-            }
-        }
-    }
-}
-
-// plain canonical twiddles as doubles from the Montgomery table: w = reduce(redc(S))
-__global__ void __launch_bounds__(256) twiddle_dp_kernel(const i64 *__restrict__ mont, double *__restrict__ out, i64 N,
-                                                         const i64 *__restrict__ ql, const i64 *__restrict__ qh,
-                                                         const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
-    const int r = blockIdx.y;
-    const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
-    if (j >= N) return;
-    const RowMod m = load_mod(ql, qh, kl, kh, r);
-    i64 v = redc62(mont[(i64)r * N + j], m.q, m.k);
-    v = v < (i64)m.q ? v : v - (i64)m.q;
-    out[(i64)r * N + j] = (double)v;
-}
 
 // split the rows into the two arithmetic classes (host side; q_host may be NULL = all integer)
 void classify(int rows, const int64_t *q_host, const void *dp_table, RowList &dp, RowList &in) {
@@ -626,6 +45,31 @@ void classify(int rows, const int64_t *q_host, const void *dp_table, RowList &dp
         RowList &dst = small ? dp : in;
         dst.id[dst.n++] = (unsigned short)r;
     }
+}
+
+// The two arithmetic classes of one transform are independent (disjoint limbs), but launches on one
+// stream serialise.  The integer class (a handful of 60-bit limbs) therefore runs on a per-device side
+// stream, forked from and joined back into the caller's stream with events, so its few blocks overlap
+// the fp64 class instead of adding a tail after every pass.
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+
+SideStream *side_stream(int device) {
+    static std::mutex mu;
+    static SideStream table[64];
+    int dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    SideStream &s = table[dev];
+    if (!s.stream) {
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { s.stream = nullptr; return nullptr; }
+        if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    }
+    return &s;
 }
 
 // polynomials per launch group: optional split of a batch into launch groups of `LF_NTT_CHUNK_MB` MiB (experiment knob, default off)
@@ -670,26 +114,34 @@ int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, con
     RowList dp, in;
     classify(rows, q_host, psi_dp, dp, in);
     hipStream_t st = (hipStream_t)stream;
-    // Two passes stream the stack twice.  Polynomials are processed in chunks small enough for the
-    // intermediate of a chunk to stay in the 256 MiB Infinity Cache between its two passes.
+    SideStream *side = (dp.n && in.n) ? side_stream(device) : nullptr;
+    hipStream_t st_int = side ? side->stream : st;
+    if (side) {
+        (void)hipEventRecord(side->fork, st);
+        (void)hipStreamWaitEvent(side->stream, side->fork, 0);
+    }
     const int chunk = chunk_polys(batch, rows, logN, S1 > 0);
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int nb = batch - b0 < chunk ? batch - b0 : chunk;
         i64 *base = (i64 *)a + ((i64)b0 * rows << logN);
         const unsigned per_row = (unsigned)nb << (logN - tl);
         for (int pass = (S1 > 0 ? 0 : 1); pass < 2; ++pass) {
-            const PassGeom g = pass == 0 ? PassGeom{logN, tl, 1, S1, 0, tl - S1, rows, nb, relaxed, 0}
-                                         : PassGeom{logN, tl, 0, tl, S1, 0, rows, nb, relaxed, 1};
+            const PassGeom g = pass == 0 ? PassGeom{logN, tl, 1, S1, 0, tl - S1, rows, nb, relaxed, 0, 1, 0}
+                                         : PassGeom{logN, tl, 0, tl, S1, 0, rows, nb, relaxed, 1, 1, 0};
             const i64 *rs = (pass == 0 || S1 == 0) ? (const i64 *)Rs : nullptr;
             if (dp.n)
                 hipLaunchKernelGGL(ntt_fwd_pass<true>, dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, base, g, dp,
                                    (const i64 *)psi_br, psi_dp, rs, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl,
                                    (const i64 *)kh);
             if (in.n)
-                hipLaunchKernelGGL(ntt_fwd_pass<false>, dim3(per_row * in.n), dim3(NTT_THREADS), 0, st, base, g, in,
+                hipLaunchKernelGGL(ntt_fwd_pass<false>, dim3(per_row * in.n), dim3(NTT_THREADS), 0, st_int, base, g, in,
                                    (const i64 *)psi_br, psi_dp, rs, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl,
                                    (const i64 *)kh);
         }
+    }
+    if (side) {
+        (void)hipEventRecord(side->join, side->stream);
+        (void)hipStreamWaitEvent(st, side->join, 0);
     }
     return (int)hipGetLastError();
 }
@@ -709,24 +161,34 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
     RowList dp, in;
     classify(rows, q_host, ipsi_dp, dp, in);
     hipStream_t st = (hipStream_t)stream;
+    SideStream *side = (dp.n && in.n) ? side_stream(device) : nullptr;
+    hipStream_t st_int = side ? side->stream : st;
+    if (side) {
+        (void)hipEventRecord(side->fork, st);
+        (void)hipStreamWaitEvent(side->stream, side->fork, 0);
+    }
     const int chunk = chunk_polys(batch, rows, logN, SB > 0);
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int nb = batch - b0 < chunk ? batch - b0 : chunk;
         i64 *base = (i64 *)a + ((i64)b0 * rows << logN);
         const unsigned per_row = (unsigned)nb << (logN - tl);
         for (int pass = 0; pass < (SB > 0 ? 2 : 1); ++pass) {
-            const PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, nb, relaxed, SB == 0}
-                                         : PassGeom{logN, tl, 1, SB, tl, tl - SB, rows, nb, relaxed, 1};
+            const PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, nb, relaxed, SB == 0, 1, 0}
+                                         : PassGeom{logN, tl, 1, SB, tl, tl - SB, rows, nb, relaxed, 1, 1, 0};
             const int t = g.last ? tail : TAIL_NONE;
             if (dp.n)
-                hipLaunchKernelGGL(ntt_inv_pass<true>, dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, base, g, dp,
+                hipLaunchKernelGGL(ntt_inv_pass_io<true>, dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, (const i64 *)base, base, g, dp,
                                    (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t, (const i64 *)ql, (const i64 *)qh,
                                    (const i64 *)kl, (const i64 *)kh);
             if (in.n)
-                hipLaunchKernelGGL(ntt_inv_pass<false>, dim3(per_row * in.n), dim3(NTT_THREADS), 0, st, base, g, in,
+                hipLaunchKernelGGL(ntt_inv_pass_io<false>, dim3(per_row * in.n), dim3(NTT_THREADS), 0, st_int, (const i64 *)base, base, g, in,
                                    (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t, (const i64 *)ql, (const i64 *)qh,
                                    (const i64 *)kl, (const i64 *)kh);
         }
+    }
+    if (side) {
+        (void)hipEventRecord(side->join, side->stream);
+        (void)hipStreamWaitEvent(st, side->join, 0);
     }
     return (int)hipGetLastError();
 }

@@ -93,6 +93,20 @@ class HipBackend:
         check(lib.lf_ks_inner(_p(ext), base, part_stride, comp_stride, row_off, _p(s0), _p(s1), nparts, rows, N,
                               *c.mont(), dev, st), "lf_ks_inner")
 
+    fused_ks_min_logN = 13   # lf_ks_core needs a two-pass ring degree
+
+    def ks_core(self, state, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv,
+                c: Consts):
+        """extend + NTT + key inner product + inverse NTT in three fused launches per arithmetic class."""
+        dev, st = _ds(s)
+        part_stride, comp_stride = key.stride(0), key.stride(1)
+        base = key.data_ptr() + first_part * part_stride * 8
+        psi_dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
+        ipsi_dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
+        check(lib.lf_ks_core(_p(state), nparts, rows, logN, _p(desc), _p(E), Ed.data_ptr(), base, part_stride, comp_stride,
+                             row_off, _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
+                             c.qptr(), *c.mont(), dev, st), "lf_ks_core")
+
     def ks_moddown(self, s, out, addend, ell, K, PiR, Rs, c: Consts):
         dev, st = _ds(out)
         check(lib.lf_ks_moddown(_p(s), _p(out), _p(addend), ell, K, out.size(-1), _p(PiR), _p(Rs), *c.mont(), dev, st),

@@ -709,8 +709,17 @@ class ckks_engine:
                 for i in range(len(m)):
                     flat += [L * ctx.R_square[r] % ctx.q[r] for r in dest]
                     L *= m[i]
-                desc.append([row_start[s], len(rows), e_off])
-            tabs[("extend", d)] = (self._t64(desc, d), self._t64(flat, d))
+                wide = any(ctx.q[i] >= (1 << 41) for i in primes)   # digit words beyond fp64's 53 bits
+                desc.append([row_start[s], len(rows) | (int(wide) << 8), e_off])
+            # the same constants as plain residues in doubles (fp64 class of the fused core): L_{i-1} mod q_r
+            plain = []
+            for s_, (_, rows, primes) in enumerate(order):
+                L = 1
+                for i in range(len(primes)):
+                    plain += [float(L % ctx.q[r]) for r in dest]
+                    L *= ctx.q[primes[i]]
+            tabs[("extend", d)] = (self._t64(desc, d), self._t64(flat, d),
+                                   torch.tensor(plain, dtype=torch.float64, device=self.ntt.devices[d]))
             # (3) P_j^-1 R table, [K][rows]
             K, nrows = self.ntt.num_special_primes, len(dest)
             pir = torch.zeros((K, nrows), dtype=torch.int64, device=self.ntt.devices[d])
@@ -786,16 +795,23 @@ class ckks_engine:
         for i, d in enumerate(loc):
             rows, ell = self._rows(d, level, True), self._rows(d, level, False)
             cs = self._consts(d, level, True)
-            # 3. extend every digit to this device's rows, forward NTT
             ext = self._ws("ks_ext", (nparts, rows, N), d)
-            desc, E = tabs[("extend", d)]
-            self.backend.ks_extend(digits[d], ext, nparts, rows, desc, E, cs)
-            self.backend.ntt(ext, nparts, rows, logN, self._tw(d, level, True), None, cs)
-            # 4. inner product with the key (streams the key once), inverse NTT
+            desc, E, Ed = tabs[("extend", d)]
             s = self._ws("ks_sum", (2, rows, N), d)
-            self.backend.ks_inner(ext, packs[loc0.index(d)], tabs["first_part"], self.ntt.starts[level][d], s[0], s[1],
-                                  nparts, rows, cs)
-            self.backend.intt(s, 2, rows, logN, self._tw(d, level, True, True), self._vec("Ninv", d, level, True), 2, cs)
+            key, tw, itw = packs[loc0.index(d)], self._tw(d, level, True), self._tw(d, level, True, True)
+            ninv = self._vec("Ninv", d, level, True)
+            if logN >= self.backend.fused_ks_min_logN:
+                # 3+4. fused core: extend + NTT + key inner product + inverse NTT, the extended digits never
+                # leave the chip in coefficient form
+                self.backend.ks_core(digits[d], nparts, rows, logN, desc, E, Ed, key, tabs["first_part"],
+                                     self.ntt.starts[level][d], ext, s, tw, itw, ninv, cs)
+            else:
+                # 3. extend every digit to this device's rows, forward NTT
+                self.backend.ks_extend(digits[d], ext, nparts, rows, desc, E, cs)
+                self.backend.ntt(ext, nparts, rows, logN, tw, None, cs, relaxed=True)
+                # 4. inner product with the key (streams the key once), inverse NTT
+                self.backend.ks_inner(ext, key, tabs["first_part"], self.ntt.starts[level][d], s[0], s[1], nparts, rows, cs)
+                self.backend.intt(s, 2, rows, logN, itw, ninv, 2, cs, relaxed=True)
             # 5. divide by P (+ optional addend)
             out = torch.empty((2, ell, N), dtype=torch.int64, device=self.ntt.devices[d])
             rs = self._vec("Rs", d, level, True)

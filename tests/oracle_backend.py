@@ -234,6 +234,7 @@ class OracleBackend:
         D, Et = _np(desc).reshape(-1, 3), _np(E)
         for p in range(nparts):
             r0, alpha, e_off = (int(x) for x in D[p])
+            alpha &= 0xff   # bit 8 is a hint for the HIP fused core (digit words wider than 53 bits)
             acc = np.repeat(S[r0:r0 + 1], rows, axis=0).copy()
             orc.mont_enter(acc, Et[e_off:e_off + rows].copy(), rows, *self._m(c))
             for i in range(1, alpha):
@@ -261,6 +262,15 @@ class OracleBackend:
                     orc.mont_add(acc, prod, nxt, rows, _np(c._2q))
                     acc = nxt
             _np(dst)[:rows] = acc
+
+    fused_ks_min_logN = 13
+
+    def ks_core(self, state, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv, c):
+        """The fused core as the sequence it replaces: extend, NTT, inner product + sum, inverse NTT chain."""
+        self.ks_extend(state, tmp, nparts, rows, desc, E, c)
+        self.ntt(tmp, nparts, rows, logN, psi, None, c)
+        self.ks_inner(tmp, key, first_part, row_off, s[0], s[1], nparts, rows, c)
+        self.intt(s, 2, rows, logN, ipsi, Ninv, 2, c)
 
     # ---- divide by P: ckks_engine.py:850-901 (+ relinearize 1135-1140 / switch_key 952-953) ----
     def ks_moddown(self, s, out, addend, ell, K, PiR, Rs, c):

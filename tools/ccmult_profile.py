@@ -1,0 +1,22 @@
+"""Kernel-level timing of one engine op (development aid): python tools/ccmult_profile.py gold cc_mult"""
+import sys, os, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+warnings.filterwarnings("ignore")
+import torch
+from liberate_fhe_amd.fhe import ckks_engine, presets
+from liberate_fhe_amd.utils import synth
+name = sys.argv[1] if len(sys.argv) > 1 else "gold"
+op = sys.argv[2] if len(sys.argv) > 2 else "cc_mult"
+eng = ckks_engine(**{**presets.params[name], "devices": ["cuda:0"]})
+a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
+evk = synth.key_switch_key(eng, 5)
+rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
+fn = (lambda: eng.cc_mult(a, b, evk)) if op == "cc_mult" else (lambda: eng.rotate_single(a, rotk))
+for _ in range(3): fn()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+n = 10
+e0.record()
+for _ in range(n): fn()
+e1.record(); torch.cuda.synchronize()
+print(f"{name} {op}: {e0.elapsed_time(e1)/n*1e3:.1f} us/op  {n/e0.elapsed_time(e1)*1e3:.1f} ops/s")
