@@ -144,9 +144,11 @@ int lf_ks_inner(const int64_t *ext, const int64_t *ksk, int64_t part_stride, int
 
 /* division by P = prod(special primes) (ckks_engine.py:850-901) on canonical coefficient rows s[ell+K][N];
  * PiR[P_ind][row] = P_j^-1 R mod q_row ([K][ell+K], specials last-first); optional addend:
- * out = reduce_q(result + addend) (relinearize 1135-1140 / switch_key 952-953). */
+ * out = reduce_q(result + addend) (relinearize 1135-1140 / switch_key 952-953).
+ * PiP (optional, may be NULL): the same table as plain residues P_j^-1 mod q_row in doubles; when given,
+ * rows with a prime below 2^41 take the fp64 path (identical canonical output). */
 int lf_ks_moddown(const int64_t *s, int64_t *out, const int64_t *addend, int ell, int K, int64_t N,
-                  const int64_t *PiR, const int64_t *Rs, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+                  const int64_t *PiR, const double *PiP, const int64_t *Rs, const int64_t *ql, const int64_t *qh, const int64_t *kl,
                   const int64_t *kh, int device, void *stream);
 
 /* Fused key-switch core for two-pass ring degrees (logN >= 13): extend + NTT + inner product with the key +

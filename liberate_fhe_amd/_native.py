@@ -44,7 +44,7 @@ _SIGNATURES = {
     "lf_ks_digits": [_P, _P, _I, _P, _P, _L, _P, _P, _P, _P, _I, _P],
     "lf_ks_extend": [_P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_ks_inner": [_P, _P, _L, _L, _L, _P, _P, _I, _I, _L, _P, _P, _P, _P, _I, _P],
-    "lf_ks_moddown": [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lf_ks_moddown": [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_ks_core": [_P, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
 }
 

@@ -163,9 +163,19 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(const i64 *__restrict__ e
 // eliminated last-first; PiR[P_ind][row] = P_j^-1 * R mod q_row.  Optional `addend` (relinearize's
 // d0/d1 or the rotated c0): out = reduce_q(result + addend)  (ckks_engine.py:1135-1140, 952-953).
 #define MD_ROWS 8
+// (a * w) mod q in fp64 for q < 2^41, |a| < 2^52, 0 <= w < q (see ckks_ntt_core.h)
+__device__ __forceinline__ double dp_mulmod_q(double a, double w, double q, double qinv) {
+    const double hi = a * w;
+    const double lo = __builtin_fma(a, w, -hi);
+    const double quo = __builtin_rint(hi * qinv);
+    const double r = __builtin_fma(-quo, q, hi) + lo;
+    return r < 0.0 ? r + q : r;
+}
+
 __global__ void __launch_bounds__(256) ks_moddown_kernel(const i64 *__restrict__ s, i64 *__restrict__ out,
                                                          const i64 *__restrict__ addend, int ell, int K, i64 N,
-                                                         const i64 *__restrict__ PiR, const i64 *__restrict__ Rs,
+                                                         const i64 *__restrict__ PiR, const double *__restrict__ PiP,
+                                                         const i64 *__restrict__ Rs,
                                                          const i64 *__restrict__ ql, const i64 *__restrict__ qh,
                                                          const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
     const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -199,19 +209,40 @@ __global__ void __launch_bounds__(256) ks_moddown_kernel(const i64 *__restrict__
     const int r0 = blockIdx.y * MD_ROWS;
     for (int r = r0; r < r0 + MD_ROWS && r < ell; ++r) {
         const RowMod m = load_mod(ql, qh, kl, kh, r);
-        const i64 rs = Rs[r];
-        i64 d = mm62s(s[(i64)r * N + j], rs, m.q, m.k);
+        i64 d;
+        if (PiP != nullptr && m.q < (1ull << 41)) {
+            // fp64 class: the chain ((s - p_0) / P_0 - p_1) / P_1 ... in the plain domain, one modular product
+            // per special prime; the 60-bit pivots enter fp64 as 31-bit halves.  Same canonical result.
+            const double q = (double)m.q, qinv = 1.0 / q;
+            double x = (double)s[(i64)r * N + j];                    // canonical < q
+            const double two31 = 2147483648.0;
 #pragma unroll
-        for (int pi = 0; pi < KS_MAX_K; ++pi) {
-            if (pi < K) {
-                const i64 Q = mm62s(pv[pi], rs, m.q, m.k);
-                d = csub(d + m.q2 - Q, m.q2);
-                d = mm62s(d, PiR[(i64)pi * rows + r], m.q, m.k);
-                d = d < (i64)m.q ? d : d - (i64)m.q;
+            for (int pi = 0; pi < KS_MAX_K; ++pi) {
+                if (pi < K) {
+                    const double ph = (double)(pv[pi] >> 31), pl = (double)(pv[pi] & 0x7fffffffll);
+                    // pivot mod q (< 3q after the two terms), then (x - pivot) * P^-1 mod q
+                    double pm = dp_mulmod_q(ph, two31, q, qinv) + pl;
+                    pm = pm >= q ? pm - q : pm;
+                    pm = pm >= q ? pm - q : pm;
+                    x = dp_mulmod_q(x - pm + q, PiP[(i64)pi * rows + r], q, qinv);
+                }
             }
+            d = (i64)x;
+        } else {
+            const i64 rs = Rs[r];
+            d = mm62s(s[(i64)r * N + j], rs, m.q, m.k);
+#pragma unroll
+            for (int pi = 0; pi < KS_MAX_K; ++pi) {
+                if (pi < K) {
+                    const i64 Q = mm62s(pv[pi], rs, m.q, m.k);
+                    d = csub(d + m.q2 - Q, m.q2);
+                    d = mm62s(d, PiR[(i64)pi * rows + r], m.q, m.k);
+                    d = d < (i64)m.q ? d : d - (i64)m.q;
+                }
+            }
+            d = redc62(d, m.q, m.k);
+            d = d < (i64)m.q ? d : d - (i64)m.q;
         }
-        d = redc62(d, m.q, m.k);
-        d = d < (i64)m.q ? d : d - (i64)m.q;
         if (addend) {
             d += addend[(i64)r * N + j];
             d = d < (i64)m.q ? d : d - (i64)m.q;
@@ -286,14 +317,14 @@ int lf_ks_inner(const int64_t *ext, const int64_t *ksk, int64_t part_stride, int
 }
 
 int lf_ks_moddown(const int64_t *s, int64_t *out, const int64_t *addend, int ell, int K, int64_t N, const int64_t *PiR,
-                  const int64_t *Rs, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+                  const double *PiP, const int64_t *Rs, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
                   void *stream) {
     if (ell < 0 || K < 1 || K > KS_MAX_K || N < 1) return LF_ERR_ARG;
     if (ell == 0) return 0;
     if (int e = lf_set_device(device)) return e;
     dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ell + MD_ROWS - 1) / MD_ROWS));
     hipLaunchKernelGGL(ks_moddown_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const i64 *)s, (i64 *)out,
-                       (const i64 *)addend, ell, K, (i64)N, (const i64 *)PiR, (const i64 *)Rs, (const i64 *)ql,
+                       (const i64 *)addend, ell, K, (i64)N, (const i64 *)PiR, PiP, (const i64 *)Rs, (const i64 *)ql,
                        (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     return (int)hipGetLastError();
 }

@@ -92,19 +92,19 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ks_ext_pass1(const i6
                 if (i < alpha) {
                     const longlong2 y = *reinterpret_cast<const longlong2 *>(state + (i64)(row_start + i) * kg.N + j);
                     if (!wide) {
-                        a0 += dp_mulmod((double)y.x, cst[i], c.d);    // signed digit words: the formula is sign-agnostic
-                        a1 += dp_mulmod((double)y.y, cst[i], c.d);
+                        a0 += dp_mulmod_bal((double)y.x, cst[i], c.d);    // signed digit words: the formula is sign-agnostic
+                        a1 += dp_mulmod_bal((double)y.y, cst[i], c.d);
                     } else {
-                        a0 += dp_mulmod((double)(y.x >> 31), cst31[i], c.d) + dp_mulmod((double)(y.x & 0x7fffffffll), cst[i], c.d);
-                        a1 += dp_mulmod((double)(y.y >> 31), cst31[i], c.d) + dp_mulmod((double)(y.y & 0x7fffffffll), cst[i], c.d);
+                        a0 += dp_mulmod_bal((double)(y.x >> 31), cst31[i], c.d) + dp_mulmod_bal((double)(y.x & 0x7fffffffll), cst[i], c.d);
+                        a1 += dp_mulmod_bal((double)(y.y >> 31), cst31[i], c.d) + dp_mulmod_bal((double)(y.y & 0x7fffffffll), cst[i], c.d);
                     }
                 }
             }
-            smd[PAD(L)] = a0;        // < 2 * alpha * q
+            smd[PAD(L)] = a0;        // |.| < alpha * q (balanced terms)
             smd[PAD(L + 1)] = a1;
         }
         lds_barrier();
-        run_fwd_stages<ArithDp, true>(smd, g, tile, c);
+        run_fwd_stages<ArithDpR, true>(smd, g, tile, c);
         for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2) {
             longlong2 o;
             o.x = dp_to_word(dp_reduce(smd[PAD(L)], c.d.q, c.d.qinv));

@@ -159,6 +159,19 @@ __device__ __forceinline__ double dp_mulmod(double a, double w, const RowDp &m) 
     return dp_addmask(r, m.q);
 }
 
+// (a * w) mod q as a BALANCED residue in [-q/2, q/2] (no sign fix-up): 6 fp64 ops.  |a| < 2^52.
+__device__ __forceinline__ double dp_mulmod_bal(double a, double w, const RowDp &m) {
+    const double hi = a * w;
+    const double lo = __builtin_fma(a, w, -hi);
+    const double quo = __builtin_rint(hi * m.qinv);
+    return __builtin_fma(-quo, m.q, hi) + lo;
+}
+
+// x mod q as a balanced residue, |x| < 2^52
+__device__ __forceinline__ double dp_reduce_bal(double x, const RowDp &m) {
+    return __builtin_fma(-__builtin_rint(x * m.qinv), m.q, x);
+}
+
 // x mod m for 0 <= x < 2^52 (m = q or 2q, minv its reciprocal)
 __device__ __forceinline__ double dp_reduce(double x, double m, double minv) {
     const double quo = __builtin_rint(x * minv);
@@ -245,6 +258,35 @@ struct ArithDp {
         if (c.inv_reduce) {
 #pragma unroll
             for (int e = 0; e < NN; ++e) x[e] = dp_reduce(x[e], c.d.q2, c.d.q2inv);
+        }
+    }
+};
+
+// fp64 class, RELAXED: only the residue mod q matters, so products stay balanced (no sign fix-up), sums
+// and differences are plain fp64 adds on signed words, and nothing is compared or subtracted per
+// butterfly: 8 fp64 instructions per butterfly instead of 13.  Forward words grow by q/2 per stage;
+// inverse words double per stage and are folded back to balanced residues every second step.
+struct ArithDpR {
+    typedef double T;
+    typedef double W;
+    static __device__ __forceinline__ W tw(const Ctx &c, int idx) { return c.tw_dp[(unsigned)idx]; }
+    static __device__ __forceinline__ void fwd(const Ctx &c, T &a, T &b, W w, int) {
+        const T U = a, V = dp_mulmod_bal(b, w, c.d);
+        a = U + V;
+        b = U - V;
+    }
+    static __device__ __forceinline__ void inv(const Ctx &c, T &a, T &b, W w, int) {
+        const T U = a, V = b;
+        b = dp_mulmod_bal(U - V, w, c.d);
+        a = U + V;
+    }
+    template <int NN>
+    static __device__ __forceinline__ void fwd_end(const Ctx &, T (&)[NN]) {}
+    template <int NN>
+    static __device__ __forceinline__ void inv_end(const Ctx &c, T (&x)[NN]) {
+        if (c.inv_reduce) {
+#pragma unroll
+            for (int e = 0; e < NN; ++e) x[e] = dp_reduce_bal(x[e], c.d);
         }
     }
 };
@@ -459,7 +501,8 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_fwd_pass(i64 *__r
                 }
             }
             lds_barrier();
-            run_fwd_stages<ArithDp, true>(smd, g, cur_tile, c);
+            if (g.relaxed) run_fwd_stages<ArithDpR, true>(smd, g, cur_tile, c);
+            else run_fwd_stages<ArithDp, true>(smd, g, cur_tile, c);
             // the pass accumulated without subtractions: back to the lazy word in [0, 2q)
             // (relaxed: the canonical residue)
             const double md = g.relaxed ? c.d.q : c.d.q2, mi = g.relaxed ? c.d.qinv : c.d.q2inv;
@@ -533,7 +576,8 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_inv_pass_io(const
                 smd[PAD(L + 1)] = dp_from_word(sm[PAD(L + 1)]);
             }
             lds_barrier();
-            run_inv_stages<ArithDp, true>(smd, g, cur_tile, c);
+            if (g.relaxed) run_inv_stages<ArithDpR, true>(smd, g, cur_tile, c);
+            else run_inv_stages<ArithDp, true>(smd, g, cur_tile, c);
 
             // chain tail: z = REDC(t * Ninv); [redc]; [reduce]; [signed]    (K.cu:527-529, 754-902)
             const double ninv_plain = c.d.q - (double)((c.m.q - 1) >> g.logN);                  // N^-1 mod q
@@ -547,7 +591,7 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_inv_pass_io(const
                     const double t = smd[PAD(L + e)];
                     double z;
                     if (tail == TAIL_NONE) {
-                        z = t;
+                        z = g.relaxed ? dp_addmask(t, c.d.q) : t;   // relaxed words are balanced residues
                     } else if (tail >= 2) {
                         // redc then reduce yield the canonical residue of t * N^-1 * R^-1 whatever lazy
                         // representatives the intermediate steps took (redc(q) = q reduces to 0)

@@ -107,7 +107,7 @@ class HipBackend:
                              row_off, _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
                              c.qptr(), *c.mont(), dev, st), "lf_ks_core")
 
-    def ks_moddown(self, s, out, addend, ell, K, PiR, Rs, c: Consts):
+    def ks_moddown(self, s, out, addend, ell, K, PiR, Rs, c: Consts, PiP=None):
         dev, st = _ds(out)
-        check(lib.lf_ks_moddown(_p(s), _p(out), _p(addend), ell, K, out.size(-1), _p(PiR), _p(Rs), *c.mont(), dev, st),
-              "lf_ks_moddown")
+        check(lib.lf_ks_moddown(_p(s), _p(out), _p(addend), ell, K, out.size(-1), _p(PiR),
+                                0 if PiP is None else PiP.data_ptr(), _p(Rs), *c.mont(), dev, st), "lf_ks_moddown")

@@ -727,6 +727,11 @@ class ckks_engine:
                 v = self.PiRs[level][P_ind][d]
                 pir[P_ind, :len(v)] = v
             tabs[("pir", d)] = pir
+            # plain P_j^-1 mod q_row as doubles (fp64 class of the mod-down kernel)
+            specials = ctx.q[-K:][::-1]
+            tabs[("pip", d)] = torch.tensor(
+                [[float(pow(specials[P_ind], -1, ctx.q[r])) if i < nrows - P_ind - 1 else 0.0 for i, r in enumerate(dest)]
+                 for P_ind in range(K)], dtype=torch.float64, device=self.ntt.devices[d])
         # (4) gather map for the digit all-gather (multi-device): row of the stacked per-device states
         if n_alive > 1:
             max_rows = max(self._rows(d, level, False) for d in range(n_alive))
@@ -819,7 +824,7 @@ class ckks_engine:
                 add = addends[comp][i] if addends is not None and addends[comp] is not None else None
                 if add is not None and not add.is_contiguous():
                     add = add.contiguous()
-                self.backend.ks_moddown(s[comp], out[comp], add, ell, K, tabs[("pir", d)], rs, cs)
+                self.backend.ks_moddown(s[comp], out[comp], add, ell, K, tabs[("pir", d)], rs, cs, PiP=tabs[("pip", d)])
             c0.append(out[0]); c1.append(out[1])
         return c0, c1
 

@@ -273,7 +273,7 @@ class OracleBackend:
         self.intt(s, 2, rows, logN, ipsi, Ninv, 2, c)
 
     # ---- divide by P: ckks_engine.py:850-901 (+ relinearize 1135-1140 / switch_key 952-953) ----
-    def ks_moddown(self, s, out, addend, ell, K, PiR, Rs, c):
+    def ks_moddown(self, s, out, addend, ell, K, PiR, Rs, c, PiP=None):
         rows = ell + K
         d = np.ascontiguousarray(_np(s)[:rows]).copy()
         ql, qh, kl, kh = self._m(c)
