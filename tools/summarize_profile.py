@@ -44,17 +44,17 @@ for counter, sub, stem in (("FETCH_SIZE", f"pmc_fetch_{tag}", "fetch"), ("WRITE_
                  "from counters_collection group by kernel_name")
     for r in rows:
         pm.append(f"{counter:10s} | {r[0][:70]:70s} | n={r[2]:4d} | avg={r[3]:12.1f} | min={r[4]:12.1f} | max={r[5]:12.1f} | avg_ns={r[6]:10.0f}")
-    disp = q(db, "select dispatch_id, value, duration from counters_collection where kernel_name like '%ntt_fwd_pass%' order by dispatch_id")
+    disp = q(db, "select dispatch_id, value, duration from counters_collection where kernel_name like '%ntt_fwd_pass<true>%' order by dispatch_id")
     per[counter] = disp
     pm.append("")
-pm.append("# ntt_fwd_pass dispatches alternate: strided pass (4 stages) / contiguous pass (12 stages + twiddles)")
+pm.append("# ntt_fwd_pass<true> (fp64 class, 25 limbs x 16 polynomials) dispatches alternate: strided pass (4 stages) / contiguous pass (12 stages + twiddles)")
 for (d, v, ns), (_, w, _) in zip(per["FETCH_SIZE"], per["WRITE_SIZE"]):
     pm.append(f"dispatch {d}: FETCH_SIZE={v:10.1f} KiB -> {2 * v * 1024 / 1e6:7.1f} MB read (corrected) | WRITE_SIZE={w:10.1f} KiB -> {w * 1024 / 1e6:7.1f} MB | {ns / 1e3:7.1f} us")
 open(os.path.join(out_dir, f"{tag}_bench_pmc_hbm.txt"), "w").write("\n".join(pm) + "\n")
 
 fetch = sum(v for _, v, _ in per["FETCH_SIZE"]) / len(per["FETCH_SIZE"])
 write = sum(v for _, v, _ in per["WRITE_SIZE"]) / len(per["WRITE_SIZE"])
-traffic = {"ntt_fwd_pass_bytes_per_launch": (2 * fetch + write) * 1024,
+traffic = {"ntt_fwd_pass_dp_bytes_per_launch": (2 * fetch + write) * 1024,
            "fetch_kib_avg_raw": fetch, "write_kib_avg": write,
            "note": "average over the two passes of one transform; FETCH_SIZE doubled per the gfx950 1/2-count caveat"}
 json.dump(traffic, open(os.path.join(out_dir, f"traffic_{tag}.json"), "w"), indent=1)
