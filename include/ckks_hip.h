@@ -83,6 +83,10 @@ int lf_mont_sub(const int64_t *a, const int64_t *b, int64_t *c, int rows, int64_
  * residues instead of the reference's lazy representatives) — for fused internal use, never for the
  * drop-in ops. */
 #define LF_NTT_RELAXED 1
+/* with LF_NTT_RELAXED: fp64-class limbs stay in the PLAIN domain — lf_ntt applies Rs to integer-class limbs
+ * only, lf_intt (tail >= 2) multiplies fp64-class limbs by N^-1 instead of N^-1 R^-1.  Used by the fused
+ * cc_mult, whose tensor product then needs one plain modular product per term (lf_tensor, plain = 1). */
+#define LF_NTT_PLAIN 2
 
 /* plain twiddles as doubles from the Montgomery-form compact table: out = reduce_q(redc(mont)). */
 int lf_twiddle_dp(const int64_t *mont, double *out, int rows, int64_t N, const int64_t *ql, const int64_t *qh,
@@ -120,9 +124,11 @@ int lf_rescale(const int64_t *in, const int64_t *row0, int64_t *out, int rows, i
                int64_t round_at, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
                int device, void *stream);
 
-/* cc_mult's tensor product (ckks_engine.py:1095-1101): d0 = x0*y0, d1 = x0*y1 (+) x1*y0, d2 = x1*y1 (REDC, lazy). */
+/* cc_mult's tensor product (ckks_engine.py:1095-1101): d0 = x0*y0, d1 = x0*y1 (+) x1*y0, d2 = x1*y1 (REDC, lazy).
+ * plain = 1 (operands from lf_ntt with LF_NTT_RELAXED|LF_NTT_PLAIN): limbs with a prime below 2^41 hold plain
+ * canonical residues and get plain fp64 products (canonical outputs); other limbs as above. */
 int lf_tensor(const int64_t *x0, const int64_t *x1, const int64_t *y0, const int64_t *y1, int64_t *d0, int64_t *d1,
-              int64_t *d2, int rows, int64_t N, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+              int64_t *d2, int rows, int64_t N, int plain, const int64_t *ql, const int64_t *qh, const int64_t *kl,
               const int64_t *kh, int device, void *stream);
 
 /* pre_extend (ckks_engine.py:654-705) for all local key-switch digits at once: mixed-radix (Garner) digits.

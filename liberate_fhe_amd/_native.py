@@ -40,7 +40,7 @@ _SIGNATURES = {
     "lf_intt": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     "lf_galois": [_P, _P, _I, _I, _L, _P, _I, _P],
     "lf_rescale": [_P, _P, _P, _I, _L, _P, _L, _P, _P, _P, _P, _I, _P],
-    "lf_tensor": [_P, _P, _P, _P, _P, _P, _P, _I, _L, _P, _P, _P, _P, _I, _P],
+    "lf_tensor": [_P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, _I, _P],
     "lf_ks_digits": [_P, _P, _I, _P, _P, _L, _P, _P, _P, _P, _I, _P],
     "lf_ks_extend": [_P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_ks_inner": [_P, _P, _L, _L, _L, _P, _P, _I, _I, _L, _P, _P, _P, _P, _I, _P],
@@ -65,3 +65,4 @@ def check(code: int, what: str):
 
 EXPORTED = tuple(_SIGNATURES)
 LF_NTT_RELAXED = 1
+LF_NTT_PLAIN = 2

@@ -15,6 +15,15 @@
 
 namespace {
 
+// (a * w) mod q in fp64 for q < 2^41, |a| < 2^52, 0 <= w < q (see ckks_ntt_core.h)
+__device__ __forceinline__ double dp_mulmod_q(double a, double w, double q, double qinv) {
+    const double hi = a * w;
+    const double lo = __builtin_fma(a, w, -hi);
+    const double quo = __builtin_rint(hi * qinv);
+    const double r = __builtin_fma(-quo, q, hi) + lo;
+    return r < 0.0 ? r + q : r;
+}
+
 // ---- rescale (ckks_engine.py:1029-1041) ----------------------------------------------------------
 // out = reduce_q( REDC(in - row0, q_l^-1 * R mod q_i) + [row0 > q_l/2] )
 __global__ void __launch_bounds__(256) rescale_kernel(const i64 *__restrict__ in, const i64 *__restrict__ row0,
@@ -40,7 +49,7 @@ __global__ void __launch_bounds__(256) rescale_kernel(const i64 *__restrict__ in
 __global__ void __launch_bounds__(256) tensor_kernel(const i64 *__restrict__ x0, const i64 *__restrict__ x1,
                                                      const i64 *__restrict__ y0, const i64 *__restrict__ y1,
                                                      i64 *__restrict__ d0, i64 *__restrict__ d1, i64 *__restrict__ d2, i64 N,
-                                                     const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                     int plain, const i64 *__restrict__ ql, const i64 *__restrict__ qh,
                                                      const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
     const int r = blockIdx.y;
     const i64 j = ((i64)blockIdx.x * 256 + threadIdx.x) * 2;
@@ -50,6 +59,25 @@ __global__ void __launch_bounds__(256) tensor_kernel(const i64 *__restrict__ x0,
     const longlong2 a0 = *reinterpret_cast<const longlong2 *>(x0 + off), a1 = *reinterpret_cast<const longlong2 *>(x1 + off);
     const longlong2 b0 = *reinterpret_cast<const longlong2 *>(y0 + off), b1 = *reinterpret_cast<const longlong2 *>(y1 + off);
     longlong2 o0, o1, o2;
+    if (plain && m.q < (1ull << 41)) {
+        // plain canonical residues in, plain canonical residues out: one fp64 product per term
+        const double q = (double)m.q, qinv = 1.0 / q;
+        const double A0[2] = {(double)a0.x, (double)a0.y}, A1[2] = {(double)a1.x, (double)a1.y};
+        const double B0[2] = {(double)b0.x, (double)b0.y}, B1[2] = {(double)b1.x, (double)b1.y};
+        i64 r0[2], r1[2], r2[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            r0[e] = (i64)dp_mulmod_q(A0[e], B0[e], q, qinv);
+            double t = dp_mulmod_q(A0[e], B1[e], q, qinv) + dp_mulmod_q(A1[e], B0[e], q, qinv);
+            r1[e] = (i64)(t >= q ? t - q : t);
+            r2[e] = (i64)dp_mulmod_q(A1[e], B1[e], q, qinv);
+        }
+        o0.x = r0[0]; o0.y = r0[1]; o1.x = r1[0]; o1.y = r1[1]; o2.x = r2[0]; o2.y = r2[1];
+        *reinterpret_cast<longlong2 *>(d0 + off) = o0;
+        *reinterpret_cast<longlong2 *>(d1 + off) = o1;
+        *reinterpret_cast<longlong2 *>(d2 + off) = o2;
+        return;
+    }
     o0.x = mm62s(a0.x, b0.x, m.q, m.k);
     o0.y = mm62s(a0.y, b0.y, m.q, m.k);
     o1.x = csub(mm62s(a0.x, b1.x, m.q, m.k) + mm62s(a1.x, b0.x, m.q, m.k), m.q2);
@@ -163,15 +191,6 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(const i64 *__restrict__ e
 // eliminated last-first; PiR[P_ind][row] = P_j^-1 * R mod q_row.  Optional `addend` (relinearize's
 // d0/d1 or the rotated c0): out = reduce_q(result + addend)  (ckks_engine.py:1135-1140, 952-953).
 #define MD_ROWS 8
-// (a * w) mod q in fp64 for q < 2^41, |a| < 2^52, 0 <= w < q (see ckks_ntt_core.h)
-__device__ __forceinline__ double dp_mulmod_q(double a, double w, double q, double qinv) {
-    const double hi = a * w;
-    const double lo = __builtin_fma(a, w, -hi);
-    const double quo = __builtin_rint(hi * qinv);
-    const double r = __builtin_fma(-quo, q, hi) + lo;
-    return r < 0.0 ? r + q : r;
-}
-
 __global__ void __launch_bounds__(256) ks_moddown_kernel(const i64 *__restrict__ s, i64 *__restrict__ out,
                                                          const i64 *__restrict__ addend, int ell, int K, i64 N,
                                                          const i64 *__restrict__ PiR, const double *__restrict__ PiP,
@@ -269,14 +288,14 @@ int lf_rescale(const int64_t *in, const int64_t *row0, int64_t *out, int rows, i
 }
 
 int lf_tensor(const int64_t *x0, const int64_t *x1, const int64_t *y0, const int64_t *y1, int64_t *d0, int64_t *d1,
-              int64_t *d2, int rows, int64_t N, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
+              int64_t *d2, int rows, int64_t N, int plain, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
               int device, void *stream) {
     if (rows < 0 || N < 2 || (N & 1)) return LF_ERR_ARG;
     if (rows == 0) return 0;
     if (int e = lf_set_device(device)) return e;
     dim3 grid((unsigned)((N / 2 + 255) / 256), (unsigned)rows);
     hipLaunchKernelGGL(tensor_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const i64 *)x0, (const i64 *)x1, (const i64 *)y0,
-                       (const i64 *)y1, (i64 *)d0, (i64 *)d1, (i64 *)d2, (i64)N, (const i64 *)ql, (const i64 *)qh,
+                       (const i64 *)y1, (i64 *)d0, (i64 *)d1, (i64 *)d2, (i64)N, plain, (const i64 *)ql, (const i64 *)qh,
                        (const i64 *)kl, (const i64 *)kh);
     return (int)hipGetLastError();
 }

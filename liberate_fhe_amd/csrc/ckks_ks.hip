@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ks_ext_pass1(const i6
     const int pt = b / rl.n;
     const int tile = pt % tiles, p = pt / tiles;
     const int crow = rl.id[ri];
-    const PassGeom g{kg.logN, kg.tl, 1, kg.S1, 0, kg.tl - kg.S1, kg.rows, kg.nparts, 1, 0, 1, 0};
+    const PassGeom g{kg.logN, kg.tl, 1, kg.S1, 0, kg.tl - kg.S1, kg.rows, kg.nparts, 1, 0, 0, 1, 0};
 
     Ctx c;
     c.m = load_mod(ql, qh, kl, kh, crow);
@@ -225,7 +225,7 @@ int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64
                            (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     // contiguous forward pass, in place on tmp (relaxed)
     {
-        const PassGeom g{logN, tl, 0, tl, S1, 0, rows, nparts, 1, 1, 1, 0};
+        const PassGeom g{logN, tl, 0, tl, S1, 0, rows, nparts, 1, 1, 0, 1, 0};
         const unsigned per_row = (unsigned)nparts << (logN - tl);
         if (dp.n)
             hipLaunchKernelGGL(ntt_fwd_pass<true>, dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, (i64 *)tmp, g, dp,
@@ -247,8 +247,8 @@ int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64
     // K4: inverse transform -> canonical coefficients (relaxed, tail 2), in place on s
     const unsigned per_row2 = 2u << (logN - tl);
     for (int pass = 0; pass < 2; ++pass) {
-        PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, 2, 1, 0, 1, 0}
-                               : PassGeom{logN, tl, 1, S1, tl, tl - S1, rows, 2, 1, 1, 1, 0};
+        PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, 2, 1, 0, 0, 1, 0}
+                               : PassGeom{logN, tl, 1, S1, tl, tl - S1, rows, 2, 1, 1, 0, 1, 0};
         if (dp.n)
             hipLaunchKernelGGL(ntt_inv_pass_io<true>, dim3(per_row2 * dp.n), dim3(NTT_THREADS), 0, st, (const i64 *)s, (i64 *)s,
                                g, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, pass == 1 ? 2 : TAIL_NONE,

@@ -111,6 +111,7 @@ int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, con
     const int tl = logN < NTT_TILE_LOG_MAX ? logN : NTT_TILE_LOG_MAX;
     const int S1 = logN - tl;
     const int relaxed = flags & LF_NTT_RELAXED;
+    const int plain = (relaxed && (flags & LF_NTT_PLAIN)) ? 1 : 0;
     RowList dp, in;
     classify(rows, q_host, psi_dp, dp, in);
     hipStream_t st = (hipStream_t)stream;
@@ -126,8 +127,8 @@ int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, con
         i64 *base = (i64 *)a + ((i64)b0 * rows << logN);
         const unsigned per_row = (unsigned)nb << (logN - tl);
         for (int pass = (S1 > 0 ? 0 : 1); pass < 2; ++pass) {
-            const PassGeom g = pass == 0 ? PassGeom{logN, tl, 1, S1, 0, tl - S1, rows, nb, relaxed, 0, 1, 0}
-                                         : PassGeom{logN, tl, 0, tl, S1, 0, rows, nb, relaxed, 1, 1, 0};
+            const PassGeom g = pass == 0 ? PassGeom{logN, tl, 1, S1, 0, tl - S1, rows, nb, relaxed, 0, plain, 1, 0}
+                                         : PassGeom{logN, tl, 0, tl, S1, 0, rows, nb, relaxed, 1, plain, 1, 0};
             const i64 *rs = (pass == 0 || S1 == 0) ? (const i64 *)Rs : nullptr;
             if (dp.n)
                 hipLaunchKernelGGL(ntt_fwd_pass<true>, dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, base, g, dp,
@@ -158,6 +159,7 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
     const int tl = logN < NTT_TILE_LOG_MAX ? logN : NTT_TILE_LOG_MAX;
     const int SB = logN - tl;
     const int relaxed = flags & LF_NTT_RELAXED;
+    const int plain = (relaxed && (flags & LF_NTT_PLAIN)) ? 1 : 0;
     RowList dp, in;
     classify(rows, q_host, ipsi_dp, dp, in);
     hipStream_t st = (hipStream_t)stream;
@@ -173,8 +175,8 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
         i64 *base = (i64 *)a + ((i64)b0 * rows << logN);
         const unsigned per_row = (unsigned)nb << (logN - tl);
         for (int pass = 0; pass < (SB > 0 ? 2 : 1); ++pass) {
-            const PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, nb, relaxed, SB == 0, 1, 0}
-                                         : PassGeom{logN, tl, 1, SB, tl, tl - SB, rows, nb, relaxed, 1, 1, 0};
+            const PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, nb, relaxed, SB == 0, plain, 1, 0}
+                                         : PassGeom{logN, tl, 1, SB, tl, tl - SB, rows, nb, relaxed, 1, plain, 1, 0};
             const int t = g.last ? tail : TAIL_NONE;
             if (dp.n)
                 hipLaunchKernelGGL(ntt_inv_pass_io<true>, dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, (const i64 *)base, base, g, dp,

@@ -51,6 +51,8 @@ struct PassGeom {
     int batch;     // polynomials
     int relaxed;   // 1: result only needed modulo q
     int last;      // 1: last pass of the transform
+    int plain;     // relaxed only: fp64-class limbs work in the PLAIN domain — no Montgomery entry on the way in
+                   // (Rs applies to integer-class limbs only), inverse tail multiplies by N^-1 instead of N^-1 R^-1
     int nsum;      // relaxed only: the input tile is the sum of `nsum` stacks (<= 1: plain load)
     i64 sum_stride;  // words between those stacks
 };
@@ -458,7 +460,7 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_fwd_pass(i64 *__r
                                                             const i64 *__restrict__ kh) {
     __shared__ i64 sm[NTT_LDS_WORDS + 1];
     const int T = 1 << g.tl;
-    const bool enter = (Rs != nullptr);
+    const bool enter = (Rs != nullptr) && !(DP && g.plain);
     // persistent block: a contiguous run of work items; the next tile's global loads are in flight
     // while the current tile is transformed out of LDS
     if (threadIdx.x == 0) sm[NTT_FLAG_WORD] = 0;   // both block_or flag words
@@ -582,7 +584,7 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_inv_pass_io(const
             // chain tail: z = REDC(t * Ninv); [redc]; [reduce]; [signed]    (K.cu:527-529, 754-902)
             const double ninv_plain = c.d.q - (double)((c.m.q - 1) >> g.logN);                  // N^-1 mod q
             const double rinv = (double)(u64)((((u128)c.m.k * (u128)c.m.q) + 1) >> 62);         // R^-1 mod q
-            const double c2 = dp_mulmod(ninv_plain, rinv, c.d);                                 // N^-1 R^-1 mod q
+            const double c2 = g.plain ? ninv_plain : dp_mulmod(ninv_plain, rinv, c.d);          // N^-1 (R^-1) mod q
             const i64 ninv_mont = (tail != TAIL_NONE) ? Ninv[cur_row] : 0;
             for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2) {
                 i64 o[2];

@@ -47,18 +47,19 @@ class HipBackend:
     ops = ntt_cuda  # the 15 reference-shaped primitives
 
     # ---- NTT family over [batch][rows][N] stacks ------------------------------------------------
-    def ntt(self, buf, batch, rows, logN, psi, Rs, c: Consts, relaxed=False):
-        """relaxed: the caller only needs residues mod q (internal transforms whose consumers reduce)."""
+    def ntt(self, buf, batch, rows, logN, psi, Rs, c: Consts, relaxed=False, plain=False):
+        """relaxed: the caller only needs residues mod q (internal transforms whose consumers reduce).
+        plain (with relaxed): fp64-class limbs stay in the plain domain (see LF_NTT_PLAIN)."""
         dev, st = _ds(buf)
         dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
-        check(lib.lf_ntt(_p(buf), batch, rows, logN, _p(psi), dp, c.qptr(), _p(Rs), 1 if relaxed else 0, _p(c._2q),
+        check(lib.lf_ntt(_p(buf), batch, rows, logN, _p(psi), dp, c.qptr(), _p(Rs), (1 if relaxed else 0) | (2 if relaxed and plain else 0), _p(c._2q),
                          *c.mont(), dev, st), "lf_ntt")
 
-    def intt(self, buf, batch, rows, logN, ipsi, Ninv, tail, c: Consts, relaxed=False):
+    def intt(self, buf, batch, rows, logN, ipsi, Ninv, tail, c: Consts, relaxed=False, plain=False):
         dev, st = _ds(buf)
         dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
         check(lib.lf_intt(_p(buf), batch, rows, logN, _p(ipsi), dp, c.qptr(), _p(Ninv), tail,
-                          1 if relaxed and tail >= 2 else 0, _p(c._2q), *c.mont(), dev, st), "lf_intt")
+                          (3 if plain else 1) if relaxed and tail >= 2 else 0, _p(c._2q), *c.mont(), dev, st), "lf_intt")
 
     def galois(self, a, dst, rows, logN, p, _2q):
         dev, st = _ds(a)
@@ -70,9 +71,10 @@ class HipBackend:
         check(lib.lf_rescale(_p(src), _p(row0), _p(out), rows, out.size(-1), _p(scales), round_at, *c.mont(), dev, st),
               "lf_rescale")
 
-    def tensor(self, x0, x1, y0, y1, d0, d1, d2, rows, c: Consts):
+    def tensor(self, x0, x1, y0, y1, d0, d1, d2, rows, c: Consts, plain=False):
         dev, st = _ds(d0)
-        check(lib.lf_tensor(_p(x0), _p(x1), _p(y0), _p(y1), _p(d0), _p(d1), _p(d2), rows, d0.size(-1), *c.mont(), dev, st),
+        check(lib.lf_tensor(_p(x0), _p(x1), _p(y0), _p(y1), _p(d0), _p(d1), _p(d2), rows, d0.size(-1), 1 if plain else 0,
+                            *c.mont(), dev, st),
               "lf_tensor")
 
     def ks_digits(self, a, state, nparts, desc, tab, c: Consts):

@@ -630,18 +630,25 @@ class ckks_engine:
             rows = self._rows(d, level, False)
             c = self._consts(d, level, False)
             x = stacks[d]
-            self.backend.ntt(x, 4, rows, logN, self._tw(d, level, False), self._vec("Rs", d, level, False), c)
+            # with relinearisation the triplet never leaves this method: only residues matter, so the 40-bit
+            # limbs take the relaxed plain-domain transforms (one fp64 product per tensor term)
+            self.backend.ntt(x, 4, rows, logN, self._tw(d, level, False), self._vec("Rs", d, level, False), c,
+                             relaxed=relin, plain=relin)
             out = torch.empty((3, rows, N), dtype=torch.int64, device=self.ntt.devices[d])
-            self.backend.tensor(x[0], x[1], x[2], x[3], out[0], out[1], out[2], rows, c)
+            self.backend.tensor(x[0], x[1], x[2], x[3], out[0], out[1], out[2], rows, c, plain=relin)
             d0.append(out[0]); d1.append(out[1]); d2.append(out[2])
         ct_mult = self._new((d0, d1, d2), types.origins["ctt"], level=level, ntt_state=True, montgomery_state=True)
-        return self.relinearize(ct_triplet=ct_mult, evk=evk) if relin else ct_mult
+        return self._relinearize(ct_mult, evk, plain=True) if relin else ct_mult
 
     def relinearize(self, ct_triplet: data_struct, evk: data_struct) -> data_struct:
         if ct_triplet.origin != types.origins["ctt"]:
             raise errors.NotMatchType(origin=ct_triplet.origin, to=types.origins["ctt"])
         if not ct_triplet.ntt_state or not ct_triplet.montgomery_state:
             raise errors.NotMatchDataStructState(origin=ct_triplet.origin)
+        return self._relinearize(ct_triplet, evk, plain=False)
+
+    def _relinearize(self, ct_triplet, evk, plain):
+        """plain: the triplet comes from cc_mult's internal plain-domain product (40-bit limbs un-Montgomeried)."""
         d0, d1, d2 = ct_triplet.data
         level = ct_triplet.level
         # the three inverse transforms mutate the triplet in place, as the reference does (eng.py:1127-1129)
@@ -650,10 +657,10 @@ class ckks_engine:
             tw, ninv = self._tw(d, level, False, True), self._vec("Ninv", d, level, False)
             stacked = self._as_stack([d0[i], d1[i], d2[i]])
             if stacked is not None:
-                self.backend.intt(stacked, 3, rows, self.ctx.logN, tw, ninv, 2, c)
+                self.backend.intt(stacked, 3, rows, self.ctx.logN, tw, ninv, 2, c, relaxed=plain, plain=plain)
             else:
                 for t in (d0[i], d1[i], d2[i]):
-                    self.backend.intt(t, 1, rows, self.ctx.logN, tw, ninv, 2, c)
+                    self.backend.intt(t, 1, rows, self.ctx.logN, tw, ninv, 2, c, relaxed=plain, plain=plain)
         c0, c1 = self.create_switcher(d2, evk, level, addends=(d0, d1))
         return self._new((c0, c1), types.origins["ct"], level=level)
 

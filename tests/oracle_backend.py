@@ -155,7 +155,7 @@ class OracleBackend:
         return _np(c.ql), _np(c.qh), _np(c.kl), _np(c.kh)
 
     # ---- NTT family ----
-    def ntt(self, buf, batch, rows, logN, psi, Rs, c, relaxed=False):
+    def ntt(self, buf, batch, rows, logN, psi, Rs, c, relaxed=False, plain=False):
         v = _np(buf).reshape(batch, -1, buf.size(-1))
         for b in range(batch):
             x = v[b][:rows]
@@ -163,7 +163,7 @@ class OracleBackend:
                 orc.mont_enter(x, _np(Rs), rows, *self._m(c))
             orc.ntt(x, _np(psi), rows, logN, _np(c._2q), *self._m(c))
 
-    def intt(self, buf, batch, rows, logN, ipsi, Ninv, tail, c, relaxed=False):
+    def intt(self, buf, batch, rows, logN, ipsi, Ninv, tail, c, relaxed=False, plain=False):
         v = _np(buf).reshape(batch, -1, buf.size(-1))
         for b in range(batch):
             x = v[b][:rows]
@@ -192,7 +192,7 @@ class OracleBackend:
         _np(out)[:rows] = data
 
     # ---- tensor product: ckks_engine.py:1095-1101 ----
-    def tensor(self, x0, x1, y0, y1, d0, d1, d2, rows, c):
+    def tensor(self, x0, x1, y0, y1, d0, d1, d2, rows, c, plain=False):
         a0, a1, b0, b1 = (np.ascontiguousarray(_np(t)[:rows]) for t in (x0, x1, y0, y1))
         t0, t1 = np.empty_like(a0), np.empty_like(a0)
         orc.mont_mult(a0, b0, t0, rows, *self._m(c)); _np(d0)[:rows] = t0
