@@ -100,6 +100,51 @@ def engine_rates(dev, quick):
     return out
 
 
+def multi_gpu_rates(dev, world, rank, sharded):
+    """N > 1: gold cc_mult(+relinearize) (a) limb-sharded over all ranks — one ciphertext at a time, rescale row by
+    RCCL broadcast, key-switch digits by RCCL all-gather — and (b) as independent replicas (one full engine per
+    GPU, zero communication; the whole-job rate is the sum).  Returns a dict for `extra`; never raises."""
+    import torch.distributed as dist
+    out = {}
+    try:
+        from liberate_fhe_amd.fhe import ckks_engine, presets
+        from liberate_fhe_amd.fhe.comm import DistComm
+        from liberate_fhe_amd.utils import synth
+        params = {k: v for k, v in presets.params["gold"].items() if k != "devices"}
+        # (b) replicas
+        eng = ckks_engine(devices=[dev], **params)
+        a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
+        evk = synth.key_switch_key(eng, 5)
+        for _ in range(2):
+            eng.cc_mult(a, b, evk)
+        torch.cuda.synchronize()
+        dist.barrier()
+        ms = event_time_ms(lambda: eng.cc_mult(a, b, evk), 10)
+        t = torch.tensor([ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out["cc_mult_evk_gold_replicas_ops_per_s"] = world * 1e3 / float(t.item())
+        del eng, a, b, evk
+        torch.cuda.empty_cache()
+        if not sharded:
+            return out
+        # (a) limb-sharded (opt-in: a failure on one rank inside the engine's collectives would hang the others,
+        # and this box cannot rehearse a multi-GPU run — see DESIGN.md §7)
+        eng = ckks_engine(devices=[dev], comm=DistComm(local_device=dev), **params)
+        a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
+        evk = synth.key_switch_key(eng, 5)
+        for _ in range(2):
+            eng.cc_mult(a, b, evk)
+        torch.cuda.synchronize()
+        dist.barrier()
+        ms = event_time_ms(lambda: eng.cc_mult(a, b, evk), 10)
+        t = torch.tensor([ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out["cc_mult_evk_gold_limb_sharded_ops_per_s"] = 1e3 / float(t.item())
+    except Exception as e:   # the headline line must survive a failure of this optional leg
+        out["multi_gpu_cc_mult_error"] = f"{type(e).__name__}: {e}"[:300]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +152,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16, help="polynomials per step per GPU")
     ap.add_argument("--no-extra", action="store_true", help="skip the cc_mult / rotate / CPU legs")
+    ap.add_argument("--sharded", action="store_true",
+                    help="N > 1: also time the limb-sharded gold cc_mult (RCCL broadcast + all-gather)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -224,6 +271,9 @@ def main():
         result["cpu_baseline"] = cpu_baseline(ctx, rows_idx, batch=B)
     else:
         result["cpu_baseline"] = None   # reported by the N=1 run only
+    if world > 1 and not args.no_extra:
+        more = multi_gpu_rates(dev, world, rank, args.sharded)
+        extra.update(more)
     result["extra"] = extra
     if world > 1:
         dist.barrier()
