@@ -145,45 +145,73 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
                                                         int nparts, int rows, i64 N, const i64 *__restrict__ ql,
                                                         const i64 *__restrict__ qh, const i64 *__restrict__ kl,
                                                         const i64 *__restrict__ kh) {
+    // each thread owns KI_V 16-byte column pairs 4 KiB apart: every block streams KI_V x 4 KiB contiguous runs
+    // from 3 x nparts arrays, enough bytes in flight to keep HBM busy
+    constexpr int KI_V = 2;
     const int r = blockIdx.y;
-    const i64 j = ((i64)blockIdx.x * 256 + threadIdx.x) * 2;
-    if (j >= N) return;
+    const i64 j0 = (i64)blockIdx.x * (512 * KI_V) + threadIdx.x * 2;
+    if (j0 >= N) return;
     const RowMod m = load_mod(ql, qh, kl, kh, r);
     const RowDp d = make_dp(m);
-    const i64 *e = ext + (i64)r * N + j;
-    const i64 *k = ksk + (row_off + r) * N + j;
-    longlong2 o0, o1;
+    const i64 *e = ext + (i64)r * N + j0;
+    const i64 *k = ksk + (row_off + r) * N + j0;
     if (m.q < SMALL_PRIME_LIMIT) {
-        double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+        double acc[2][KI_V][2];
+#pragma unroll
+        for (int v = 0; v < KI_V; ++v) acc[0][v][0] = acc[0][v][1] = acc[1][v][0] = acc[1][v][1] = 0.0;
+#pragma unroll 2
         for (int p = 0; p < nparts; ++p) {
-            const longlong2 x = *reinterpret_cast<const longlong2 *>(e + (i64)p * rows * N);
-            const longlong2 k0 = *reinterpret_cast<const longlong2 *>(k + (i64)p * part_stride);
-            const longlong2 k1 = *reinterpret_cast<const longlong2 *>(k + (i64)p * part_stride + comp_stride);
-            const double x0 = dp_from_word(x.x), x1 = dp_from_word(x.y);
-            a00 += dp_mulmod(x0, dp_from_word(k0.x), d);
-            a01 += dp_mulmod(x1, dp_from_word(k0.y), d);
-            a10 += dp_mulmod(x0, dp_from_word(k1.x), d);
-            a11 += dp_mulmod(x1, dp_from_word(k1.y), d);
+            longlong2 x[KI_V], k0[KI_V], k1[KI_V];
+#pragma unroll
+            for (int v = 0; v < KI_V; ++v) {
+                x[v] = *reinterpret_cast<const longlong2 *>(e + (i64)p * rows * N + v * 512);
+                k0[v] = *reinterpret_cast<const longlong2 *>(k + (i64)p * part_stride + v * 512);
+                k1[v] = *reinterpret_cast<const longlong2 *>(k + (i64)p * part_stride + comp_stride + v * 512);
+            }
+#pragma unroll
+            for (int v = 0; v < KI_V; ++v) {
+                const double x0 = dp_from_word(x[v].x), x1 = dp_from_word(x[v].y);
+                acc[0][v][0] += dp_mulmod_bal(x0, dp_from_word(k0[v].x), d);
+                acc[0][v][1] += dp_mulmod_bal(x1, dp_from_word(k0[v].y), d);
+                acc[1][v][0] += dp_mulmod_bal(x0, dp_from_word(k1[v].x), d);
+                acc[1][v][1] += dp_mulmod_bal(x1, dp_from_word(k1[v].y), d);
+            }
         }
-        o0.x = dp_to_word(dp_reduce(a00, d.q, d.qinv));
-        o0.y = dp_to_word(dp_reduce(a01, d.q, d.qinv));
-        o1.x = dp_to_word(dp_reduce(a10, d.q, d.qinv));
-        o1.y = dp_to_word(dp_reduce(a11, d.q, d.qinv));
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int v = 0; v < KI_V; ++v) {
+                longlong2 o;
+                o.x = dp_to_word(dp_reduce(acc[c][v][0], d.q, d.qinv));
+                o.y = dp_to_word(dp_reduce(acc[c][v][1], d.q, d.qinv));
+                *reinterpret_cast<longlong2 *>(s + ((i64)c * rows + r) * N + j0 + v * 512) = o;
+            }
     } else {
-        i64 a00 = 0, a01 = 0, a10 = 0, a11 = 0;
+        i64 acc[2][KI_V][2];
+#pragma unroll
+        for (int v = 0; v < KI_V; ++v) acc[0][v][0] = acc[0][v][1] = acc[1][v][0] = acc[1][v][1] = 0;
         for (int p = 0; p < nparts; ++p) {
-            const longlong2 x = *reinterpret_cast<const longlong2 *>(e + (i64)p * rows * N);
-            const longlong2 k0 = *reinterpret_cast<const longlong2 *>(k + (i64)p * part_stride);
-            const longlong2 k1 = *reinterpret_cast<const longlong2 *>(k + (i64)p * part_stride + comp_stride);
-            a00 = csub(a00 + mm62u((u64)x.x, (u64)k0.x, m.q, m.k), m.q2);
-            a01 = csub(a01 + mm62u((u64)x.y, (u64)k0.y, m.q, m.k), m.q2);
-            a10 = csub(a10 + mm62u((u64)x.x, (u64)k1.x, m.q, m.k), m.q2);
-            a11 = csub(a11 + mm62u((u64)x.y, (u64)k1.y, m.q, m.k), m.q2);
+#pragma unroll
+            for (int v = 0; v < KI_V; ++v) {
+                const longlong2 x = *reinterpret_cast<const longlong2 *>(e + (i64)p * rows * N + v * 512);
+                const longlong2 k0 = *reinterpret_cast<const longlong2 *>(k + (i64)p * part_stride + v * 512);
+                const longlong2 k1 = *reinterpret_cast<const longlong2 *>(k + (i64)p * part_stride + comp_stride + v * 512);
+                acc[0][v][0] = csub(acc[0][v][0] + mm62u((u64)x.x, (u64)k0.x, m.q, m.k), m.q2);
+                acc[0][v][1] = csub(acc[0][v][1] + mm62u((u64)x.y, (u64)k0.y, m.q, m.k), m.q2);
+                acc[1][v][0] = csub(acc[1][v][0] + mm62u((u64)x.x, (u64)k1.x, m.q, m.k), m.q2);
+                acc[1][v][1] = csub(acc[1][v][1] + mm62u((u64)x.y, (u64)k1.y, m.q, m.k), m.q2);
+            }
         }
-        o0.x = a00; o0.y = a01; o1.x = a10; o1.y = a11;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int v = 0; v < KI_V; ++v) {
+                longlong2 o;
+                o.x = acc[c][v][0];
+                o.y = acc[c][v][1];
+                *reinterpret_cast<longlong2 *>(s + ((i64)c * rows + r) * N + j0 + v * 512) = o;
+            }
     }
-    *reinterpret_cast<longlong2 *>(s + (i64)r * N + j) = o0;
-    *reinterpret_cast<longlong2 *>(s + ((i64)rows + r) * N + j) = o1;
 }
 
 void classify_rows(int rows, const int64_t *q_host, RowList &dp, RowList &in) {
@@ -239,7 +267,7 @@ int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64
     // K3: inner product with the key, summed over the digits
     {
         const i64 N = (i64)1 << logN;
-        dim3 grid((unsigned)((N / 2 + 255) / 256), (unsigned)rows);
+        dim3 grid((unsigned)((N + 1023) / 1024), (unsigned)rows);
         hipLaunchKernelGGL(ks_inner2_kernel, grid, dim3(256), 0, st, (const i64 *)tmp, (const i64 *)ksk, (i64)part_stride,
                            (i64)comp_stride, (i64)row_off, (i64 *)s, nparts, rows, N, (const i64 *)ql, (const i64 *)qh,
                            (const i64 *)kl, (const i64 *)kh);
