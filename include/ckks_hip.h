@@ -34,7 +34,7 @@ extern "C" {
 
 #define LF_ERR_ARG 10001
 
-/* Library probe: returns the ABI version (currently 2). */
+/* Library probe: returns the ABI version (currently 3). */
 int lf_abi_version(void);
 
 /* ---- elementwise family --------------------------------------------------------------------- */
@@ -172,6 +172,43 @@ int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64
                int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
                const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
                const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Samplers: the reference's csprng extensions, src/liberate/csprng/.
+ * A ChaCha20 state is 16 int64 words holding 32-bit values (csprng.py:124-160); words 12/13 are
+ * the 64-bit block counter, advanced by `step` after every draw.  All tables below are DEVICE
+ * pointers except q_host / btree_host, which the reference also takes as host pointers.
+ * Row counts need not be multiples of the block size (the reference silently drops the tail).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* chacha20_cuda.chacha20 (chacha20.cpp:17-40, chacha20_cuda_kernel.cu:10-46): dest[i] = block(states[i])
+ * for n states [n][16]; states' counters advance. */
+int lf_chacha20(int64_t *states, int64_t *dest, int64_t n, uint64_t step, int device, void *stream);
+
+/* randint_cuda.randint_fast (randint.cpp:38-52, randint_cuda_kernel.cu:22-101): fused ChaCha20 +
+ * floor(q_c * X / 2^128) + shift, four samples per state; states [channels][L][16] -> dst [channels][4L]. */
+int lf_randint_fast(int64_t *states, int64_t *dst, int channels, int64_t L, const uint64_t *q_host, int64_t shift,
+                    uint64_t step, int device, void *stream);
+
+/* randint_cuda.randint (randint.cpp:21-33, randint_cuda_kernel.cu:108-152): the same map in place on
+ * random words rand_bytes [channels][n][16]; word 4j of each row receives the sample of words 4j..4j+3. */
+int lf_randint(int64_t *rand_bytes, int channels, int64_t n, const uint64_t *q_host, int device, void *stream);
+
+/* discrete_gaussian_cuda.discrete_gaussian_fast (discrete_gaussian_cuda_kernel.cu:28-109, 186-215): fused
+ * ChaCha20 + CDT binary-tree walk, four samples per state; states [n][16] -> dst [4n].
+ * btree_host: btree_size low words in level order, then btree_size high words
+ * (discrete_gaussian_sampler.py:96-118); 2*btree_size <= 128. */
+int lf_discrete_gaussian_fast(int64_t *states, int64_t *dst, int64_t n, const uint64_t *btree_host, int btree_size,
+                              int depth, uint64_t step, int device, void *stream);
+
+/* discrete_gaussian_cuda.discrete_gaussian (discrete_gaussian_cuda_kernel.cu:118-168, 222-240): in place on
+ * rand_bytes [n][16]. */
+int lf_discrete_gaussian(int64_t *rand_bytes, int64_t n, const uint64_t *btree_host, int btree_size, int depth,
+                         int device, void *stream);
+
+/* randround_cuda.randround (randround_cuda_kernel.cu:8-56): rand_bytes[i] = sign(c) * (floor|c| +
+ * [rand_bytes[i] < rn(frac|c| * 2^32)]), c = coef[i]; rand_bytes holds 32-bit random words. */
+int lf_randround(const double *coef, int64_t *rand_bytes, int64_t n, int device, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,7 @@
 """ctypes binding of libckks_hip.so (C ABI declared in include/ckks_hip.h).
 
 There is NO fallback: if the HIP library has not been built (python -c "import __graft_entry__ as g;
-g.build()" or `make -C liberate_fhe_amd/csrc`), importing this module raises.
+g.build()"), importing this module raises.
 """
 from __future__ import annotations
 
@@ -23,6 +23,7 @@ lib = ctypes.CDLL(LIB_PATH)
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 _L = ctypes.c_int64
+_U = ctypes.c_uint64
 
 _SIGNATURES = {
     "lf_abi_version": [],
@@ -45,6 +46,12 @@ _SIGNATURES = {
     "lf_ks_extend": [_P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_ks_inner": [_P, _P, _L, _L, _L, _P, _P, _I, _I, _L, _P, _P, _P, _P, _I, _P],
     "lf_ks_moddown": [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lf_chacha20": [_P, _P, _L, _U, _I, _P],
+    "lf_randint_fast": [_P, _P, _I, _L, _P, _L, _U, _I, _P],
+    "lf_randint": [_P, _I, _L, _P, _I, _P],
+    "lf_discrete_gaussian_fast": [_P, _P, _L, _P, _I, _I, _U, _I, _P],
+    "lf_discrete_gaussian": [_P, _L, _P, _I, _I, _I, _P],
+    "lf_randround": [_P, _P, _L, _I, _P],
     "lf_ks_core": [_P, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
 }
 

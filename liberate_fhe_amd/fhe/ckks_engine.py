@@ -21,6 +21,7 @@ Data lists (`data_struct.data[i]`) hold one tensor per LOCAL participating devic
 from __future__ import annotations
 
 import math
+import os
 from hashlib import sha256
 
 import numpy as np
@@ -60,11 +61,14 @@ class ckks_engine:
         self.num_levels = self.ntt.num_levels - 1
         self.num_slots = self.ctx.N // 2
 
-        shared_seed = None
+        # Every rank runs the same ChaCha20 key / nonce; the counters make the streams distinct (csprng.py:216-223).
+        seed_words = None
         if comm is not None and comm.world_size > 1:
-            shared_seed = comm.broadcast_int(int.from_bytes(np.random.bytes(7), "little"), src=0)
-        self.rng = Csprng(self.ctx.N, [len(di) for di in self.ntt.p.d], max(self.ntt.num_special_primes, 2),
-                          devices=self.ntt.devices, shared_seed=shared_seed, local_ids=self.local_ids)
+            fresh = torch.tensor([int.from_bytes(os.urandom(4), "big") for _ in range(10)], dtype=torch.int64)
+            seed_words = comm.broadcast(fresh.to(comm.local_device), src=0, shape=(10,), device=comm.local_device).tolist()
+        self.rng = getattr(backend, "csprng_class", Csprng)(self.ctx.N, [len(di) for di in self.ntt.p.d], max(self.ntt.num_special_primes, 2),
+                          devices=self.ntt.devices, local_ids=self.local_ids,
+                          seed=seed_words[:8] if seed_words else None, nonce=seed_words[8:] if seed_words else None)
 
         self.int_scale = 2 ** self.ctx.scale_bits
         self.scale = np.float64(self.int_scale)

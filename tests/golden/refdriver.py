@@ -96,10 +96,12 @@ def load_reference(seed=12345):
         np.bool8 = np.bool_
     sys.path.insert(0, REFERENCE_SRC)
     sys.modules["liberate.ntt.ntt_cuda"] = _make_ntt_cuda_standin()
-    for name in ("chacha20_cuda", "randint_cuda", "randround_cuda", "discrete_gaussian_cuda"):
-        sys.modules["liberate.csprng." + name] = types.ModuleType("liberate.csprng." + name)
+    from tests.oracle_csprng import make_modules
+    for name, mod in make_modules().items():
+        sys.modules["liberate.csprng." + name] = mod        # oracle-backed sampler kernels (CPU)
     import liberate.csprng.csprng as csprng_mod  # noqa: E402
     import liberate.csprng as csprng_pkg  # noqa: E402
+    _state["RefCsprng"] = csprng_mod.Csprng                # the reference's own class, kept for the sampler tests
     csprng_mod.Csprng = SeededCsprng
     csprng_pkg.Csprng = SeededCsprng
     from liberate import fhe  # noqa: E402
@@ -152,3 +154,21 @@ def reference_context(**params):
     load_reference()
     from liberate.fhe.context.ckks_context import ckks_context
     return ckks_context(cache_folder=_state["cache"], read_cache=False, save_cache=False, **params)
+
+
+def reference_csprng(num_coefs, num_channels, num_repeating_channels, n_dev, key, nonce):
+    """The REFERENCE's Csprng class (csprng.py) on CPU with the oracle's sampler kernels underneath and a
+    caller-chosen key / nonce (the reference always draws them from os.urandom, so they are set after
+    construction through its own initialize_states)."""
+    load_reference()
+    r = _state["RefCsprng"](num_coefs, list(num_channels), num_repeating_channels, devices=["cpu"] * n_dev)
+    # The reference hands out the address of a temporary (discrete_gaussian_sampler.py:111-113: `btree_conti`
+    # is local, so `btree_ptr` dangles once the builder returns).  Re-flatten the reference's own table into
+    # an array that stays alive.
+    r._btree_flat = np.ascontiguousarray(r.btree.T.ravel(), dtype=np.uint64)
+    r.btree_ptr = r._btree_flat.__array_interface__["data"][0]
+    r.key = [torch.tensor(key, dtype=torch.int64) for _ in range(n_dev)]
+    r.nonce = [torch.tensor(nonce, dtype=torch.int64) for _ in range(n_dev)]
+    for d in range(n_dev):
+        r.initialize_states(d)
+    return r

@@ -148,7 +148,9 @@ class OracleBackend:
     name = "oracle-cpu"
 
     def __init__(self):
+        from tests.oracle_csprng import oracle_csprng_class
         self.ops = make_ops()
+        self.csprng_class = oracle_csprng_class()     # product host logic over the checker's sampler kernels
 
     @staticmethod
     def _m(c):
