@@ -10,9 +10,15 @@
 // value (csprng.py:124-160); words 12/13 are the 64-bit block counter, stepped by `step` after every
 // draw.  One thread owns one state.  The block function runs on 16 uint32 registers (the reference
 // keeps int64 copies in shared memory and masks after every add/rotate); rotates are single
-// v_alignbit instructions.  Per state a draw moves 128 B in, 16 B (counter) + 32 B (four samples)
-// out against ~1000 integer instructions, so the kernels sit near the HBM roofline at a few TB/s
-// once n >> 256 CUs x 64 lanes.
+// v_alignbit instructions.
+//
+// Roofline (measured, MI355X, 43 limbs x 65536 coefficients = 704,512 states per launch): a draw moves
+// 128 B in, 16 B (counter) + 32 B (four samples) out = 176 B per state, 124 MB per launch, against
+// ~1,150 VALU instructions per state (80 quarter rounds x 12 + sampling).  At 4 cycles per wave64
+// instruction that is ~20 us of issue time per launch, the same order as the ~19 us the bytes need at
+// the 6.4 TB/s streaming floor; the kernels run in 32 us (3.8 TB/s algorithmic), i.e. co-bound with
+// partial overlap.  Staging the states through LDS for fully coalesced loads was measured slower
+// (35 us): the strided per-thread loads are not what limits it.
 //
 // Small per-launch tables (moduli, CDT tree) travel as kernel arguments instead of __constant__
 // symbols, so concurrent streams / devices never race on them.
