@@ -33,11 +33,12 @@ from . import encdec
 from .backend import Consts
 from .context.ckks_context import ckks_context
 from .data_struct import data_struct
+from .evaluator import EvaluatorOps, is_struct
 from .presets import errors, types
 from .version import VERSION
 
 
-class ckks_engine:
+class ckks_engine(EvaluatorOps):
     @errors.log_error
     def __init__(self, devices: list[int] = None, verbose: bool = False, bias_guard: bool = True,
                  norm: str = "forward", backend=None, comm=None, **ctx_params):
@@ -88,9 +89,18 @@ class ckks_engine:
         self._workspace = {}
 
         ds, nd, ls = data_struct, np.ndarray, list
-        self.mult_dispatch_dict = {(ds, ds): self.auto_cc_mult}
-        self.add_dispatch_dict = {(ds, ds): self.auto_cc_add}
-        self.sub_dispatch_dict = {(ds, ds): self.auto_cc_sub}
+        self.mult_dispatch_dict = {
+            (ds, ds): self.auto_cc_mult, (ls, ds): self.mc_mult, (nd, ds): self.mc_mult, (ds, nd): self.cm_mult,
+            (ds, ls): self.cm_mult, (float, ds): self.scalar_mult, (ds, float): self.mult_scalar,
+            (int, ds): self.int_scalar_mult, (ds, int): self.mult_int_scalar}
+        self.add_dispatch_dict = {
+            (ds, ds): self.auto_cc_add, (ls, ds): self.mc_add, (nd, ds): self.mc_add, (ds, nd): self.cm_add,
+            (ds, ls): self.cm_add, (float, ds): self.scalar_add, (ds, float): self.add_scalar,
+            (int, ds): self.scalar_add, (ds, int): self.add_scalar}
+        self.sub_dispatch_dict = {
+            (ds, ds): self.auto_cc_sub, (ls, ds): self.mc_sub, (nd, ds): self.mc_sub, (ds, nd): self.cm_sub,
+            (ds, ls): self.cm_sub, (float, ds): self.scalar_sub, (ds, float): self.sub_scalar,
+            (int, ds): self.scalar_sub, (ds, int): self.sub_scalar}
 
     # =============================================================================================
     # small helpers
@@ -992,34 +1002,20 @@ class ckks_engine:
         a, b = self.auto_level(ct0, ct1)
         return self.cc_sub(a, b)
 
+    def _dispatch(self, table, a, b):
+        try:
+            return table[data_struct if is_struct(a) else type(a), data_struct if is_struct(b) else type(b)]
+        except Exception as e:
+            raise Exception(f"Unsupported data types are input.\n{e}")
+
     def mult(self, a, b, evk=None, relin=True):
-        fn = self.mult_dispatch_dict.get((type(a), type(b)))
-        if fn is None:
-            raise NotImplementedError(f"mult for ({type(a).__name__}, {type(b).__name__}) is outside this build's scope")
-        return fn(a, b, evk, relin=relin)
+        return self._dispatch(self.mult_dispatch_dict, a, b)(a, b, evk, relin)
 
     def add(self, a, b):
-        fn = self.add_dispatch_dict.get((type(a), type(b)))
-        if fn is None:
-            raise NotImplementedError(f"add for ({type(a).__name__}, {type(b).__name__}) is outside this build's scope")
-        return fn(a, b)
+        return self._dispatch(self.add_dispatch_dict, a, b)(a, b)
 
     def sub(self, a, b):
-        fn = self.sub_dispatch_dict.get((type(a), type(b)))
-        if fn is None:
-            raise NotImplementedError(f"sub for ({type(a).__name__}, {type(b).__name__}) is outside this build's scope")
-        return fn(a, b)
+        return self._dispatch(self.sub_dispatch_dict, a, b)(a, b)
 
     def square(self, ct: data_struct, evk: data_struct, relin=True) -> data_struct:
         return self.cc_mult(ct, ct, evk, relin=relin)
-
-    def clone(self, text):
-        def rec(x):
-            if isinstance(x, torch.Tensor):
-                return x.clone()
-            if hasattr(x, "_replace") and hasattr(x, "data"):   # data_struct (this package's or a foreign one)
-                return x._replace(data=rec(x.data))
-            if isinstance(x, (list, tuple)):
-                return type(x)(rec(y) for y in x)
-            return x
-        return rec(text)

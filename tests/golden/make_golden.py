@@ -66,6 +66,74 @@ def run(name, params, n_dev=1):
     return rec
 
 
+def galois_key(eng, seed0):
+    """Synthetic galois key: one synthetic rotation key per power-of-two delta."""
+    parts = [synth.key_switch_key(eng, seed0 + i, origin=f"rotation key:{d}") for i, d in enumerate(eng.galois_deltas)]
+    return type(parts[0])(data=parts, include_special=True, ntt_state=True, montgomery_state=True,
+                          origin="galois key", level=0, hash=eng.hash, version=eng.version)
+
+
+EVALUATOR_OPS = {
+    "negate(a)": lambda e, a, b, evk, gk: e.negate(a),
+    "mult_int_scalar(a,-7)": lambda e, a, b, evk, gk: e.mult_int_scalar(a, -7),
+    "mult(3,a)": lambda e, a, b, evk, gk: e.mult(3, a),
+    "mult_scalar(a,0.37)": lambda e, a, b, evk, gk: e.mult_scalar(a, 0.37),
+    "add_scalar(a,1.25)": lambda e, a, b, evk, gk: e.add_scalar(a, 1.25),
+    "sub(2.5,a)": lambda e, a, b, evk, gk: e.sub(2.5, a),
+    "sum(a,gk)": lambda e, a, b, evk, gk: e.sum(a, gk),
+    "mean(a,gk)": lambda e, a, b, evk, gk: e.mean(a, gk),
+    "pow(a,3,evk)": lambda e, a, b, evk, gk: e.pow(a, 3, evk),
+    "square(a,relin=False)": lambda e, a, b, evk, gk: e.square(a, evk, relin=False),
+    "var(a,evk,gk)": lambda e, a, b, evk, gk: e.var(a, evk, gk),
+    "cov(a,b,evk,gk)": lambda e, a, b, evk, gk: e.cov(a, b, evk, gk),
+    "add(a,level_up(b,2))": lambda e, a, b, evk, gk: e.add(a, e.level_up(b, 2)),
+}
+
+
+def run_evaluator(params, n_dev):
+    """Digests of the evaluator surface around the hot path on synthetic inputs, from the reference engine."""
+    eng = rd.reference_engine(n_dev, **params)
+    rec = {"params": params, "n_devices": n_dev, "seeds": {"ct_a": 21, "ct_b": 22, "evk": 23, "gk": 100}, "ops": {}}
+    a, b = synth.ciphertext(eng, 21, 0), synth.ciphertext(eng, 22, 0)
+    evk, gk = synth.key_switch_key(eng, 23), galois_key(eng, 100)
+    for name, fn in EVALUATOR_OPS.items():
+        rec["ops"][name] = digest(fn(eng, a, b, evk, gk))
+    return rec
+
+
+def write_pickle_fixture(params):
+    """A ciphertext file written by the REFERENCE's save() (host form, eng.py:2001-2015): data, not code."""
+    import pickle
+    eng = rd.reference_engine(1, **params)
+    ct = synth.ciphertext(eng, 31, eng.num_levels - 1)
+    host = type(ct)(data=[eng.download_to_cpu.__func__(eng, _as_cuda(c), ct.level, False) for c in ct.data],
+                    include_special=False, ntt_state=False, montgomery_state=False, origin=ct.origin, level=ct.level,
+                    hash=ct.hash, version=ct.version)
+    with open(os.path.join(HERE, "reference_saved_ct.pkl"), "wb") as f:
+        pickle.dump(host, f)
+    return {"seed": 31, "level": ct.level, "digest": digest(ct), "params": params}
+
+
+class _Dev:
+    type = "cuda"
+
+
+class _CudaLike(torch.Tensor):
+    @property
+    def device(self):
+        return _Dev()
+
+
+def _as_cuda(tensors):
+    """The reference refuses to download non-CUDA tensors; present the CPU stand-ins as CUDA for that check."""
+    out = []
+    for t in tensors:
+        t = t.clone()
+        t.__class__ = _CudaLike
+        out.append(t)
+    return out
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or list(CONFIGS)
     path = os.path.join(HERE, "engine_digests.json")
@@ -74,4 +142,8 @@ if __name__ == "__main__":
         out[name] = run(name, CONFIGS[name])
         if name == "small":
             out["small_x2"] = run(name, CONFIGS[name], 2)
+        if name == "small":
+            out["evaluator_small"] = run_evaluator(CONFIGS[name], 1)
+            out["evaluator_small_x2"] = run_evaluator(CONFIGS[name], 2)
+            out["saved_ct"] = write_pickle_fixture(CONFIGS[name])
         json.dump(out, open(path, "w"), indent=1)

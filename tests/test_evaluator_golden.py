@@ -1,0 +1,177 @@
+"""The evaluator surface around the hot path (scalar / plaintext operands, negation, statistics, data
+movement, save / load, multiparty) against digests and a ciphertext file recorded from the reference
+engine (tests/golden/make_golden.py).  CPU leg: orchestration over the checker backend; GPU leg: the
+product on HIP kernels."""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from liberate_fhe_amd.utils import synth
+from tests.test_engine_golden import digest
+
+warnings.filterwarnings("ignore", category=UserWarning)
+HERE = os.path.dirname(__file__)
+GOLD = json.load(open(os.path.join(HERE, "golden", "engine_digests.json")))
+SAVED = os.path.join(HERE, "golden", "reference_saved_ct.pkl")
+
+
+def galois_key(eng, seed0):
+    parts = [synth.key_switch_key(eng, seed0 + i, origin=f"rotation key:{d}") for i, d in enumerate(eng.galois_deltas)]
+    return eng._new(parts, "galois key", include_special=True, ntt_state=True, montgomery_state=True)
+
+
+OPS = {
+    "negate(a)": lambda e, a, b, evk, gk: e.negate(a),
+    "mult_int_scalar(a,-7)": lambda e, a, b, evk, gk: e.mult_int_scalar(a, -7),
+    "mult(3,a)": lambda e, a, b, evk, gk: e.mult(3, a),
+    "mult_scalar(a,0.37)": lambda e, a, b, evk, gk: e.mult_scalar(a, 0.37),
+    "add_scalar(a,1.25)": lambda e, a, b, evk, gk: e.add_scalar(a, 1.25),
+    "sub(2.5,a)": lambda e, a, b, evk, gk: e.sub(2.5, a),
+    "sum(a,gk)": lambda e, a, b, evk, gk: e.sum(a, gk),
+    "mean(a,gk)": lambda e, a, b, evk, gk: e.mean(a, gk),
+    "pow(a,3,evk)": lambda e, a, b, evk, gk: e.pow(a, 3, evk),
+    "square(a,relin=False)": lambda e, a, b, evk, gk: e.square(a, evk, relin=False),
+    "var(a,evk,gk)": lambda e, a, b, evk, gk: e.var(a, evk, gk),
+    "cov(a,b,evk,gk)": lambda e, a, b, evk, gk: e.cov(a, b, evk, gk),
+    "add(a,level_up(b,2))": lambda e, a, b, evk, gk: e.add(a, e.level_up(b, 2)),
+}
+
+
+def make(device, rec, backend=None):
+    from liberate_fhe_amd.fhe import ckks_engine
+    kw = {} if backend is None else {"backend": backend}
+    return ckks_engine(devices=[device] * rec["n_devices"], **kw, **rec["params"])
+
+
+def check_ops(eng, rec):
+    s = rec["seeds"]
+    a, b = synth.ciphertext(eng, s["ct_a"], 0), synth.ciphertext(eng, s["ct_b"], 0)
+    evk, gk = synth.key_switch_key(eng, s["evk"]), galois_key(eng, s["gk"])
+    assert set(OPS) == set(rec["ops"])
+    for name, fn in OPS.items():
+        assert digest(fn(eng, a, b, evk, gk)) == rec["ops"][name], name
+
+
+def check_saved_file(eng, tmp_path):
+    """load() of a file the reference wrote; save() -> load() round trips; cpu() / cuda()."""
+    rec = GOLD["saved_ct"]
+    ct = eng.load(SAVED)
+    assert ct.level == rec["level"] and ct.origin == "cipher text" and digest(ct) == rec["digest"]
+    again = synth.ciphertext(eng, rec["seed"], rec["level"])
+    assert digest(again) == rec["digest"]
+    for text in (again, synth.key_switch_key(eng, 41), galois_key(eng, 50)):
+        f = str(tmp_path / "x.pkl")
+        eng.save(text, f)
+        host = eng.load(f, move_to_gpu=False)
+        assert eng.device(host) == "cpu"
+        back = eng.cuda(host)
+        assert _flat_equal(text, back)
+    # the file records the reference's class path, so the reference's load() reads it too
+    raw = open(str(tmp_path / "x.pkl"), "rb").read()
+    assert b"liberate.fhe.data_struct" in raw and b"liberate_fhe_amd" not in raw
+
+
+def _flat_equal(x, y):
+    if hasattr(x.data[0], "origin"):
+        return len(x.data) == len(y.data) and all(_flat_equal(a, b) for a, b in zip(x.data, y.data))
+    return all(torch.equal(s, t) for a, b in zip(x.data, y.data) for s, t in zip(a, b)) and (
+        x.origin, x.level, x.include_special) == (y.origin, y.level, y.include_special)
+
+
+@pytest.mark.parametrize("name", ["evaluator_small", "evaluator_small_x2"])
+def test_checker_engine_reproduces_reference_digests(name, tmp_path):
+    from tests.oracle_backend import OracleBackend
+    eng = make("cpu", GOLD[name], OracleBackend())
+    check_ops(eng, GOLD[name])
+    check_saved_file(eng, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["evaluator_small", "evaluator_small_x2"])
+def test_hip_engine_reproduces_reference_digests(name, tmp_path):
+    eng = make("cuda:0", GOLD[name])
+    check_ops(eng, GOLD[name])
+    check_saved_file(eng, tmp_path)
+
+
+@pytest.mark.gpu
+def test_hip_plaintext_operands_equal_checker():
+    """mc_* / cm_*: both engines get the same encoded plaintext (the fp64 FFT of encode differs in the last
+    bits between host and device, so the integer plaintext is injected); everything after it is bit-exact."""
+    from tests.oracle_backend import OracleBackend
+    rec = GOLD["evaluator_small"]
+    hip, chk = make("cuda:0", rec), make("cpu", rec, OracleBackend())
+    np.random.seed(9)
+    m = chk.example(-1, 1)
+    cache = {}
+
+    def injected(eng):
+        def encode(msg, level=0, padding=True):
+            key = (np.asarray(msg).tobytes(), level)
+            if key not in cache:
+                cache[key] = type(chk).encode(chk, msg, level, padding)[0].clone()
+            return [cache[key].to(eng.ntt.devices[d]) for d in eng.local_ids]
+        return encode
+    chk_encode = injected(chk)
+    outs = []
+    for eng in (chk, hip):
+        eng.encode = chk_encode if eng is chk else injected(eng)
+        a = synth.ciphertext(eng, 61, 0)
+        outs.append([digest(x) for x in (eng.mc_mult(m, a), eng.mc_add(m, a), eng.mc_sub(m, a), eng.cm_sub(a, m),
+                                         eng.mult(a, m), eng.add(list(m), a))])
+    assert outs[0] == outs[1]
+
+
+@pytest.mark.gpu
+def test_hip_plaintext_and_scalar_operands_decode():
+    from liberate_fhe_amd.fhe import ckks_engine
+    eng = ckks_engine(devices=["cuda:0"], logN=12, num_scales=5, num_special_primes=2, is_secured=False)
+    sk = eng.create_secret_key()
+    pk, evk, gk = eng.create_public_key(sk), eng.create_evk(sk), eng.create_galois_key(sk)
+    np.random.seed(4)
+    m1, m2 = eng.example(-1, 1), eng.example(-1, 1)
+    c1 = eng.encorypt(m1, pk)
+    dec = lambda ct: eng.decrode(ct, sk)
+    assert np.abs(dec(eng.mult(c1, m2)) - m1 * m2).max() < 1e-6
+    assert np.abs(dec(eng.add(c1, m2)) - (m1 + m2)).max() < 1e-6
+    assert np.abs(dec(eng.sub(m2, c1)) - (m2 - m1)).max() < 1e-6
+    assert np.abs(dec(eng.mult(c1, 0.25)) - m1 * 0.25).max() < 1e-6
+    assert np.abs(dec(eng.mult(-3, c1)) + 3 * m1).max() < 1e-6
+    assert np.abs(dec(eng.add(c1, 1.5)) - (m1 + 1.5)).max() < 1e-6
+    assert np.abs(dec(eng.sub(2, c1)) - (2 - m1)).max() < 1e-6
+    assert np.abs(dec(eng.negate(c1)) + m1).max() < 1e-6
+    assert np.abs(dec(eng.pow(c1, 3, evk)) - m1 ** 3).max() < 1e-5
+    assert np.abs(dec(eng.mean(c1, gk)) - m1.mean()).max() < 1e-6
+    assert np.abs(dec(eng.sum(c1, gk)) - m1.sum()).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_hip_multiparty_protocol():
+    """Two parties, HIP samplers: collective public / rotation / evaluation keys work end to end."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    e = ckks_engine(devices=["cuda:0"], logN=12, num_scales=5, num_special_primes=2, is_secured=False)
+    sks = [e.create_secret_key(), e.create_secret_key()]
+    pk0 = e.multiparty_create_public_key(sks[0])
+    pk1 = e.multiparty_create_public_key(sks[1], a=e.multiparty_public_crs(pk0))
+    cpk = e.multiparty_create_collective_public_key([pk0, pk1])
+    np.random.seed(5)
+    m = e.example(-1, 1)
+    ct = e.encorypt(m, cpk)
+
+    def open_(x):
+        return e.multiparty_decrypt_fusion([e.multiparty_decrypt_head(x, sks[0]), e.multiparty_decrypt_partial(x, sks[1])],
+                                           level=x.level)
+    assert np.abs(open_(ct) - m).max() < 1e-6
+    r0 = e.multiparty_create_rotation_key(sks[0], 3)
+    r1 = e.multiparty_create_rotation_key(sks[1], 3, a=e.generate_rotation_crs(r0))
+    rot = e.rotate_single(ct, e.multiparty_generate_rotation_key([r0, r1]))
+    assert np.abs(open_(rot) - np.roll(m, 3)).max() < 1e-5
+    shares = [e.create_key_switching_key(sks[0], sks[0])]
+    shares.append(e.create_key_switching_key(sks[1], sks[1], a=e.generate_rotation_crs(shares[0])))
+    evk_sum = e.multiparty_sum_evk_share(shares)
+    cevk = e.multiparty_sum_evk_share_mult([e.multiparty_mult_evk_share_sum(evk_sum, s) for s in sks])
+    assert np.abs(open_(e.cc_mult(ct, ct, cevk)) - m * m).max() < 1e-4
