@@ -55,6 +55,10 @@ def next_ntt_prime(start: int, M: int, up: bool) -> int:
         step = -M
     while not is_prime(q):
         q += step
+        if q < 2:
+            # walked off the bottom: there is no such prime (the reference's search fails the same way,
+            # inside its primality test, once the candidate turns negative — prim_test.py:31)
+            raise LookupError(f"no prime = 1 mod {M} below {start}")
     return q
 
 
@@ -102,7 +106,14 @@ def scale_primes(scale_bits: int, N: int, how_many: int) -> tuple:
 
 
 def scale_prime_pool(scale_bits: int, N: int) -> tuple:
-    """The pool the reference context draws from: 64 primes for logN < 16, else 128
-    (ckks_context.py:230-232 of the reference)."""
+    """The pool the reference context draws from: 64 primes for logN < 16, else 128; where the ring leaves
+    too few NTT primes near 2^scale_bits the request is halved until the search succeeds, and below two
+    primes there is no pool (generate_primes.py:234-247, 264-270 of the reference)."""
     logN = N.bit_length() - 1
-    return scale_primes(scale_bits, N, 64 if logN < 16 else 128)
+    how_many = 64 if logN < 16 else 128
+    while how_many >= 2:
+        try:
+            return scale_primes(scale_bits, N, how_many)
+        except LookupError:
+            how_many //= 2
+    raise LookupError(f"not enough NTT primes near 2^{scale_bits} for N = {N}")

@@ -1,1 +1,1 @@
-from . import synth
+from . import helpers, synth
