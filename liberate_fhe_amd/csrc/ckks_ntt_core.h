@@ -191,6 +191,25 @@ __device__ __noinline__ double dp_lazy_fix(double t0, u64 A, u64 B, double q) {
     return ((xh > t) || (xh == t && xl != 0)) ? t0 + q : t0;
 }
 
+// CNT consecutive table entries starting at idx0 (a multiple of CNT): the twiddles of one stage inside a
+// radix-2^K step are neighbours in the bit-reversed table, so they come in as 16-byte loads.
+template <int MAXC, class E>
+__device__ __forceinline__ void load_group(const E *tab, int idx0, int cnt, E (&w)[MAXC]) {
+    static_assert(sizeof(E) == 8, "8-byte table entries");
+    if (cnt == 1) {
+        w[0] = tab[(unsigned)idx0];
+    } else {
+        const longlong2 *src = reinterpret_cast<const longlong2 *>(tab + (unsigned)idx0);
+#pragma unroll
+        for (int i = 0; i < MAXC / 2; ++i) {
+            if (2 * i >= cnt) break;
+            const longlong2 v = src[i];
+            w[2 * i] = *reinterpret_cast<const E *>(&v.x);
+            w[2 * i + 1] = *reinterpret_cast<const E *>(&v.y);
+        }
+    }
+}
+
 struct Ctx {
     RowMod m;
     RowDp d;
@@ -209,6 +228,8 @@ struct ArithInt {
     typedef i64 T;
     typedef i64 W;
     static __device__ __forceinline__ W tw(const Ctx &c, int idx) { return c.tw_mont[(unsigned)idx]; }
+    template <int MAXC>
+    static __device__ __forceinline__ void tw_group(const Ctx &c, int idx0, int cnt, W (&w)[MAXC]) { load_group<MAXC>(c.tw_mont, idx0, cnt, w); }
     static __device__ __forceinline__ T mul(const Ctx &c, W S, T O) {
         return SIGNED ? mm62s(S, O, c.m.q, c.m.k) : mm62u((u64)S, (u64)O, c.m.q, c.m.k);
     }
@@ -236,6 +257,8 @@ struct ArithDp {
     typedef double T;
     typedef double W;
     static __device__ __forceinline__ W tw(const Ctx &c, int idx) { return c.tw_dp[(unsigned)idx]; }
+    template <int MAXC>
+    static __device__ __forceinline__ void tw_group(const Ctx &c, int idx0, int cnt, W (&w)[MAXC]) { load_group<MAXC>(c.tw_dp, idx0, cnt, w); }
     // lazy REDC62(S * O) for O = o (any representative < 2^52 of the lazy word mod 2q)
     static __device__ __forceinline__ T mul(const Ctx &c, W w, T o, int idx) {
         T v = dp_mulmod(o, w, c.d);
@@ -272,6 +295,8 @@ struct ArithDpR {
     typedef double T;
     typedef double W;
     static __device__ __forceinline__ W tw(const Ctx &c, int idx) { return c.tw_dp[(unsigned)idx]; }
+    template <int MAXC>
+    static __device__ __forceinline__ void tw_group(const Ctx &c, int idx0, int cnt, W (&w)[MAXC]) { load_group<MAXC>(c.tw_dp, idx0, cnt, w); }
     static __device__ __forceinline__ void fwd(const Ctx &c, T &a, T &b, W w, int) {
         const T U = a, V = dp_mulmod_bal(b, w, c.d);
         a = U + V;
@@ -305,17 +330,18 @@ __device__ __forceinline__ void fwd_step(typename A::T *sm, int T, int log_dl_rt
         typename A::T x[1 << K];
 #pragma unroll
         for (int e = 0; e < (1 << K); ++e) x[e] = sm[PAD(p + (e << log_dl))];
+        // stage u uses 2^u twiddles, entries (i0 << u) .. (i0 << u) + 2^u - 1 of the bit-reversed table
+        const int i0 = (1 << s) + ((base + p) >> (E - s));
 #pragma unroll
         for (int u = 0; u < K; ++u) {
             const int du = 1 << (K - 1 - u);
-            const int st = s + u;
+            typename A::W wv[K > 1 ? (1 << (K - 1)) : 1];
+            A::tw_group(c, i0 << u, 1 << u, wv);
 #pragma unroll
             for (int j = 0; j < (1 << u); ++j) {
                 const int e0 = j << (K - u);
-                const int idx = (1 << st) + ((base + p + (e0 << log_dl)) >> (E - st));
-                const typename A::W wv = A::tw(c, idx);
 #pragma unroll
-                for (int t = 0; t < du; ++t) A::fwd(c, x[e0 + t], x[e0 + t + du], wv, idx);
+                for (int t = 0; t < du; ++t) A::fwd(c, x[e0 + t], x[e0 + t + du], wv[j], (i0 << u) + j);
             }
         }
         A::fwd_end(c, x);
@@ -336,17 +362,18 @@ __device__ __forceinline__ void inv_step(typename A::T *sm, int T, int log_dl_rt
         typename A::T x[1 << K];
 #pragma unroll
         for (int e = 0; e < (1 << K); ++e) x[e] = sm[PAD(p + (e << log_dl))];
+        // stage u uses 2^(K-1-u) twiddles, entries (il << (K-1-u)) .. of the bit-reversed table
+        const int il = (1 << (logN - s - K)) + ((base + p) >> (s + K - adj));
 #pragma unroll
         for (int u = 0; u < K; ++u) {
             const int du = 1 << u;
-            const int st = s + u;
+            typename A::W wv[K > 1 ? (1 << (K - 1)) : 1];
+            A::tw_group(c, il << (K - 1 - u), 1 << (K - 1 - u), wv);
 #pragma unroll
             for (int h = 0; h < (1 << (K - 1 - u)); ++h) {
                 const int e0 = h << (u + 1);
-                const int idx = (1 << (logN - st - 1)) + ((base + p + (e0 << log_dl)) >> (st + 1 - adj));
-                const typename A::W wv = A::tw(c, idx);
 #pragma unroll
-                for (int t = 0; t < du; ++t) A::inv(c, x[e0 + t], x[e0 + t + du], wv, idx);
+                for (int t = 0; t < du; ++t) A::inv(c, x[e0 + t], x[e0 + t + du], wv[h], (il << (K - 1 - u)) + h);
             }
         }
         A::inv_end(c, x);
