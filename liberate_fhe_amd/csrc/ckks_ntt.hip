@@ -86,6 +86,35 @@ int chunk_polys(int batch, int rows, int logN, bool two_pass) {
     return c < 1 ? 1 : (c > batch ? batch : c);
 }
 
+// experiment knob: LF_NTT_COLS=0 falls back to the LDS-tiled strided pass
+bool cols_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("LF_NTT_COLS");
+        on = e ? atoi(e) != 0 : 1;
+    }
+    return on != 0;
+}
+
+template <bool DP>
+void launch_cols(int K, unsigned blocks, hipStream_t st, i64 *base, const PassGeom &g, const RowList &rl,
+                 const int64_t *psi_br, const double *psi_dp, const i64 *rs, const int64_t *ql, const int64_t *qh,
+                 const int64_t *kl, const int64_t *kh) {
+#define LF_COLS_CASE(KK)                                                                                              \
+    case KK:                                                                                                          \
+        hipLaunchKernelGGL((ntt_fwd_cols<DP, KK>), dim3(blocks), dim3(NTT_COL_THREADS), 0, st, base, g, rl,           \
+                           (const i64 *)psi_br, psi_dp, rs, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl,        \
+                           (const i64 *)kh);                                                                          \
+        break;
+    switch (K) {
+        LF_COLS_CASE(1)
+        LF_COLS_CASE(2)
+        LF_COLS_CASE(3)
+        LF_COLS_CASE(4)
+    }
+#undef LF_COLS_CASE
+}
+
 }  // namespace
 
 extern "C" {
@@ -130,6 +159,12 @@ int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, con
             const PassGeom g = pass == 0 ? PassGeom{logN, tl, 1, S1, 0, tl - S1, rows, nb, relaxed, 0, plain, 1, 0}
                                          : PassGeom{logN, tl, 0, tl, S1, 0, rows, nb, relaxed, 1, plain, 1, 0};
             const i64 *rs = (pass == 0 || S1 == 0) ? (const i64 *)Rs : nullptr;
+            if (pass == 0 && S1 <= 4 && cols_enabled()) {   // leading stages: one register step per column
+                const unsigned col_blocks = (unsigned)nb * ((1u << (logN - S1)) / NTT_COL_THREADS);
+                if (dp.n) launch_cols<true>(S1, col_blocks * dp.n, st, base, g, dp, psi_br, psi_dp, rs, ql, qh, kl, kh);
+                if (in.n) launch_cols<false>(S1, col_blocks * in.n, st_int, base, g, in, psi_br, psi_dp, rs, ql, qh, kl, kh);
+                continue;
+            }
             if (dp.n)
                 hipLaunchKernelGGL(ntt_fwd_pass<true>, dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, base, g, dp,
                                    (const i64 *)psi_br, psi_dp, rs, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl,

@@ -269,11 +269,11 @@ struct ArithDp {
     static __device__ __forceinline__ void fwd(const Ctx &c, T &a, T &b, W w, int idx) {
         const T U = a, V = mul(c, w, b, idx);      // V in [0, 2q)
         a = U + V;
-        b = U + (c.d.q2 - V);
+        b = U - V;                                  // representatives may be negative: only the class mod 2q counts
     }
     static __device__ __forceinline__ void inv(const Ctx &c, T &a, T &b, W w, int idx) {
-        const T U = a, V = b;                       // both < c.inv_off (a multiple of 2q) inside a step
-        b = mul(c, w, U - V + c.inv_off, idx);
+        const T U = a, V = b;
+        b = mul(c, w, U - V, idx);
         a = U + V;
     }
     template <int NN>
@@ -560,6 +560,100 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_fwd_pass(i64 *__r
             else run_fwd_stages<ArithInt<false>, true>(sm, g, cur_tile, c);
             store_tile_raw(sm, row, g, cur_tile);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward STRIDED pass as one radix-2^K register step straight from global memory (two-pass transforms
+// with K = logN - 12 <= 4 leading stages).  Thread = one column: its 2^K words sit N/2^K apart, so a wave's
+// loads and stores are 512 contiguous bytes per row; the 2^K - 1 twiddles of these stages depend only on
+// the row index, i.e. they are the table entries 1 .. 2^K - 1 for every thread of the limb (scalar loads).
+// No LDS, no barriers, no per-lane twiddle traffic: 2.4x fewer VALU instructions than staging the same
+// four stages through a 4096-word LDS tile.  Arithmetic, entry and range handling are those of
+// ntt_fwd_pass; the class decision (exact fp64 vs signed integer routine) is taken per lane.
+// ------------------------------------------------------------------------------------------------
+#define NTT_COL_THREADS 256
+
+template <class A, int K>
+__device__ __forceinline__ void cols_fwd_stages(typename A::T (&x)[1 << K], const Ctx &c) {
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        const int du = 1 << (K - 1 - u);
+#pragma unroll
+        for (int j = 0; j < (1 << u); ++j) {
+            const int e0 = j << (K - u);
+            const int idx = (1 << u) + j;
+            const typename A::W wv = A::tw(c, idx);
+#pragma unroll
+            for (int t = 0; t < du; ++t) A::fwd(c, x[e0 + t], x[e0 + t + du], wv, idx);
+        }
+    }
+}
+
+template <bool DP, int K>
+__global__ void __launch_bounds__(NTT_COL_THREADS) ntt_fwd_cols(i64 *__restrict__ a, PassGeom g, RowList rl,
+                                                               const i64 *__restrict__ psi_br,
+                                                               const double *__restrict__ psi_dp, const i64 *__restrict__ Rs,
+                                                               const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                               const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    constexpr int R = 1 << K;
+    const int logC = g.logN - K;
+    const int chunks = (1 << logC) / NTT_COL_THREADS;
+    const int b = blockIdx.x;
+    const int chunk = b % chunks, r = b / chunks;
+    const int poly = r % g.batch, crow = rl.id[r / g.batch];
+    const bool enter = (Rs != nullptr) && !(DP && g.plain);
+
+    Ctx c;
+    c.m = load_mod(ql, qh, kl, kh, crow);
+    c.d = make_dp(c.m);
+    c.tw_mont = psi_br + ((i64)crow << g.logN);
+    c.tw_dp = DP ? psi_dp + ((i64)crow << g.logN) : nullptr;
+    c.relaxed = g.relaxed;
+    c.inv_off = 0.0;
+    c.inv_reduce = 0;
+    const i64 rs = enter ? Rs[crow] : 0;
+    i64 *col = a + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS + threadIdx.x;
+
+    i64 w[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) w[k] = col[(i64)k << logC];
+    int odd = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        if (g.relaxed) w[k] = w[k] < 0 ? w[k] + c.m.q2 : w[k];   // residues only: fold signed-lazy words
+        odd |= ((u64)w[k] >= (u64)c.m.q2);
+    }
+    if (DP && (g.relaxed || !odd)) {
+        double x[R];
+        const double r1 = enter ? (double)((1ull << 62) % c.m.q) : 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            double v = dp_from_word(w[k]);
+            if (enter) {   // Montgomery entry, emulated exactly: REDC62(a * R^2)
+                v = dp_mulmod(v, r1, c.d);
+                if (!g.relaxed && v < LAZY_FIX_LIMIT) v = dp_lazy_fix(v, (u64)w[k], (u64)rs, c.d.q);
+            }
+            x[k] = v;
+        }
+        if (g.relaxed) cols_fwd_stages<ArithDpR, K>(x, c);
+        else cols_fwd_stages<ArithDp, K>(x, c);
+        const double md = g.relaxed ? c.d.q : c.d.q2, mi = g.relaxed ? c.d.qinv : c.d.q2inv;
+#pragma unroll
+        for (int k = 0; k < R; ++k) col[(i64)k << logC] = dp_to_word(dp_reduce(x[k], md, mi));
+    } else {
+        // integer class, or a lane of the fp64 class holding signed-lazy words
+        if (enter) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                w[k] = mm62s(w[k], rs, c.m.q, c.m.k);
+                odd |= ((u64)w[k] >= (u64)c.m.q2);
+            }
+        }
+        if (odd || DP) cols_fwd_stages<ArithInt<true>, K>(w, c);
+        else cols_fwd_stages<ArithInt<false>, K>(w, c);
+#pragma unroll
+        for (int k = 0; k < R; ++k) col[(i64)k << logC] = w[k];
     }
 }
 
