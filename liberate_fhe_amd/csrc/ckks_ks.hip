@@ -277,6 +277,15 @@ int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64
     for (int pass = 0; pass < 2; ++pass) {
         PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, 2, 1, 0, 0, 1, 0}
                                : PassGeom{logN, tl, 1, S1, tl, tl - S1, rows, 2, 1, 1, 0, 1, 0};
+        if (pass == 1 && S1 <= 4 && cols_enabled()) {
+            if (dp.n)
+                launch_inv_cols<true>(S1, 2, st, (i64 *)s, g, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,
+                                      (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+            if (in.n)
+                launch_inv_cols<false>(S1, 2, st, (i64 *)s, g, in, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,
+                                       (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+            continue;
+        }
         if (dp.n)
             hipLaunchKernelGGL(ntt_inv_pass_io<true>, dim3(per_row2 * dp.n), dim3(NTT_THREADS), 0, st, (const i64 *)s, (i64 *)s,
                                g, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, pass == 1 ? 2 : TAIL_NONE,

@@ -86,16 +86,6 @@ int chunk_polys(int batch, int rows, int logN, bool two_pass) {
     return c < 1 ? 1 : (c > batch ? batch : c);
 }
 
-// experiment knob: LF_NTT_COLS=0 falls back to the LDS-tiled strided pass
-bool cols_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char *e = getenv("LF_NTT_COLS");
-        on = e ? atoi(e) != 0 : 1;
-    }
-    return on != 0;
-}
-
 template <bool DP>
 void launch_cols(int K, unsigned blocks, hipStream_t st, i64 *base, const PassGeom &g, const RowList &rl,
                  const int64_t *psi_br, const double *psi_dp, const i64 *rs, const int64_t *ql, const int64_t *qh,
@@ -213,6 +203,15 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
             const PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, nb, relaxed, SB == 0, plain, 1, 0}
                                          : PassGeom{logN, tl, 1, SB, tl, tl - SB, rows, nb, relaxed, 1, plain, 1, 0};
             const int t = g.last ? tail : TAIL_NONE;
+            if (pass == 1 && SB <= 4 && cols_enabled()) {   // trailing stages + chain tail: one register step per column
+                if (dp.n)
+                    launch_inv_cols<true>(SB, nb, st, base, g, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t,
+                                          (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+                if (in.n)
+                    launch_inv_cols<false>(SB, nb, st_int, base, g, in, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t,
+                                           (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+                continue;
+            }
             if (dp.n)
                 hipLaunchKernelGGL(ntt_inv_pass_io<true>, dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, (const i64 *)base, base, g, dp,
                                    (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t, (const i64 *)ql, (const i64 *)qh,

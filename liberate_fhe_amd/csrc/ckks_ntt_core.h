@@ -3,6 +3,7 @@
 // See the header comment of ckks_ntt.hip for the design.
 #pragma once
 #include "ckks_common.h"
+#include <stdlib.h>
 
 #define NTT_THREADS 512
 #define NTT_TILE_LOG_MAX 12
@@ -755,6 +756,134 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_inv_pass_io(const
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// inverse STRIDED (last) pass as one radix-2^K register step per column, chain tail included: the mirror
+// image of ntt_fwd_cols.  Stage u of the step uses the table entries 2^(K-1-u) .. 2^(K-u) - 1.
+// ------------------------------------------------------------------------------------------------
+template <class A, int K>
+__device__ __forceinline__ void cols_inv_stages(typename A::T (&x)[1 << K], const Ctx &c) {
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        const int du = 1 << u;
+#pragma unroll
+        for (int h = 0; h < (1 << (K - 1 - u)); ++h) {
+            const int e0 = h << (u + 1);
+            const int idx = (1 << (K - 1 - u)) + h;
+            const typename A::W wv = A::tw(c, idx);
+#pragma unroll
+            for (int t = 0; t < du; ++t) A::inv(c, x[e0 + t], x[e0 + t + du], wv, idx);
+        }
+    }
+}
+
+// integer chain tail of one word (K.cu:527-529, 754-902)
+__device__ __forceinline__ i64 inv_tail_int(i64 t, int tail, i64 ninv, const Ctx &c) {
+    if (tail == TAIL_NONE) return t;
+    const i64 qq = (i64)c.m.q;
+    i64 z = mm62s(t, ninv, c.m.q, c.m.k);
+    if (tail >= 1) z = redc62(z, c.m.q, c.m.k);
+    if (tail >= 2) z = z < qq ? z : z - qq;
+    if (tail >= 3) z = z <= (qq >> 1) ? z : z - qq;
+    return z;
+}
+
+template <bool DP, int K>
+__global__ void __launch_bounds__(NTT_COL_THREADS) ntt_inv_cols(i64 *__restrict__ a, PassGeom g, RowList rl,
+                                                               const i64 *__restrict__ ipsi_br,
+                                                               const double *__restrict__ ipsi_dp, const i64 *__restrict__ Ninv,
+                                                               int tail, const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                               const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    constexpr int R = 1 << K;
+    const int logC = g.logN - K;
+    const int chunks = (1 << logC) / NTT_COL_THREADS;
+    const int b = blockIdx.x;
+    const int chunk = b % chunks, r = b / chunks;
+    const int poly = r % g.batch, crow = rl.id[r / g.batch];
+    Ctx c;
+    c.m = load_mod(ql, qh, kl, kh, crow);
+    c.d = make_dp(c.m);
+    c.tw_mont = ipsi_br + ((i64)crow << g.logN);
+    c.tw_dp = DP ? ipsi_dp + ((i64)crow << g.logN) : nullptr;
+    c.relaxed = g.relaxed;
+    c.inv_off = 0.0;
+    c.inv_reduce = 0;
+    const i64 ninv_mont = (tail != TAIL_NONE) ? Ninv[crow] : 0;
+    i64 *col = a + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS + threadIdx.x;
+
+    i64 w[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) w[k] = col[(i64)k << logC];
+    int odd = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        if (g.relaxed) w[k] = w[k] < 0 ? w[k] + c.m.q2 : w[k];
+        odd |= ((u64)w[k] >= (u64)c.m.q2);
+    }
+    if (DP && !odd) {
+        double x[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) x[k] = dp_from_word(w[k]);
+        if (g.relaxed) cols_inv_stages<ArithDpR, K>(x, c);
+        else cols_inv_stages<ArithDp, K>(x, c);
+        const i64 qq = (i64)c.m.q;
+        const double ninv_plain = c.d.q - (double)((c.m.q - 1) >> g.logN);                  // N^-1 mod q
+        const double rinv = (double)(u64)((((u128)c.m.k * (u128)c.m.q) + 1) >> 62);         // R^-1 mod q
+        const double c2 = g.plain ? ninv_plain : dp_mulmod(ninv_plain, rinv, c.d);          // N^-1 (R^-1) mod q
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const double t = x[k];
+            double z;
+            if (tail == TAIL_NONE) {
+                z = g.relaxed ? dp_addmask(dp_reduce_bal(t, c.d), c.d.q) : dp_reduce(t, c.d.q2, c.d.q2inv);
+            } else if (tail >= 2) {
+                z = dp_mulmod(t, c2, c.d);
+                if (tail >= 3) z = z <= (double)(qq >> 1) ? z : z - c.d.q;
+            } else {
+                const double tr = dp_reduce(t, c.d.q2, c.d.q2inv);   // the reference's lazy word
+                z = dp_mulmod(tr, ninv_plain, c.d);
+                if (z < LAZY_FIX_LIMIT) z = dp_lazy_fix(z, (u64)tr, (u64)ninv_mont, c.d.q);
+                if (tail == 1) z = (z == c.d.q) ? c.d.q : dp_mulmod(z, rinv, c.d);   // redc(q) = q (K.cu:587-606)
+            }
+            col[(i64)k << logC] = (tail >= 3) ? (i64)z : dp_to_word(z);
+        }
+    } else {
+        if (odd || DP) cols_inv_stages<ArithInt<true>, K>(w, c);
+        else cols_inv_stages<ArithInt<false>, K>(w, c);
+#pragma unroll
+        for (int k = 0; k < R; ++k) col[(i64)k << logC] = inv_tail_int(w[k], tail, ninv_mont, c);
+    }
+}
+
+// host: launch of the inverse column pass for one arithmetic class (K = number of trailing stages, 1..4)
+template <bool DP>
+inline void launch_inv_cols(int K, int polys, hipStream_t st, i64 *base, const PassGeom &g, const RowList &rl,
+                            const i64 *ipsi_br, const double *ipsi_dp, const i64 *Ninv, int tail, const i64 *ql,
+                            const i64 *qh, const i64 *kl, const i64 *kh) {
+    const unsigned blocks = (unsigned)polys * (unsigned)rl.n * ((1u << (g.logN - K)) / NTT_COL_THREADS);
+#define LF_ICOLS_CASE(KK)                                                                                             \
+    case KK:                                                                                                          \
+        hipLaunchKernelGGL((ntt_inv_cols<DP, KK>), dim3(blocks), dim3(NTT_COL_THREADS), 0, st, base, g, rl, ipsi_br,  \
+                           ipsi_dp, Ninv, tail, ql, qh, kl, kh);                                                      \
+        break;
+    switch (K) {
+        LF_ICOLS_CASE(1)
+        LF_ICOLS_CASE(2)
+        LF_ICOLS_CASE(3)
+        LF_ICOLS_CASE(4)
+    }
+#undef LF_ICOLS_CASE
+}
+
+// experiment knob: LF_NTT_COLS=0 falls back to the LDS-tiled strided passes
+inline bool cols_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("LF_NTT_COLS");
+        on = e ? atoi(e) != 0 : 1;
+    }
+    return on != 0;
 }
 
 // plain canonical twiddles as doubles from the Montgomery table: w = reduce(redc(S))
