@@ -11,10 +11,11 @@ Infinity Cache.  Inputs are synthetic (splitmix64 -> mod 2q), resident in HBM be
 Polynomials are independent, so ranks shard them with no data-path collective: weak scaling.
 
 The JSON line also carries
-  roofline     : the dominant kernel (ntt_fwd_pass<true>, the fp64-class pass kernel, 2 launches per
-                 transform) against the 8 TB/s HBM peak; algorithmic bytes per launch = 8*N*limbs (each
-                 pass streams the stack once; a transform is 16*N bytes per limb); its launch
-                 duration is measured live with HIP events on the launch stream;
+  roofline     : the dominant kernel (ntt_fwd_pass<true>: the fp64-class tiled pass, the second of the two
+                 launches of a transform, 12 of its 16 stages) against the 8 TB/s HBM peak; algorithmic bytes
+                 per launch = 8*N*limbs (a transform is 16*N bytes per limb, SURVEY.md §8d, spread over its two
+                 launches); its launch duration is measured live with HIP events on the launch stream, the
+                 kernel launched alone (LF_NTT_ONLY_PASS=2) with the grid it has inside the full step;
   cpu_baseline : the C oracle (strict reference-kernel semantics) on this box's host cores, same workload,
                  bounded sample;
   extra        : cc_mult(+relinearize) ops/s for silver and gold on this rank, rotate ops/s, limb-NTT/s.
@@ -222,10 +223,10 @@ def main():
 
     value = world * B / (wall / args.steps)                         # poly-NTT(30)/s, whole job
 
-    # Roofline of the dominant kernel, ntt_fwd_pass<true> (the fp64-class pass kernel: 25 of the 30 limbs).
-    # In the step above its two launches overlap the integer-class launches on a side stream, so it is timed
-    # on its own here: the same lf_ntt call on the stack of the 25 fp64-class limbs launches exactly that
-    # kernel twice (strided pass, contiguous pass) with the same grid as inside the full step.
+    # Roofline of the dominant kernel, ntt_fwd_pass<true> (the fp64-class tiled pass: 25 of the 30 limbs, 12 of
+    # the 16 stages).  In the step above it overlaps the integer-class launches on a side stream and follows the
+    # column pass, so it is timed on its own here: lf_ntt on the stack of the 25 fp64-class limbs with
+    # LF_NTT_ONLY_PASS=2 launches exactly that kernel, once, with the grid it has inside the full step.
     dp_idx = [i for i in rows_idx if ctx.q[i] < (1 << 41)]
     sel = torch.tensor([i - lo for i in dp_idx], device=dev)
     xd = x[:, [i - lo for i in dp_idx], :].contiguous()
@@ -240,9 +241,16 @@ def main():
     for _ in range(max(3, args.warmup // 2)):
         dp_step()
     torch.cuda.synchronize()
-    launches = 2                                                    # strided pass + contiguous pass
     n_roof = max(10, args.steps // 2)
-    k_ms = event_time_ms(dp_step, n_roof) / launches
+    transform_ms = event_time_ms(dp_step, n_roof)                   # both launches (column pass + tiled pass)
+    os.environ["LF_NTT_ONLY_PASS"] = "2"
+    try:
+        dp_step()
+        torch.cuda.synchronize()
+        launches = 1
+        k_ms = event_time_ms(dp_step, n_roof)
+    finally:
+        del os.environ["LF_NTT_ONLY_PASS"]
     alg_bytes_per_launch = 8 * N * len(dp_idx) * B                  # 16*N per limb per transform, two launches
     achieved = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
     traffic = None
@@ -260,8 +268,10 @@ def main():
                    "batch_per_gpu": B, "limbs": L_LIMBS, "logN": LOGN, "parallelism": f"replicas x{world} (independent polynomials)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "ntt_fwd_pass<true> (fp64 class, 25 of the 30 limbs)", "launches_per_transform": launches,
-                     "avg_launch_ms": k_ms, "launches_timed": launches * n_roof,
+                     "kernel": "ntt_fwd_pass<true> (fp64 class, 25 of the 30 limbs; tiled pass = 12 of 16 stages)",
+                     "launches_per_transform": 2, "avg_launch_ms": k_ms, "launches_timed": launches * n_roof,
+                     "fp64_class_transform_ms": transform_ms,
+                     "fp64_class_transform_algorithmic_GBps": 2 * alg_bytes_per_launch / (transform_ms * 1e-3) / 1e9,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                      "whole_step_algorithmic_GBps": 16 * N * L_LIMBS * B / (dev_ms * 1e-3) / 1e9},
     }

@@ -140,12 +140,17 @@ int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, con
         (void)hipEventRecord(side->fork, st);
         (void)hipStreamWaitEvent(side->stream, side->fork, 0);
     }
+    // LF_NTT_ONLY_PASS=1|2 (read per call): launch only the column pass / only the tiled pass of a two-pass
+    // transform.  The result is then NOT a transform; bench.py uses it to time the dominant kernel alone.
+    const char *only_env = S1 > 0 ? getenv("LF_NTT_ONLY_PASS") : nullptr;
+    const int only_pass = only_env ? atoi(only_env) : 0;
     const int chunk = chunk_polys(batch, rows, logN, S1 > 0);
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int nb = batch - b0 < chunk ? batch - b0 : chunk;
         i64 *base = (i64 *)a + ((i64)b0 * rows << logN);
         const unsigned per_row = (unsigned)nb << (logN - tl);
         for (int pass = (S1 > 0 ? 0 : 1); pass < 2; ++pass) {
+            if (only_pass && pass + 1 != only_pass) continue;   // measurement only: time one pass kernel by itself
             const PassGeom g = pass == 0 ? PassGeom{logN, tl, 1, S1, 0, tl - S1, rows, nb, relaxed, 0, plain, 1, 0}
                                          : PassGeom{logN, tl, 0, tl, S1, 0, rows, nb, relaxed, 1, plain, 1, 0};
             const i64 *rs = (pass == 0 || S1 == 0) ? (const i64 *)Rs : nullptr;
