@@ -351,6 +351,42 @@ __device__ __forceinline__ void fwd_step(typename A::T *sm, int T, int log_dl_rt
     }
 }
 
+// The radix-8 step of the 4096-word schedules with its 7 twiddles passed in: the caller loads the NEXT
+// step's twiddles before the barrier that ends the current one, so their L2 latency hides behind it.
+template <class A, int LOGDL>
+struct StepTw {
+    typename A::W w0[1], w1[2], w2[4];
+    int i0;
+    __device__ __forceinline__ void load(const Ctx &c, int s, int E, int base) {
+        const int w = threadIdx.x;
+        const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
+        i0 = (1 << s) + ((base + p) >> (E - s));
+        A::tw_group(c, i0, 1, w0);
+        A::tw_group(c, i0 << 1, 2, w1);
+        A::tw_group(c, i0 << 2, 4, w2);
+    }
+};
+
+template <class A, int LOGDL>
+__device__ __forceinline__ void fwd_step8(typename A::T *sm, const StepTw<A, LOGDL> &tw, const Ctx &c) {
+    const int w = threadIdx.x;
+    const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
+    typename A::T x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = sm[PAD(p + (e << LOGDL))];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) A::fwd(c, x[t], x[t + 4], tw.w0[0], tw.i0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) A::fwd(c, x[4 * j + t], x[4 * j + t + 2], tw.w1[j], (tw.i0 << 1) + j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) A::fwd(c, x[2 * j], x[2 * j + 1], tw.w2[j], (tw.i0 << 2) + j);
+    A::fwd_end(c, x);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm[PAD(p + (e << LOGDL))] = x[e];
+}
+
 // Inverse radix-2^K step over local distances dl, 2dl, .. at stages s, s+1, ..
 //   twiddle index: (N >> (st+1)) + ((base + L) >> (st + 1 - adj))
 template <int K, class A, int LOGDL = -1>
@@ -383,6 +419,41 @@ __device__ __forceinline__ void inv_step(typename A::T *sm, int T, int log_dl_rt
     }
 }
 
+// inverse counterpart: stage u of the radix-8 step uses 2^(2-u) twiddles, entries (il << (2-u)) + h
+template <class A, int LOGDL>
+struct StepTwInv {
+    typename A::W w0[4], w1[2], w2[1];
+    int il;
+    __device__ __forceinline__ void load(const Ctx &c, int s, int adj, int logN, int base) {
+        const int w = threadIdx.x;
+        const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
+        il = (1 << (logN - s - 3)) + ((base + p) >> (s + 3 - adj));
+        A::tw_group(c, il << 2, 4, w0);
+        A::tw_group(c, il << 1, 2, w1);
+        A::tw_group(c, il, 1, w2);
+    }
+};
+
+template <class A, int LOGDL>
+__device__ __forceinline__ void inv_step8(typename A::T *sm, const StepTwInv<A, LOGDL> &tw, const Ctx &c) {
+    const int w = threadIdx.x;
+    const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
+    typename A::T x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = sm[PAD(p + (e << LOGDL))];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) A::inv(c, x[2 * h], x[2 * h + 1], tw.w0[h], (tw.il << 2) + h);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) A::inv(c, x[4 * h + t], x[4 * h + t + 2], tw.w1[h], (tw.il << 1) + h);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) A::inv(c, x[t], x[t + 4], tw.w2[0], tw.il);
+    A::inv_end(c, x);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm[PAD(p + (e << LOGDL))] = x[e];
+}
+
 template <class A, bool FAST>
 __device__ __forceinline__ void run_fwd_stages(typename A::T *sm, const PassGeom &g, int tile, const Ctx &c) {
     const int T = 1 << g.tl;
@@ -390,10 +461,22 @@ __device__ __forceinline__ void run_fwd_stages(typename A::T *sm, const PassGeom
     const int base = g.strided ? 0 : (tile << g.tl);
     int s = g.s0, left = g.S, log_d = g.tl - 1;
     if (FAST && g.tl == 12 && g.S == 12) {   // contiguous 4096-word pass: distances known at compile time
-        fwd_step<3, A, 9>(sm, T, 9, s, E, base, c); lds_barrier();
-        fwd_step<3, A, 6>(sm, T, 6, s + 3, E, base, c); lds_barrier();
-        fwd_step<3, A, 3>(sm, T, 3, s + 6, E, base, c); lds_barrier();
-        fwd_step<3, A, 0>(sm, T, 0, s + 9, E, base, c); lds_barrier();
+        StepTw<A, 9> t9;
+        StepTw<A, 6> t6;
+        StepTw<A, 3> t3;
+        StepTw<A, 0> t0;
+        t9.load(c, s, E, base);
+        fwd_step8<A, 9>(sm, t9, c);
+        t6.load(c, s + 3, E, base);
+        lds_barrier();
+        fwd_step8<A, 6>(sm, t6, c);
+        t3.load(c, s + 6, E, base);
+        lds_barrier();
+        fwd_step8<A, 3>(sm, t3, c);
+        t0.load(c, s + 9, E, base);
+        lds_barrier();
+        fwd_step8<A, 0>(sm, t0, c);
+        lds_barrier();
         return;
     }
     if (FAST && g.tl == 12 && left >= 3) {   // strided pass of a 4096-word tile: first step at distance 2^11
@@ -432,11 +515,23 @@ __device__ __forceinline__ void run_inv_stages(typename A::T *sm, const PassGeom
         cc.inv_reduce = ((nstep & 1) == 0) || (left - K <= 0);
         if (cc.inv_reduce) bound = c.d.q2;
     };
-    if (FAST && g.tl == 12 && g.S == 12) {
-        arm(3); inv_step<3, A, 0>(sm, T, 0, s, adj, g.logN, base, cc); left -= 3; lds_barrier();
-        arm(3); inv_step<3, A, 3>(sm, T, 3, s + 3, adj, g.logN, base, cc); left -= 3; lds_barrier();
-        arm(3); inv_step<3, A, 6>(sm, T, 6, s + 6, adj, g.logN, base, cc); left -= 3; lds_barrier();
-        arm(3); inv_step<3, A, 9>(sm, T, 9, s + 9, adj, g.logN, base, cc); lds_barrier();
+    if (FAST && g.tl == 12 && g.S == 12) {   // the next step's twiddles are requested before each barrier
+        StepTwInv<A, 0> t0;
+        StepTwInv<A, 3> t3;
+        StepTwInv<A, 6> t6;
+        StepTwInv<A, 9> t9;
+        t0.load(c, s, adj, g.logN, base);
+        arm(3); inv_step8<A, 0>(sm, t0, cc); left -= 3;
+        t3.load(c, s + 3, adj, g.logN, base);
+        lds_barrier();
+        arm(3); inv_step8<A, 3>(sm, t3, cc); left -= 3;
+        t6.load(c, s + 6, adj, g.logN, base);
+        lds_barrier();
+        arm(3); inv_step8<A, 6>(sm, t6, cc); left -= 3;
+        t9.load(c, s + 9, adj, g.logN, base);
+        lds_barrier();
+        arm(3); inv_step8<A, 9>(sm, t9, cc);
+        lds_barrier();
         return;
     }
     while (left > 0) {
