@@ -137,10 +137,11 @@ struct RowDp {
     double q, q2, qinv, q2inv;
 };
 
-// r < 0 ? r + m : r, with the select done on the sign bit by 32-bit integer ops (full rate)
+// r < 0 ? r + m : r in three fp64 instructions: floor(r * 2^-64) is -1 for r < 0 and 0 otherwise (|r| < 2^53).
+// (Masking m with the sign bit costs four: shift, two 32-bit ANDs, add; measured 1 % slower on the tiled pass.)
 __device__ __forceinline__ double dp_addmask(double r, double m) {
-    const i64 mask = __double_as_longlong(r) >> 63;
-    return r + __longlong_as_double(__double_as_longlong(m) & mask);
+    const double neg = __builtin_floor(r * 5.421010862427522e-20);
+    return __builtin_fma(-neg, m, r);
 }
 
 // exact int <-> double for 0 <= x < 2^52 with one OR/AND on the high word and one fp64 add
