@@ -52,11 +52,18 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ks_ext_pass1(const i6
     __shared__ i64 sm[NTT_LDS_WORDS + 1];
     const int T = 1 << kg.tl;
     const int tiles = 1 << (kg.logN - kg.tl);
-    // consecutive blocks share (digit, tile) and differ in the target limb: they re-read the same digit
-    // columns, which stay in L2
+    // the blocks of one (digit, tile) pair differ in the target limb and re-read the same digit columns: they are
+    // placed on ONE XCD (blocks b, b + 8, .. share an XCD), so those columns are fetched into one L2, once
     const int b = blockIdx.x;
-    const int ri = b % rl.n;
-    const int pt = b / rl.n;
+    int ri, pt;
+    if (((tiles * kg.nparts) & 7) == 0) {
+        const int x = b & 7, r = b >> 3;
+        ri = r % rl.n;
+        pt = (r / rl.n) * 8 + x;
+    } else {
+        ri = b % rl.n;
+        pt = b / rl.n;
+    }
     const int tile = pt % tiles, p = pt / tiles;
     const int crow = rl.id[ri];
     const PassGeom g{kg.logN, kg.tl, 1, kg.S1, 0, kg.tl - kg.S1, kg.rows, kg.nparts, 1, 0, 0, 1, 0};
