@@ -585,8 +585,10 @@ class ckks_engine(EvaluatorOps):
     # =============================================================================================
     # rescale (eng.py:967-1052)
     # =============================================================================================
-    def _rescale_into(self, ct, outs):
-        """Rescale ct (level l) writing component c of local device d into outs[c][d] ([rows, N] views)."""
+    def _rescale_into(self, ct, outs, exact_rounding=True):
+        """Rescale ct (level l) writing component c of local device d into outs[c][d] ([rows, N] views).
+        Without exact rounding the [row0 > q_l / 2] term is dropped (eng.py:1017-1027, 1036-1038): the kernel's
+        threshold is put out of reach."""
         level = ct.level
         nxt = level + 1
         owner = self.ntt.p.rescaler_loc[level]
@@ -598,7 +600,7 @@ class ckks_engine(EvaluatorOps):
         else:
             row0 = None
         shared = self._share_rows(row0, owner, list(range(self.len_devices[nxt])), (2, N))
-        round_at = self.ctx.q[self.ntt.p.destination_arrays[level][owner][0]] // 2
+        round_at = self.ctx.q[self.ntt.p.destination_arrays[level][owner][0]] // 2 if exact_rounding else (1 << 62)
         for d in self._loc(nxt):
             i = loc_before.index(d)
             rows = self._rows(d, nxt, False)
@@ -614,12 +616,10 @@ class ckks_engine(EvaluatorOps):
         nxt = ct.level + 1
         if nxt >= self.num_levels:
             raise errors.MaximumLevelError(level=ct.level, level_max=self.num_levels)
-        if not exact_rounding:
-            raise NotImplementedError("rescale without exact rounding is not provided (the reference default is exact)")
         loc = self._loc(nxt)
         outs = [{d: torch.empty((self._rows(d, nxt, False), self.ctx.N), dtype=torch.int64, device=self.ntt.devices[d])
                  for d in loc} for _ in range(2)]
-        self._rescale_into(ct, outs)
+        self._rescale_into(ct, outs, exact_rounding)
         return self._new(([outs[0][d] for d in loc], [outs[1][d] for d in loc]), types.origins["ct"], level=nxt)
 
     # =============================================================================================

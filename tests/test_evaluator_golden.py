@@ -38,6 +38,7 @@ OPS = {
     "var(a,evk,gk)": lambda e, a, b, evk, gk: e.var(a, evk, gk),
     "cov(a,b,evk,gk)": lambda e, a, b, evk, gk: e.cov(a, b, evk, gk),
     "add(a,level_up(b,2))": lambda e, a, b, evk, gk: e.add(a, e.level_up(b, 2)),
+    "rescale(a,exact_rounding=False)": lambda e, a, b, evk, gk: e.rescale(a, exact_rounding=False),
 }
 
 

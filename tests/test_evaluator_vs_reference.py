@@ -89,6 +89,7 @@ def test_scalar_operands(world):
     both(w, lambda e: e.add(2, c1))
     both(w, lambda e: e.sub(2.5, c1))
     both(w, lambda e: e.reduce_error(c1))
+    both(w, lambda e: e.rescale(c1, exact_rounding=False))
     with pytest.raises(Exception, match="Unsupported data types"):
         w["me"].mult("x", c1)
 
