@@ -107,7 +107,7 @@ class EvaluatorOps:
         alive = [d for d in range(len(dest)) if len(dest[d])]
         loc = [d for d in alive if d in self.local_ids]
         for t in gpu_data:
-            if t.device.type != "cuda" and self.backend.name != "oracle-cpu":
+            if t.device.type != "cuda" and not getattr(self.backend, "host_tensors", False):
                 raise Exception("To download data to the CPU, it must already be in a GPU!!!")
         # The row count follows the reference (sum over GPUs), which counts the replicated special rows once
         # per GPU: with several GPUs the host tensor carries that many unused trailing rows (zeros here,
@@ -195,7 +195,7 @@ class EvaluatorOps:
         if filename is None:
             filename = self.auto_generate_filename()
         if on_host is None:
-            on_host = self.device(text) == "cpu" and self.backend.name != "oracle-cpu"
+            on_host = self.device(text) == "cpu" and not getattr(self.backend, "host_tensors", False)
         host = text if on_host else self.cpu(text)
         Path(filename).write_bytes(_portable_dumps(host))
 

@@ -146,6 +146,7 @@ def make_ops(name="oracle_ntt_cuda"):
 class OracleBackend:
     """Fused engine ops as sequences of oracle primitives (reference composition, one device)."""
     name = "oracle-cpu"
+    host_tensors = True      # this checker keeps "device" tensors in host memory (engine: cpu()/save() heuristics)
 
     def __init__(self):
         from tests.oracle_csprng import oracle_csprng_class
