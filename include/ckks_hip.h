@@ -34,7 +34,7 @@ extern "C" {
 
 #define LF_ERR_ARG 10001
 
-/* Library probe: returns the ABI version (currently 3). */
+/* Library probe: returns the ABI version (currently 4). */
 int lf_abi_version(void);
 
 /* ---- elementwise family --------------------------------------------------------------------- */
@@ -172,6 +172,18 @@ int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64
                int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
                const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
                const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+
+/* Batched forms: `count` (<= 8) independent operand sets in ONE launch — the two components of a ciphertext, the
+ * four polynomials cc_mult rescales.  The arrays of pointers are HOST arrays of device pointers; constants are
+ * shared by all sets.  addend may be NULL, or hold NULL entries. */
+int lf_rescale_batch(const int64_t *const *in, const int64_t *const *row0, int64_t *const *out, int count, int rows,
+                     int64_t N, const int64_t *scales, int64_t round_at, const int64_t *ql, const int64_t *qh,
+                     const int64_t *kl, const int64_t *kh, int device, void *stream);
+int lf_ks_moddown_batch(const int64_t *const *s, int64_t *const *out, const int64_t *const *addend, int count, int ell, int K,
+                        int64_t N, const int64_t *PiR, const double *PiP, const int64_t *Rs, const int64_t *ql,
+                        const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+int lf_galois_batch(const int64_t *const *a, int64_t *const *dst, int count, int rows, int logN, int64_t p,
+                    const int64_t *_2q, int device, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Samplers: the reference's csprng extensions, src/liberate/csprng/.

@@ -26,10 +26,21 @@ __device__ __forceinline__ double dp_mulmod_q(double a, double w, double q, doub
 
 // ---- rescale (ckks_engine.py:1029-1041) ----------------------------------------------------------
 // out = reduce_q( REDC(in - row0, q_l^-1 * R mod q_i) + [row0 > q_l/2] )
-__global__ void __launch_bounds__(256) rescale_kernel(const i64 *__restrict__ in, const i64 *__restrict__ row0,
-                                                      i64 *__restrict__ out, i64 N, const i64 *__restrict__ scales,
+// Up to LF_BATCH_MAX independent operand sets per launch (blockIdx.z): the two components of a ciphertext, or
+// the four polynomials cc_mult rescales, share one launch instead of paying a launch gap each.
+#define LF_BATCH_MAX 8
+struct PtrBatch {
+    const i64 *in[LF_BATCH_MAX];
+    const i64 *aux[LF_BATCH_MAX];
+    i64 *out[LF_BATCH_MAX];
+};
+
+__global__ void __launch_bounds__(256) rescale_kernel(PtrBatch pb, i64 N, const i64 *__restrict__ scales,
                                                       i64 round_at, const i64 *__restrict__ ql, const i64 *__restrict__ qh,
                                                       const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    const i64 *__restrict__ in = pb.in[blockIdx.z];
+    const i64 *__restrict__ row0 = pb.aux[blockIdx.z];
+    i64 *__restrict__ out = pb.out[blockIdx.z];
     const int r = blockIdx.y;
     const i64 j = ((i64)blockIdx.x * 256 + threadIdx.x) * 2;
     if (j >= N) return;
@@ -191,12 +202,14 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(const i64 *__restrict__ e
 // eliminated last-first; PiR[P_ind][row] = P_j^-1 * R mod q_row.  Optional `addend` (relinearize's
 // d0/d1 or the rotated c0): out = reduce_q(result + addend)  (ckks_engine.py:1135-1140, 952-953).
 #define MD_ROWS 8
-__global__ void __launch_bounds__(256) ks_moddown_kernel(const i64 *__restrict__ s, i64 *__restrict__ out,
-                                                         const i64 *__restrict__ addend, int ell, int K, i64 N,
+__global__ void __launch_bounds__(256) ks_moddown_kernel(PtrBatch pb, int ell, int K, i64 N,
                                                          const i64 *__restrict__ PiR, const double *__restrict__ PiP,
                                                          const i64 *__restrict__ Rs,
                                                          const i64 *__restrict__ ql, const i64 *__restrict__ qh,
                                                          const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    const i64 *__restrict__ s = pb.in[blockIdx.z];
+    const i64 *__restrict__ addend = pb.aux[blockIdx.z];
+    i64 *__restrict__ out = pb.out[blockIdx.z];
     const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
     if (j >= N) return;
     const int rows = ell + K;
@@ -274,17 +287,24 @@ __global__ void __launch_bounds__(256) ks_moddown_kernel(const i64 *__restrict__
 
 extern "C" {
 
+int lf_rescale_batch(const int64_t *const *in, const int64_t *const *row0, int64_t *const *out, int count, int rows,
+                     int64_t N, const int64_t *scales, int64_t round_at, const int64_t *ql, const int64_t *qh,
+                     const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (count < 0 || count > LF_BATCH_MAX || rows < 0 || N < 2 || (N & 1)) return LF_ERR_ARG;
+    if (count == 0 || rows == 0) return 0;
+    if (int e = lf_set_device(device)) return e;
+    PtrBatch pb;
+    for (int i = 0; i < count; ++i) pb.in[i] = (const i64 *)in[i], pb.aux[i] = (const i64 *)row0[i], pb.out[i] = (i64 *)out[i];
+    dim3 grid((unsigned)((N / 2 + 255) / 256), (unsigned)rows, (unsigned)count);
+    hipLaunchKernelGGL(rescale_kernel, grid, dim3(256), 0, (hipStream_t)stream, pb, (i64)N, (const i64 *)scales, (i64)round_at,
+                       (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+    return (int)hipGetLastError();
+}
+
 int lf_rescale(const int64_t *in, const int64_t *row0, int64_t *out, int rows, int64_t N, const int64_t *scales,
                int64_t round_at, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
                void *stream) {
-    if (rows < 0 || N < 2 || (N & 1)) return LF_ERR_ARG;
-    if (rows == 0) return 0;
-    if (int e = lf_set_device(device)) return e;
-    dim3 grid((unsigned)((N / 2 + 255) / 256), (unsigned)rows);
-    hipLaunchKernelGGL(rescale_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const i64 *)in, (const i64 *)row0, (i64 *)out,
-                       (i64)N, (const i64 *)scales, (i64)round_at, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl,
-                       (const i64 *)kh);
-    return (int)hipGetLastError();
+    return lf_rescale_batch(&in, &row0, &out, 1, rows, N, scales, round_at, ql, qh, kl, kh, device, stream);
 }
 
 int lf_tensor(const int64_t *x0, const int64_t *x1, const int64_t *y0, const int64_t *y1, int64_t *d0, int64_t *d1,
@@ -335,17 +355,25 @@ int lf_ks_inner(const int64_t *ext, const int64_t *ksk, int64_t part_stride, int
     return (int)hipGetLastError();
 }
 
-int lf_ks_moddown(const int64_t *s, int64_t *out, const int64_t *addend, int ell, int K, int64_t N, const int64_t *PiR,
-                  const double *PiP, const int64_t *Rs, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
-                  void *stream) {
-    if (ell < 0 || K < 1 || K > KS_MAX_K || N < 1) return LF_ERR_ARG;
-    if (ell == 0) return 0;
+int lf_ks_moddown_batch(const int64_t *const *s, int64_t *const *out, const int64_t *const *addend, int count, int ell, int K,
+                        int64_t N, const int64_t *PiR, const double *PiP, const int64_t *Rs, const int64_t *ql,
+                        const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (count < 0 || count > LF_BATCH_MAX || ell < 0 || K < 1 || K > KS_MAX_K || N < 1) return LF_ERR_ARG;
+    if (count == 0 || ell == 0) return 0;
     if (int e = lf_set_device(device)) return e;
-    dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ell + MD_ROWS - 1) / MD_ROWS));
-    hipLaunchKernelGGL(ks_moddown_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const i64 *)s, (i64 *)out,
-                       (const i64 *)addend, ell, K, (i64)N, (const i64 *)PiR, PiP, (const i64 *)Rs, (const i64 *)ql,
-                       (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+    PtrBatch pb;
+    for (int i = 0; i < count; ++i)
+        pb.in[i] = (const i64 *)s[i], pb.aux[i] = addend ? (const i64 *)addend[i] : nullptr, pb.out[i] = (i64 *)out[i];
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ell + MD_ROWS - 1) / MD_ROWS), (unsigned)count);
+    hipLaunchKernelGGL(ks_moddown_kernel, grid, dim3(256), 0, (hipStream_t)stream, pb, ell, K, (i64)N, (const i64 *)PiR, PiP,
+                       (const i64 *)Rs, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     return (int)hipGetLastError();
+}
+
+int lf_ks_moddown(const int64_t *s, int64_t *out, const int64_t *addend, int ell, int K, int64_t N, const int64_t *PiR,
+                  const double *PiP, const int64_t *Rs, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+                  const int64_t *kh, int device, void *stream) {
+    return lf_ks_moddown_batch(&s, &out, &addend, 1, ell, K, N, PiR, PiP, Rs, ql, qh, kl, kh, device, stream);
 }
 
 }  // extern "C"

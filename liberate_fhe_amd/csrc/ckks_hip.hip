@@ -78,8 +78,15 @@ int launch_ew(const i64 *a, const i64 *b, i64 *c, int rows, i64 N, const i64 *v0
     return (int)hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) galois_kernel(const i64 *__restrict__ a, i64 *__restrict__ dst, int logN, i64 p,
-                                                     const i64 *__restrict__ _2q) {
+#define LF_BATCH_MAX 8
+struct GaloisBatch {
+    const i64 *a[LF_BATCH_MAX];
+    i64 *dst[LF_BATCH_MAX];
+};
+
+__global__ void __launch_bounds__(256) galois_kernel(GaloisBatch gb, int logN, i64 p, const i64 *__restrict__ _2q) {
+    const i64 *__restrict__ a = gb.a[blockIdx.z];
+    i64 *__restrict__ dst = gb.dst[blockIdx.z];
     const int row = blockIdx.y;
     const i64 N = (i64)1 << logN;
     const i64 n = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -102,7 +109,7 @@ __global__ void __launch_bounds__(256) galois_kernel(const i64 *__restrict__ a, 
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int lf_abi_version(void) { return 3; }
+int lf_abi_version(void) { return 4; }
 
 int lf_mont_mult(const int64_t *a, const int64_t *b, int64_t *c, int rows, int64_t N, const int64_t *ql,
                  const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
@@ -154,15 +161,24 @@ int lf_mont_sub(const int64_t *a, const int64_t *b, int64_t *c, int rows, int64_
                              nullptr, device, stream);
 }
 
-int lf_galois(const int64_t *a, int64_t *dst, int rows, int logN, int64_t p, const int64_t *_2q, int device, void *stream) {
-    if (rows < 0 || logN < 1 || logN > 30 || p < 1 || !(p & 1) || p >= ((int64_t)2 << logN) || a == dst) return LF_ERR_ARG;
-    if (rows == 0) return 0;
+int lf_galois_batch(const int64_t *const *a, int64_t *const *dst, int count, int rows, int logN, int64_t p,
+                    const int64_t *_2q, int device, void *stream) {
+    if (count < 0 || count > LF_BATCH_MAX || rows < 0 || logN < 1 || logN > 30 || p < 1 || p >= ((int64_t)2 << logN) || !(p & 1))
+        return LF_ERR_ARG;
+    for (int i = 0; i < count; ++i)
+        if (a[i] == dst[i]) return LF_ERR_ARG;   // a permutation cannot run in place
+    if (count == 0 || rows == 0) return 0;
     if (int e = lf_set_device(device)) return e;
+    GaloisBatch gb;
+    for (int i = 0; i < count; ++i) gb.a[i] = (const i64 *)a[i], gb.dst[i] = (i64 *)dst[i];
     const i64 N = (i64)1 << logN;
-    dim3 grid((unsigned)((N + 255) / 256), (unsigned)rows);
-    hipLaunchKernelGGL(galois_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const i64 *)a, (i64 *)dst, logN, (i64)p,
-                       (const i64 *)_2q);
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)rows, (unsigned)count);
+    hipLaunchKernelGGL(galois_kernel, grid, dim3(256), 0, (hipStream_t)stream, gb, logN, (i64)p, (const i64 *)_2q);
     return (int)hipGetLastError();
+}
+
+int lf_galois(const int64_t *a, int64_t *dst, int rows, int logN, int64_t p, const int64_t *_2q, int device, void *stream) {
+    return lf_galois_batch(&a, &dst, 1, rows, logN, p, _2q, device, stream);
 }
 
 }  // extern "C"

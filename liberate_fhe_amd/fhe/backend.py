@@ -7,6 +7,8 @@ exercised by the CPU test-suite with a checker backend that lives under tests/.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from .._native import lib, check
@@ -25,6 +27,14 @@ def _p(t):
         return 0
     assert t.dtype == torch.int64 and t.is_contiguous(), (t.dtype, t.is_contiguous())
     return t.data_ptr()
+
+
+def _parr(tensors):
+    """Host array of device pointers (None -> NULL) for the batched entry points."""
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else _p(t)
+    return arr
 
 
 class Consts:
@@ -65,7 +75,23 @@ class HipBackend:
         dev, st = _ds(a)
         check(lib.lf_galois(_p(a), _p(dst), rows, logN, p, _p(_2q), dev, st), "lf_galois")
 
+    def galois_batch(self, srcs, dsts, rows, logN, p, _2q):
+        """Several polynomials (the components of a ciphertext) through the same permutation in one launch."""
+        dev, st = _ds(dsts[0])
+        check(lib.lf_galois_batch(_parr(srcs), _parr(dsts), len(srcs), rows, logN, p, _p(_2q), dev, st), "lf_galois_batch")
+
     # ---- fused engine ops ------------------------------------------------------------------------
+    def rescale_batch(self, srcs, row0s, outs, rows, scales, round_at, c: Consts):
+        dev, st = _ds(outs[0])
+        check(lib.lf_rescale_batch(_parr(srcs), _parr(row0s), _parr(outs), len(srcs), rows, outs[0].size(-1), _p(scales),
+                                   round_at, *c.mont(), dev, st), "lf_rescale_batch")
+
+    def ks_moddown_batch(self, ss, outs, addends, ell, K, PiR, Rs, c: Consts, PiP=None):
+        dev, st = _ds(outs[0])
+        check(lib.lf_ks_moddown_batch(_parr(ss), _parr(outs), _parr(addends), len(ss), ell, K, outs[0].size(-1), _p(PiR),
+                                      0 if PiP is None else PiP.data_ptr(), _p(Rs), *c.mont(), dev, st),
+              "lf_ks_moddown_batch")
+
     def rescale(self, src, row0, out, rows, scales, round_at, c: Consts):
         dev, st = _ds(out)
         check(lib.lf_rescale(_p(src), _p(row0), _p(out), rows, out.size(-1), _p(scales), round_at, *c.mont(), dev, st),

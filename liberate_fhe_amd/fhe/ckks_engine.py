@@ -586,29 +586,46 @@ class ckks_engine(EvaluatorOps):
     # rescale (eng.py:967-1052)
     # =============================================================================================
     def _rescale_into(self, ct, outs, exact_rounding=True):
-        """Rescale ct (level l) writing component c of local device d into outs[c][d] ([rows, N] views).
+        """Rescale ct (level l) writing component c of local device d into outs[c][d] ([rows, N] views)."""
+        self._rescale_many([ct], [outs], exact_rounding)
+
+    def _rescale_many(self, cts, outs_list, exact_rounding=True):
+        """Rescale several ciphertexts of one level; outs_list[k][c][d] receives component c of cts[k] on local
+        device d.  All their polynomials go through ONE launch per device (cc_mult: four).
         Without exact rounding the [row0 > q_l / 2] term is dropped (eng.py:1017-1027, 1036-1038): the kernel's
         threshold is put out of reach."""
-        level = ct.level
+        level = cts[0].level
         nxt = level + 1
         owner = self.ntt.p.rescaler_loc[level]
         loc_before = self._loc(level)
         N = self.ctx.N
-        if owner in loc_before:
-            i = loc_before.index(owner)
-            row0 = torch.stack([ct.data[0][i][0], ct.data[1][i][0]])
-        else:
-            row0 = None
-        shared = self._share_rows(row0, owner, list(range(self.len_devices[nxt])), (2, N))
+        targets = list(range(self.len_devices[nxt]))
         round_at = self.ctx.q[self.ntt.p.destination_arrays[level][owner][0]] // 2 if exact_rounding else (1 << 62)
+        # the dropped limb's row of every polynomial, on every local target device
+        rows0 = []                                   # rows0[k][comp] = {device: [N] tensor}
+        multi = self.comm is not None and self.comm.world_size > 1
+        for ct in cts:
+            if multi:
+                stacked = None
+                if owner in loc_before:
+                    i = loc_before.index(owner)
+                    stacked = torch.stack([ct.data[0][i][0], ct.data[1][i][0]])
+                shared = self._share_rows(stacked, owner, targets, (2, N))
+                rows0.append([{d: t[comp] for d, t in shared.items()} for comp in range(2)])
+            else:
+                i = loc_before.index(owner)
+                rows0.append([self._share_rows(ct.data[comp][i][0], owner, targets, (N,)) for comp in range(2)])
         for d in self._loc(nxt):
             i = loc_before.index(d)
-            rows = self._rows(d, nxt, False)
-            c = self._consts(d, nxt, False)
-            for comp in range(2):
-                src = ct.data[comp][i]
-                src = src[1:] if d == owner else src
-                self.backend.rescale(src, shared[d][comp], outs[comp][d], rows, self.rescale_scales[level][d], round_at, c)
+            srcs, r0s, dsts = [], [], []
+            for k, ct in enumerate(cts):
+                for comp in range(2):
+                    src = ct.data[comp][i]
+                    srcs.append(src[1:] if d == owner else src)
+                    r0s.append(rows0[k][comp][d])
+                    dsts.append(outs_list[k][comp][d])
+            self.backend.rescale_batch(srcs, r0s, dsts, self._rows(d, nxt, False), self.rescale_scales[level][d], round_at,
+                                       self._consts(d, nxt, False))
 
     def rescale(self, ct: data_struct, exact_rounding=True) -> data_struct:
         if ct.origin != types.origins["ct"]:
@@ -638,8 +655,8 @@ class ckks_engine(EvaluatorOps):
         d0, d1, d2 = [], [], []
         stacks = {d: self._ws("mult4", (4, self._rows(d, level, False), N), d) for d in loc}
         # x0, x1, y0, y1 are written by the two rescales straight into one [4, rows, N] stack per device
-        self._rescale_into(a, [{d: stacks[d][0] for d in loc}, {d: stacks[d][1] for d in loc}])
-        self._rescale_into(b, [{d: stacks[d][2] for d in loc}, {d: stacks[d][3] for d in loc}])
+        self._rescale_many([a, b], [[{d: stacks[d][0] for d in loc}, {d: stacks[d][1] for d in loc}],
+                                    [{d: stacks[d][2] for d in loc}, {d: stacks[d][3] for d in loc}]])
         for d in loc:
             rows = self._rows(d, level, False)
             c = self._consts(d, level, False)
@@ -841,11 +858,14 @@ class ckks_engine(EvaluatorOps):
             # 5. divide by P (+ optional addend)
             out = torch.empty((2, ell, N), dtype=torch.int64, device=self.ntt.devices[d])
             rs = self._vec("Rs", d, level, True)
+            adds = []
             for comp in range(2):
                 add = addends[comp][i] if addends is not None and addends[comp] is not None else None
                 if add is not None and not add.is_contiguous():
                     add = add.contiguous()
-                self.backend.ks_moddown(s[comp], out[comp], add, ell, K, tabs[("pir", d)], rs, cs, PiP=tabs[("pip", d)])
+                adds.append(add)
+            self.backend.ks_moddown_batch([s[0], s[1]], [out[0], out[1]], adds, ell, K, tabs[("pir", d)], rs, cs,
+                                          PiP=tabs[("pip", d)])
             c0.append(out[0]); c1.append(out[1])
         return c0, c1
 
@@ -871,10 +891,8 @@ class ckks_engine(EvaluatorOps):
             rows = ct.data[0][i].size(0)
             r = torch.empty((2, rows, self.ctx.N), dtype=torch.int64, device=self.ntt.devices[d])
             _2q = self._vec("_2q", d, level, ct.include_special) if canonical else None
-            for comp in range(2):
-                src = ct.data[comp][i]
-                self.backend.galois(src if src.is_contiguous() else src.contiguous(), r[comp], rows, self.ctx.logN,
-                                    exponent, _2q)
+            srcs = [t if t.is_contiguous() else t.contiguous() for t in (ct.data[0][i], ct.data[1][i])]
+            self.backend.galois_batch(srcs, [r[0], r[1]], rows, self.ctx.logN, exponent, _2q)
             rot0.append(r[0]); rot1.append(r[1])
         permuted = data_struct(data=(rot0, rot1), include_special=ct.include_special, ntt_state=ct.ntt_state,
                                montgomery_state=ct.montgomery_state, origin=types.origins["ct"], level=level,

@@ -194,6 +194,18 @@ class OracleBackend:
         orc.reduce_2q(data, rows, _np(c._2q))
         _np(out)[:rows] = data
 
+    def rescale_batch(self, srcs, row0s, outs, rows, scales, round_at, c):
+        for src, row0, out in zip(srcs, row0s, outs):
+            self.rescale(src, row0, out, rows, scales, round_at, c)
+
+    def ks_moddown_batch(self, ss, outs, addends, ell, K, PiR, Rs, c, PiP=None):
+        for s_, out, add in zip(ss, outs, addends):
+            self.ks_moddown(s_, out, add, ell, K, PiR, Rs, c, PiP=PiP)
+
+    def galois_batch(self, srcs, dsts, rows, logN, p, _2q):
+        for a, d in zip(srcs, dsts):
+            self.galois(a, d, rows, logN, p, _2q)
+
     # ---- tensor product: ckks_engine.py:1095-1101 ----
     def tensor(self, x0, x1, y0, y1, d0, d1, d2, rows, c, plain=False):
         a0, a1, b0, b1 = (np.ascontiguousarray(_np(t)[:rows]) for t in (x0, x1, y0, y1))

@@ -1,6 +1,6 @@
 """Kernel-level timing of one engine op (development aid): python tools/ccmult_profile.py gold cc_mult"""
 import sys, os, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("LF_PKG_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # LF_PKG_ROOT: A/B another checkout
 warnings.filterwarnings("ignore")
 import torch
 from liberate_fhe_amd.fhe import ckks_engine, presets
