@@ -42,19 +42,16 @@ struct KsGeom {
 // desc[p] = {row_start, alpha, e_off}; E (Montgomery consts, int class) / Ed (plain consts as doubles,
 // fp64 class) hold, at [e_off + i*rows + r], L_{i-1} R^2 mod q_r resp. L_{i-1} mod q_r (i = 0: R^2, 1).
 template <bool DP>
-__global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ks_ext_pass1(const i64 *__restrict__ state, i64 *__restrict__ tmp,
-                                                                          KsGeom kg, RowList rl, const i64 *__restrict__ desc,
-                                                                          const i64 *__restrict__ E, const double *__restrict__ Ed,
-                                                                          const i64 *__restrict__ psi_br,
-                                                                          const double *__restrict__ psi_dp,
-                                                                          const i64 *__restrict__ ql, const i64 *__restrict__ qh,
-                                                                          const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
-    __shared__ i64 sm[NTT_LDS_WORDS + 1];
+__device__ __forceinline__ void ks_ext_body(i64 *sm, int b, const i64 *__restrict__ state, i64 *__restrict__ tmp,
+                                            const KsGeom &kg, const RowList &rl, const i64 *__restrict__ desc,
+                                            const i64 *__restrict__ E, const double *__restrict__ Ed,
+                                            const i64 *__restrict__ psi_br, const double *__restrict__ psi_dp,
+                                            const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                            const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
     const int T = 1 << kg.tl;
     const int tiles = 1 << (kg.logN - kg.tl);
     // the blocks of one (digit, tile) pair differ in the target limb and re-read the same digit columns: they are
     // placed on ONE XCD (blocks b, b + 8, .. share an XCD), so those columns are fetched into one L2, once
-    const int b = blockIdx.x;
     int ri, pt;
     if (((tiles * kg.nparts) & 7) == 0) {
         const int x = b & 7, r = b >> 3;
@@ -140,6 +137,35 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ks_ext_pass1(const i6
         lds_barrier();
         run_fwd_stages<ArithInt<false>, true>(sm, g, tile, c);
         store_tile_raw(sm, row, g, tile);
+    }
+}
+
+template <bool DP>
+__global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ks_ext_pass1(const i64 *__restrict__ state, i64 *__restrict__ tmp,
+                                                                          KsGeom kg, RowList rl, const i64 *__restrict__ desc,
+                                                                          const i64 *__restrict__ E, const double *__restrict__ Ed,
+                                                                          const i64 *__restrict__ psi_br,
+                                                                          const double *__restrict__ psi_dp,
+                                                                          const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                          const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT_LDS_WORDS + 1];
+    ks_ext_body<DP>(sm, blockIdx.x, state, tmp, kg, rl, desc, E, Ed, psi_br, psi_dp, ql, qh, kl, kh);
+}
+
+// both arithmetic classes in one launch (integer-class blocks first), see ntt_fwd_pass_mixed
+__global__ void __launch_bounds__(NTT_THREADS, 6) ks_ext_pass1_mixed(const i64 *__restrict__ state, i64 *__restrict__ tmp,
+                                                                       KsGeom kg, ClassLists cl, const i64 *__restrict__ desc,
+                                                                       const i64 *__restrict__ E, const double *__restrict__ Ed,
+                                                                       const i64 *__restrict__ psi_br,
+                                                                       const double *__restrict__ psi_dp,
+                                                                       const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                       const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT_LDS_WORDS + 1];
+    const int b = blockIdx.x;
+    if (b < cl.in_blocks) {
+        if (b < cl.in_real) ks_ext_body<false>(sm, b, state, tmp, kg, cl.in, desc, E, Ed, psi_br, psi_dp, ql, qh, kl, kh);
+    } else {
+        ks_ext_body<true>(sm, b - cl.in_blocks, state, tmp, kg, cl.dp, desc, E, Ed, psi_br, psi_dp, ql, qh, kl, kh);
     }
 }
 
@@ -249,12 +275,18 @@ int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64
     classify_rows(rows, q_host, dp, in);
     const unsigned tiles = 1u << (logN - tl);
 
+    const bool mixed = dp.n && in.n && mixed_enabled();   // both arithmetic classes in one launch per step
     // K2: extend + strided pass
-    if (dp.n)
+    if (mixed) {
+        const ClassLists cl = class_lists(in, dp, tiles * in.n * nparts);
+        hipLaunchKernelGGL(ks_ext_pass1_mixed, dim3((unsigned)cl.in_blocks + tiles * dp.n * nparts), dim3(NTT_THREADS), 0, st,
+                           (const i64 *)state, (i64 *)tmp, kg, cl, (const i64 *)desc, (const i64 *)E, Ed, (const i64 *)psi_br,
+                           psi_dp, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+    } else if (dp.n)
         hipLaunchKernelGGL(ks_ext_pass1<true>, dim3(tiles * dp.n * nparts), dim3(NTT_THREADS), 0, st, (const i64 *)state,
                            (i64 *)tmp, kg, dp, (const i64 *)desc, (const i64 *)E, Ed, (const i64 *)psi_br, psi_dp,
                            (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
-    if (in.n)
+    if (in.n && !mixed)
         hipLaunchKernelGGL(ks_ext_pass1<false>, dim3(tiles * in.n * nparts), dim3(NTT_THREADS), 0, st, (const i64 *)state,
                            (i64 *)tmp, kg, in, (const i64 *)desc, (const i64 *)E, Ed, (const i64 *)psi_br, psi_dp,
                            (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
@@ -262,11 +294,16 @@ int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64
     {
         const PassGeom g{logN, tl, 0, tl, S1, 0, rows, nparts, 1, 1, 0, 1, 0};
         const unsigned per_row = (unsigned)nparts << (logN - tl);
-        if (dp.n)
+        if (mixed) {
+            const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
+            hipLaunchKernelGGL(ntt_fwd_pass_mixed, dim3((unsigned)cl.in_blocks + per_row * dp.n), dim3(NTT_THREADS), 0, st,
+                               (i64 *)tmp, g, cl, (const i64 *)psi_br, psi_dp, (const i64 *)nullptr, (const i64 *)ql,
+                               (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+        } else if (dp.n)
             hipLaunchKernelGGL(ntt_fwd_pass<true>, dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, (i64 *)tmp, g, dp,
                                (const i64 *)psi_br, psi_dp, (const i64 *)nullptr, (const i64 *)ql, (const i64 *)qh,
                                (const i64 *)kl, (const i64 *)kh);
-        if (in.n)
+        if (in.n && !mixed)
             hipLaunchKernelGGL(ntt_fwd_pass<false>, dim3(per_row * in.n), dim3(NTT_THREADS), 0, st, (i64 *)tmp, g, in,
                                (const i64 *)psi_br, psi_dp, (const i64 *)nullptr, (const i64 *)ql, (const i64 *)qh,
                                (const i64 *)kl, (const i64 *)kh);
@@ -285,12 +322,24 @@ int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64
         PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, 2, 1, 0, 0, 1, 0}
                                : PassGeom{logN, tl, 1, S1, tl, tl - S1, rows, 2, 1, 1, 0, 1, 0};
         if (pass == 1 && S1 <= 4 && cols_enabled()) {
+            if (mixed) {
+                launch_inv_cols_mixed(S1, 2, st, (i64 *)s, g, in, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,
+                                      (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+                continue;
+            }
             if (dp.n)
                 launch_inv_cols<true>(S1, 2, st, (i64 *)s, g, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,
                                       (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
             if (in.n)
                 launch_inv_cols<false>(S1, 2, st, (i64 *)s, g, in, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,
                                        (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+            continue;
+        }
+        if (mixed) {
+            const ClassLists cl = class_lists(in, dp, per_row2 * (unsigned)in.n);
+            hipLaunchKernelGGL(ntt_inv_pass_mixed, dim3((unsigned)cl.in_blocks + per_row2 * dp.n), dim3(NTT_THREADS), 0, st,
+                               (const i64 *)s, (i64 *)s, g, cl, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv,
+                               pass == 1 ? 2 : TAIL_NONE, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
             continue;
         }
         if (dp.n)

@@ -105,6 +105,27 @@ void launch_cols(int K, unsigned blocks, hipStream_t st, i64 *base, const PassGe
 #undef LF_COLS_CASE
 }
 
+template <int K>
+void launch_cols_mixed_k(unsigned blocks, hipStream_t st, i64 *base, const PassGeom &g, const ClassLists &cl,
+                         const int64_t *psi_br, const double *psi_dp, const i64 *rs, const int64_t *ql, const int64_t *qh,
+                         const int64_t *kl, const int64_t *kh) {
+    hipLaunchKernelGGL((ntt_fwd_cols_mixed<K>), dim3(blocks), dim3(NTT_COL_THREADS), 0, st, base, g, cl, (const i64 *)psi_br,
+                       psi_dp, rs, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+}
+
+void launch_cols_mixed(int K, unsigned per_limb, hipStream_t st, i64 *base, const PassGeom &g, const RowList &in,
+                       const RowList &dp, const int64_t *psi_br, const double *psi_dp, const i64 *rs, const int64_t *ql,
+                       const int64_t *qh, const int64_t *kl, const int64_t *kh) {
+    const ClassLists cl = class_lists(in, dp, per_limb * (unsigned)in.n);
+    const unsigned blocks = (unsigned)cl.in_blocks + per_limb * (unsigned)dp.n;
+    switch (K) {
+        case 1: launch_cols_mixed_k<1>(blocks, st, base, g, cl, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+        case 2: launch_cols_mixed_k<2>(blocks, st, base, g, cl, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+        case 3: launch_cols_mixed_k<3>(blocks, st, base, g, cl, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+        case 4: launch_cols_mixed_k<4>(blocks, st, base, g, cl, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -134,7 +155,8 @@ int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, con
     RowList dp, in;
     classify(rows, q_host, psi_dp, dp, in);
     hipStream_t st = (hipStream_t)stream;
-    SideStream *side = (dp.n && in.n) ? side_stream(device) : nullptr;
+    const bool mixed = dp.n && in.n && mixed_enabled();   // both classes in one launch per pass
+    SideStream *side = (dp.n && in.n && !mixed) ? side_stream(device) : nullptr;
     hipStream_t st_int = side ? side->stream : st;
     if (side) {
         (void)hipEventRecord(side->fork, st);
@@ -156,8 +178,19 @@ int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, con
             const i64 *rs = (pass == 0 || S1 == 0) ? (const i64 *)Rs : nullptr;
             if (pass == 0 && S1 <= 4 && cols_enabled()) {   // leading stages: one register step per column
                 const unsigned col_blocks = (unsigned)nb * ((1u << (logN - S1)) / NTT_COL_THREADS);
+                if (mixed) {
+                    launch_cols_mixed(S1, col_blocks, st, base, g, in, dp, psi_br, psi_dp, rs, ql, qh, kl, kh);
+                    continue;
+                }
                 if (dp.n) launch_cols<true>(S1, col_blocks * dp.n, st, base, g, dp, psi_br, psi_dp, rs, ql, qh, kl, kh);
                 if (in.n) launch_cols<false>(S1, col_blocks * in.n, st_int, base, g, in, psi_br, psi_dp, rs, ql, qh, kl, kh);
+                continue;
+            }
+            if (mixed) {
+                const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
+                hipLaunchKernelGGL(ntt_fwd_pass_mixed, dim3((unsigned)cl.in_blocks + per_row * dp.n), dim3(NTT_THREADS), 0, st,
+                                   base, g, cl, (const i64 *)psi_br, psi_dp, rs, (const i64 *)ql, (const i64 *)qh,
+                                   (const i64 *)kl, (const i64 *)kh);
                 continue;
             }
             if (dp.n)
@@ -193,7 +226,8 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
     RowList dp, in;
     classify(rows, q_host, ipsi_dp, dp, in);
     hipStream_t st = (hipStream_t)stream;
-    SideStream *side = (dp.n && in.n) ? side_stream(device) : nullptr;
+    const bool mixed = dp.n && in.n && mixed_enabled();   // both classes in one launch per pass
+    SideStream *side = (dp.n && in.n && !mixed) ? side_stream(device) : nullptr;
     hipStream_t st_int = side ? side->stream : st;
     if (side) {
         (void)hipEventRecord(side->fork, st);
@@ -209,12 +243,24 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
                                          : PassGeom{logN, tl, 1, SB, tl, tl - SB, rows, nb, relaxed, 1, plain, 1, 0};
             const int t = g.last ? tail : TAIL_NONE;
             if (pass == 1 && SB <= 4 && cols_enabled()) {   // trailing stages + chain tail: one register step per column
+                if (mixed) {
+                    launch_inv_cols_mixed(SB, nb, st, base, g, in, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t,
+                                          (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+                    continue;
+                }
                 if (dp.n)
                     launch_inv_cols<true>(SB, nb, st, base, g, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t,
                                           (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
                 if (in.n)
                     launch_inv_cols<false>(SB, nb, st_int, base, g, in, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t,
                                            (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+                continue;
+            }
+            if (mixed) {
+                const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
+                hipLaunchKernelGGL(ntt_inv_pass_mixed, dim3((unsigned)cl.in_blocks + per_row * dp.n), dim3(NTT_THREADS), 0, st,
+                                   (const i64 *)base, base, g, cl, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t,
+                                   (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
                 continue;
             }
             if (dp.n)

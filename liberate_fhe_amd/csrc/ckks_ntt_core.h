@@ -67,10 +67,9 @@ __device__ __forceinline__ int tile_gaddr(const PassGeom &g, int tile, int L) {
 
 // block id -> (polynomial, limb, tile): the `batch` polynomials of one (limb, tile) pair are
 // consecutive on one XCD (block b runs on XCD b % 8) so they share the pair's twiddles in that L2.
-__device__ __forceinline__ void block_coords(const PassGeom &g, const RowList &rl, int &poly, int &limb, int &tile) {
+__device__ __forceinline__ void block_coords(const PassGeom &g, const RowList &rl, int b, int &poly, int &limb, int &tile) {
     const int tiles = 1 << (g.logN - g.tl);
     const int pairs = rl.n * tiles;
-    const int b = blockIdx.x;
     int pair;
     if ((pairs & 7) == 0) {
         const int x = b & 7, r = b >> 3;
@@ -577,12 +576,11 @@ __device__ __forceinline__ void store_tile_raw(const i64 *sm, i64 *row, const Pa
 // forward pass.  DP = true: fp64 class rows; false: integer class rows.
 // ------------------------------------------------------------------------------------------------
 template <bool DP>
-__global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_fwd_pass(i64 *__restrict__ a, PassGeom g, RowList rl,
-                                                            const i64 *__restrict__ psi_br, const double *__restrict__ psi_dp,
-                                                            const i64 *__restrict__ Rs, const i64 *__restrict__ ql,
-                                                            const i64 *__restrict__ qh, const i64 *__restrict__ kl,
-                                                            const i64 *__restrict__ kh) {
-    __shared__ i64 sm[NTT_LDS_WORDS + 1];
+__device__ __forceinline__ void fwd_pass_body(i64 *sm, int b, i64 *__restrict__ a, const PassGeom &g, const RowList &rl,
+                                              const i64 *__restrict__ psi_br, const double *__restrict__ psi_dp,
+                                              const i64 *__restrict__ Rs, const i64 *__restrict__ ql,
+                                              const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                              const i64 *__restrict__ kh) {
     const int T = 1 << g.tl;
     const bool enter = (Rs != nullptr) && !(DP && g.plain);
     // persistent block: a contiguous run of work items; the next tile's global loads are in flight
@@ -591,7 +589,7 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_fwd_pass(i64 *__r
     lds_barrier();
     longlong2 pre[NTT_PRE];
     int poly, crow, tile;
-    block_coords(g, rl, poly, crow, tile);
+    block_coords(g, rl, b, poly, crow, tile);
     prefetch_tile(pre, a + ((i64)(poly * g.rows + crow) << g.logN), g, tile);
 
     {
@@ -660,6 +658,40 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_fwd_pass(i64 *__r
     }
 }
 
+template <bool DP>
+__global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_fwd_pass(i64 *__restrict__ a, PassGeom g, RowList rl,
+                                                            const i64 *__restrict__ psi_br, const double *__restrict__ psi_dp,
+                                                            const i64 *__restrict__ Rs, const i64 *__restrict__ ql,
+                                                            const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                                            const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT_LDS_WORDS + 1];
+    fwd_pass_body<DP>(sm, blockIdx.x, a, g, rl, psi_br, psi_dp, Rs, ql, qh, kl, kh);
+}
+
+// Both arithmetic classes of one pass in ONE launch: the first `in_blocks` blocks (a multiple of 8, so the
+// XCD alignment of the rest is unchanged) work on the integer-class limbs, the others on the fp64 class.
+// The few, long integer-class blocks start first; no side stream, no fork / join events, half the launches.
+struct ClassLists {
+    RowList in, dp;
+    int in_blocks;      // padded to a multiple of 8; blocks in [in_real, in_blocks) exit
+    int in_real;
+};
+
+__global__ void __launch_bounds__(NTT_THREADS, 6) ntt_fwd_pass_mixed(i64 *__restrict__ a, PassGeom g, ClassLists cl,
+                                                                       const i64 *__restrict__ psi_br,
+                                                                       const double *__restrict__ psi_dp,
+                                                                       const i64 *__restrict__ Rs, const i64 *__restrict__ ql,
+                                                                       const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                                                       const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT_LDS_WORDS + 1];
+    const int b = blockIdx.x;
+    if (b < cl.in_blocks) {
+        if (b < cl.in_real) fwd_pass_body<false>(sm, b, a, g, cl.in, psi_br, psi_dp, Rs, ql, qh, kl, kh);
+    } else {
+        fwd_pass_body<true>(sm, b - cl.in_blocks, a, g, cl.dp, psi_br, psi_dp, Rs, ql, qh, kl, kh);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward STRIDED pass as one radix-2^K register step straight from global memory (two-pass transforms
 // with K = logN - 12 <= 4 leading stages).  Thread = one column: its 2^K words sit N/2^K apart, so a wave's
@@ -688,15 +720,14 @@ __device__ __forceinline__ void cols_fwd_stages(typename A::T (&x)[1 << K], cons
 }
 
 template <bool DP, int K>
-__global__ void __launch_bounds__(NTT_COL_THREADS) ntt_fwd_cols(i64 *__restrict__ a, PassGeom g, RowList rl,
-                                                               const i64 *__restrict__ psi_br,
-                                                               const double *__restrict__ psi_dp, const i64 *__restrict__ Rs,
-                                                               const i64 *__restrict__ ql, const i64 *__restrict__ qh,
-                                                               const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+__device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const PassGeom &g, const RowList &rl,
+                                              const i64 *__restrict__ psi_br, const double *__restrict__ psi_dp,
+                                              const i64 *__restrict__ Rs, const i64 *__restrict__ ql,
+                                              const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                              const i64 *__restrict__ kh) {
     constexpr int R = 1 << K;
     const int logC = g.logN - K;
     const int chunks = (1 << logC) / NTT_COL_THREADS;
-    const int b = blockIdx.x;
     const int chunk = b % chunks, r = b / chunks;
     const int poly = r % g.batch, crow = rl.id[r / g.batch];
     const bool enter = (Rs != nullptr) && !(DP && g.plain);
@@ -754,22 +785,45 @@ __global__ void __launch_bounds__(NTT_COL_THREADS) ntt_fwd_cols(i64 *__restrict_
     }
 }
 
+template <bool DP, int K>
+__global__ void __launch_bounds__(NTT_COL_THREADS) ntt_fwd_cols(i64 *__restrict__ a, PassGeom g, RowList rl,
+                                                               const i64 *__restrict__ psi_br,
+                                                               const double *__restrict__ psi_dp, const i64 *__restrict__ Rs,
+                                                               const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                               const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    fwd_cols_body<DP, K>(blockIdx.x, a, g, rl, psi_br, psi_dp, Rs, ql, qh, kl, kh);
+}
+
+template <int K>
+__global__ void __launch_bounds__(NTT_COL_THREADS) ntt_fwd_cols_mixed(i64 *__restrict__ a, PassGeom g, ClassLists cl,
+                                                                     const i64 *__restrict__ psi_br,
+                                                                     const double *__restrict__ psi_dp,
+                                                                     const i64 *__restrict__ Rs, const i64 *__restrict__ ql,
+                                                                     const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                                                     const i64 *__restrict__ kh) {
+    const int b = blockIdx.x;
+    if (b < cl.in_blocks) {
+        if (b < cl.in_real) fwd_cols_body<false, K>(b, a, g, cl.in, psi_br, psi_dp, Rs, ql, qh, kl, kh);
+    } else {
+        fwd_cols_body<true, K>(b - cl.in_blocks, a, g, cl.dp, psi_br, psi_dp, Rs, ql, qh, kl, kh);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // inverse pass (+ fused chain tail on the last pass)
 // ------------------------------------------------------------------------------------------------
 template <bool DP>
-__global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_inv_pass_io(const i64 *src, i64 *dst, PassGeom g, RowList rl,
-                                                            const i64 *__restrict__ ipsi_br,
-                                                            const double *__restrict__ ipsi_dp, const i64 *__restrict__ Ninv,
-                                                            int tail, const i64 *__restrict__ ql, const i64 *__restrict__ qh,
-                                                            const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
-    __shared__ i64 sm[NTT_LDS_WORDS + 1];
+__device__ __forceinline__ void inv_pass_body(i64 *sm, int b, const i64 *src, i64 *dst, const PassGeom &g, const RowList &rl,
+                                              const i64 *__restrict__ ipsi_br, const double *__restrict__ ipsi_dp,
+                                              const i64 *__restrict__ Ninv, int tail, const i64 *__restrict__ ql,
+                                              const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                              const i64 *__restrict__ kh) {
     const int T = 1 << g.tl;
     if (threadIdx.x == 0) sm[NTT_FLAG_WORD] = 0;   // both block_or flag words
     lds_barrier();
     longlong2 pre[NTT_PRE];
     int poly, crow, tile;
-    block_coords(g, rl, poly, crow, tile);
+    block_coords(g, rl, b, poly, crow, tile);
     prefetch_tile(pre, src + ((i64)(poly * g.rows + crow) << g.logN), g, tile);
 
     {
@@ -854,6 +908,31 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_inv_pass_io(const
     }
 }
 
+template <bool DP>
+__global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_inv_pass_io(const i64 *src, i64 *dst, PassGeom g, RowList rl,
+                                                            const i64 *__restrict__ ipsi_br,
+                                                            const double *__restrict__ ipsi_dp, const i64 *__restrict__ Ninv,
+                                                            int tail, const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                            const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT_LDS_WORDS + 1];
+    inv_pass_body<DP>(sm, blockIdx.x, src, dst, g, rl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh);
+}
+
+__global__ void __launch_bounds__(NTT_THREADS, 6) ntt_inv_pass_mixed(const i64 *src, i64 *dst, PassGeom g, ClassLists cl,
+                                                                       const i64 *__restrict__ ipsi_br,
+                                                                       const double *__restrict__ ipsi_dp,
+                                                                       const i64 *__restrict__ Ninv, int tail,
+                                                                       const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                       const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT_LDS_WORDS + 1];
+    const int b = blockIdx.x;
+    if (b < cl.in_blocks) {
+        if (b < cl.in_real) inv_pass_body<false>(sm, b, src, dst, g, cl.in, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh);
+    } else {
+        inv_pass_body<true>(sm, b - cl.in_blocks, src, dst, g, cl.dp, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // inverse STRIDED (last) pass as one radix-2^K register step per column, chain tail included: the mirror
 // image of ntt_fwd_cols.  Stage u of the step uses the table entries 2^(K-1-u) .. 2^(K-u) - 1.
@@ -886,15 +965,14 @@ __device__ __forceinline__ i64 inv_tail_int(i64 t, int tail, i64 ninv, const Ctx
 }
 
 template <bool DP, int K>
-__global__ void __launch_bounds__(NTT_COL_THREADS) ntt_inv_cols(i64 *__restrict__ a, PassGeom g, RowList rl,
-                                                               const i64 *__restrict__ ipsi_br,
-                                                               const double *__restrict__ ipsi_dp, const i64 *__restrict__ Ninv,
-                                                               int tail, const i64 *__restrict__ ql, const i64 *__restrict__ qh,
-                                                               const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+__device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const PassGeom &g, const RowList &rl,
+                                              const i64 *__restrict__ ipsi_br, const double *__restrict__ ipsi_dp,
+                                              const i64 *__restrict__ Ninv, int tail, const i64 *__restrict__ ql,
+                                              const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                              const i64 *__restrict__ kh) {
     constexpr int R = 1 << K;
     const int logC = g.logN - K;
     const int chunks = (1 << logC) / NTT_COL_THREADS;
-    const int b = blockIdx.x;
     const int chunk = b % chunks, r = b / chunks;
     const int poly = r % g.batch, crow = rl.id[r / g.batch];
     Ctx c;
@@ -952,6 +1030,30 @@ __global__ void __launch_bounds__(NTT_COL_THREADS) ntt_inv_cols(i64 *__restrict_
     }
 }
 
+template <bool DP, int K>
+__global__ void __launch_bounds__(NTT_COL_THREADS) ntt_inv_cols(i64 *__restrict__ a, PassGeom g, RowList rl,
+                                                               const i64 *__restrict__ ipsi_br,
+                                                               const double *__restrict__ ipsi_dp, const i64 *__restrict__ Ninv,
+                                                               int tail, const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                               const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    inv_cols_body<DP, K>(blockIdx.x, a, g, rl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh);
+}
+
+template <int K>
+__global__ void __launch_bounds__(NTT_COL_THREADS) ntt_inv_cols_mixed(i64 *__restrict__ a, PassGeom g, ClassLists cl,
+                                                                     const i64 *__restrict__ ipsi_br,
+                                                                     const double *__restrict__ ipsi_dp,
+                                                                     const i64 *__restrict__ Ninv, int tail,
+                                                                     const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                     const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    const int b = blockIdx.x;
+    if (b < cl.in_blocks) {
+        if (b < cl.in_real) inv_cols_body<false, K>(b, a, g, cl.in, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh);
+    } else {
+        inv_cols_body<true, K>(b - cl.in_blocks, a, g, cl.dp, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh);
+    }
+}
+
 // host: launch of the inverse column pass for one arithmetic class (K = number of trailing stages, 1..4)
 template <bool DP>
 inline void launch_inv_cols(int K, int polys, hipStream_t st, i64 *base, const PassGeom &g, const RowList &rl,
@@ -970,6 +1072,48 @@ inline void launch_inv_cols(int K, int polys, hipStream_t st, i64 *base, const P
         LF_ICOLS_CASE(4)
     }
 #undef LF_ICOLS_CASE
+}
+
+// experiment knob: LF_NTT_MIXED=0 launches the two arithmetic classes separately (integer class on a side stream)
+inline bool mixed_enabled() {
+    static int on = -1;
+    if (on < 0) {
+        const char *e = getenv("LF_NTT_MIXED");
+        on = e ? atoi(e) != 0 : 1;
+    }
+    return on != 0;
+}
+
+inline ClassLists class_lists(const RowList &in, const RowList &dp, unsigned in_blocks) {
+    ClassLists cl;
+    cl.in = in;
+    cl.dp = dp;
+    cl.in_real = (int)in_blocks;
+    cl.in_blocks = (int)((in_blocks + 7u) & ~7u);
+    return cl;
+}
+
+template <int K>
+inline void launch_inv_cols_mixed_k(unsigned blocks, hipStream_t st, i64 *base, const PassGeom &g, const ClassLists &cl,
+                                    const i64 *ipsi_br, const double *ipsi_dp, const i64 *Ninv, int tail, const i64 *ql,
+                                    const i64 *qh, const i64 *kl, const i64 *kh) {
+    hipLaunchKernelGGL((ntt_inv_cols_mixed<K>), dim3(blocks), dim3(NTT_COL_THREADS), 0, st, base, g, cl, ipsi_br, ipsi_dp, Ninv,
+                       tail, ql, qh, kl, kh);
+}
+
+// host: inverse column pass, both classes in one launch
+inline void launch_inv_cols_mixed(int K, int polys, hipStream_t st, i64 *base, const PassGeom &g, const RowList &in,
+                                  const RowList &dp, const i64 *ipsi_br, const double *ipsi_dp, const i64 *Ninv, int tail,
+                                  const i64 *ql, const i64 *qh, const i64 *kl, const i64 *kh) {
+    const unsigned per_limb = (unsigned)polys * ((1u << (g.logN - K)) / NTT_COL_THREADS);
+    const ClassLists cl = class_lists(in, dp, per_limb * (unsigned)in.n);
+    const unsigned blocks = (unsigned)cl.in_blocks + per_limb * (unsigned)dp.n;
+    switch (K) {
+        case 1: launch_inv_cols_mixed_k<1>(blocks, st, base, g, cl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh); break;
+        case 2: launch_inv_cols_mixed_k<2>(blocks, st, base, g, cl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh); break;
+        case 3: launch_inv_cols_mixed_k<3>(blocks, st, base, g, cl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh); break;
+        case 4: launch_inv_cols_mixed_k<4>(blocks, st, base, g, cl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh); break;
+    }
 }
 
 // experiment knob: LF_NTT_COLS=0 falls back to the LDS-tiled strided passes
