@@ -11,7 +11,7 @@ Infinity Cache.  Inputs are synthetic (splitmix64 -> mod 2q), resident in HBM be
 Polynomials are independent, so ranks shard them with no data-path collective: weak scaling.
 
 The JSON line also carries
-  roofline     : the dominant kernel (ntt_fwd_pass<true>: the fp64-class tiled pass, the second of the two
+  roofline     : the dominant kernel (ntt_fwd_pass_mixed: the tiled pass of all 30 limbs, the second of the two
                  launches of a transform, 12 of its 16 stages) against the 8 TB/s HBM peak; algorithmic bytes
                  per launch = 8*N*limbs (a transform is 16*N bytes per limb, SURVEY.md §8d, spread over its two
                  launches); its launch duration is measured live with HIP events on the launch stream, the
@@ -223,40 +223,32 @@ def main():
 
     value = world * B / (wall / args.steps)                         # poly-NTT(30)/s, whole job
 
-    # Roofline of the dominant kernel, ntt_fwd_pass<true> (the fp64-class tiled pass: 25 of the 30 limbs, 12 of
-    # the 16 stages).  In the step above it overlaps the integer-class launches on a side stream and follows the
-    # column pass, so it is timed on its own here: lf_ntt on the stack of the 25 fp64-class limbs with
-    # LF_NTT_ONLY_PASS=2 launches exactly that kernel, once, with the grid it has inside the full step.
-    dp_idx = [i for i in rows_idx if ctx.q[i] < (1 << 41)]
-    sel = torch.tensor([i - lo for i in dp_idx], device=dev)
-    xd = x[:, [i - lo for i in dp_idx], :].contiguous()
-    cdp = [t.index_select(0, sel).contiguous() for t in (psi, q2, ql, qh, kl, kh)]
-    dp_tab = twiddles.dp_pointer(cdp[0], cdp[2], cdp[3], cdp[4], cdp[5], local_rank, stream)
-    q_dp = np.array([ctx.q[i] for i in dp_idx], dtype=np.int64)
-
-    def dp_step():
-        check(lib.lf_ntt(xd.data_ptr(), B, len(dp_idx), LOGN, cdp[0].data_ptr(), dp_tab, q_dp.ctypes.data, 0, 0,
-                         cdp[1].data_ptr(), cdp[2].data_ptr(), cdp[3].data_ptr(), cdp[4].data_ptr(), cdp[5].data_ptr(),
-                         local_rank, stream), "lf_ntt")
-    for _ in range(max(3, args.warmup // 2)):
-        dp_step()
-    torch.cuda.synchronize()
+    # Roofline of the dominant kernel, ntt_fwd_pass_mixed: the tiled pass (12 of the 16 stages) of all 30 limbs,
+    # integer-class blocks first, then the fp64 class.  In the step above it follows the column pass, so it is
+    # timed on its own here: the same lf_ntt call with LF_NTT_ONLY_PASS=2 launches exactly that kernel, once,
+    # with the grid it has inside the full step.  (The result of such a call is not a transform; x is scratch.)
     n_roof = max(10, args.steps // 2)
-    transform_ms = event_time_ms(dp_step, n_roof)                   # both launches (column pass + tiled pass)
     os.environ["LF_NTT_ONLY_PASS"] = "2"
     try:
-        dp_step()
+        for _ in range(3):
+            step()
         torch.cuda.synchronize()
-        launches = 1
-        k_ms = event_time_ms(dp_step, n_roof)
+        k_ms = event_time_ms(step, n_roof)
     finally:
         del os.environ["LF_NTT_ONLY_PASS"]
-    alg_bytes_per_launch = 8 * N * len(dp_idx) * B                  # 16*N per limb per transform, two launches
+    os.environ["LF_NTT_ONLY_PASS"] = "1"
+    try:
+        step()
+        torch.cuda.synchronize()
+        cols_ms = event_time_ms(step, n_roof)
+    finally:
+        del os.environ["LF_NTT_ONLY_PASS"]
+    alg_bytes_per_launch = 8 * N * L_LIMBS * B                      # 16*N per limb per transform, two launches
     achieved = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
     if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("ntt_fwd_pass_dp_bytes_per_launch")
+        traffic = json.load(open(tpath)).get("ntt_fwd_pass_mixed_bytes_per_launch")
 
     result = {
         "metric": "NTTs/sec (forward negacyclic poly-NTT, logN=16, L=30 limbs, bit-exact vs reference semantics)",
@@ -268,10 +260,10 @@ def main():
                    "batch_per_gpu": B, "limbs": L_LIMBS, "logN": LOGN, "parallelism": f"replicas x{world} (independent polynomials)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "ntt_fwd_pass<true> (fp64 class, 25 of the 30 limbs; tiled pass = 12 of 16 stages)",
-                     "launches_per_transform": 2, "avg_launch_ms": k_ms, "launches_timed": launches * n_roof,
-                     "fp64_class_transform_ms": transform_ms,
-                     "fp64_class_transform_algorithmic_GBps": 2 * alg_bytes_per_launch / (transform_ms * 1e-3) / 1e9,
+                     "kernel": "ntt_fwd_pass_mixed (tiled pass = 12 of 16 stages, all 30 limbs: 5 integer-class + 25 fp64-class)",
+                     "launches_per_transform": 2, "avg_launch_ms": k_ms, "launches_timed": n_roof,
+                     "column_pass_launch_ms": cols_ms,
+                     "column_pass_algorithmic_GBps": alg_bytes_per_launch / (cols_ms * 1e-3) / 1e9,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                      "whole_step_algorithmic_GBps": 16 * N * L_LIMBS * B / (dev_ms * 1e-3) / 1e9},
     }

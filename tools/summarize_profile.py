@@ -37,11 +37,13 @@ except Exception:
     n_last = 0
 if n_last:
     rows = q(os.path.join(src, f"prof_{tag}", "stats_results.db"),
-             "select duration from kernels where name like '%ntt_fwd_pass<true>%' order by dispatch_id")
+             "select duration from kernels where name like '%ntt_fwd_pass_mixed%' order by dispatch_id")
     durs = [r[0] / 1e3 for r in rows]
     if len(durs) >= n_last:
         tail = durs[-n_last:]
-        lines += ["", f"# ntt_fwd_pass<true>, roofline leg only (last {n_last} dispatches: the kernel alone on the GPU, "
+        # bench.py's roofline leg: 3 warm-up + n_last timed launches of the tiled pass alone, then 1 + n_last
+        # launches of the column pass (a different kernel): the tiled-pass kernel's last n_last dispatches are the timed ones
+        lines += ["", f"# ntt_fwd_pass_mixed, roofline leg only (last {n_last} dispatches: the kernel alone on the GPU, "
                       f"LF_NTT_ONLY_PASS=2): avg {sum(tail) / len(tail):.2f} us, min {min(tail):.2f}, max {max(tail):.2f}",
                   f"# bench.py reported avg_launch_ms = {bench['roofline']['avg_launch_ms'] * 1e3:.2f} us from HIP events (un-profiled run)"]
 open(os.path.join(out_dir, f"{tag}_bench_kernel_stats.txt"), "w").write("\n".join(lines) + "\n")
@@ -60,25 +62,25 @@ for counter, sub, stem in (("FETCH_SIZE", f"pmc_fetch_{tag}", "fetch"), ("WRITE_
                  "from counters_collection group by kernel_name")
     for r in rows:
         pm.append(f"{counter:10s} | {r[0][:70]:70s} | n={r[2]:4d} | avg={r[3]:12.1f} | min={r[4]:12.1f} | max={r[5]:12.1f} | avg_ns={r[6]:10.0f}")
-    disp = q(db, "select dispatch_id, value, duration from counters_collection where kernel_name like '%ntt_fwd_pass<true>%' order by dispatch_id")
+    disp = q(db, "select dispatch_id, value, duration from counters_collection where kernel_name like '%ntt_fwd_pass_mixed%' order by dispatch_id")
     per[counter] = disp
-    per[counter + "_cols"] = q(db, "select dispatch_id, value, duration from counters_collection where kernel_name like '%ntt_fwd_cols<true%' order by dispatch_id")
+    per[counter + "_cols"] = q(db, "select dispatch_id, value, duration from counters_collection where kernel_name like '%ntt_fwd_cols_mixed%' order by dispatch_id")
     pm.append("")
-pm.append("# ntt_fwd_pass<true> (fp64 class, 25 limbs x 16 polynomials): the tiled pass (12 stages + twiddles), one dispatch per transform")
+pm.append("# ntt_fwd_pass_mixed (30 limbs x 16 polynomials): the tiled pass (12 stages + twiddles), one dispatch per transform")
 for (d, v, ns), (_, w, _) in zip(per["FETCH_SIZE"], per["WRITE_SIZE"]):
     pm.append(f"dispatch {d}: FETCH_SIZE={v:10.1f} KiB -> {2 * v * 1024 / 1e6:7.1f} MB read (corrected) | WRITE_SIZE={w:10.1f} KiB -> {w * 1024 / 1e6:7.1f} MB | {ns / 1e3:7.1f} us")
-pm.append("# ntt_fwd_cols<true, 4> (same limbs): the column pass (4 leading stages), one dispatch per transform")
+pm.append("# ntt_fwd_cols_mixed<4> (same limbs): the column pass (4 leading stages), one dispatch per transform")
 for (d, v, ns), (_, w, _) in zip(per["FETCH_SIZE_cols"], per["WRITE_SIZE_cols"]):
     pm.append(f"dispatch {d}: FETCH_SIZE={v:10.1f} KiB -> {2 * v * 1024 / 1e6:7.1f} MB read (corrected) | WRITE_SIZE={w:10.1f} KiB -> {w * 1024 / 1e6:7.1f} MB | {ns / 1e3:7.1f} us")
 open(os.path.join(out_dir, f"{tag}_bench_pmc_hbm.txt"), "w").write("\n".join(pm) + "\n")
 
 fetch = sum(v for _, v, _ in per["FETCH_SIZE"]) / len(per["FETCH_SIZE"])
 write = sum(v for _, v, _ in per["WRITE_SIZE"]) / len(per["WRITE_SIZE"])
-traffic = {"ntt_fwd_pass_dp_bytes_per_launch": (2 * fetch + write) * 1024,
+traffic = {"ntt_fwd_pass_mixed_bytes_per_launch": (2 * fetch + write) * 1024,
            "fetch_kib_avg_raw": fetch, "write_kib_avg": write,
-           "note": "ntt_fwd_pass<true> (tiled pass) per launch; FETCH_SIZE doubled per the gfx950 1/2-count caveat"}
+           "note": "ntt_fwd_pass_mixed (tiled pass, 30 limbs x 16 polynomials) per launch; FETCH_SIZE doubled per the gfx950 1/2-count caveat"}
 cf, cw = per["FETCH_SIZE_cols"], per["WRITE_SIZE_cols"]
 if cf and cw:
-    traffic["ntt_fwd_cols_dp_bytes_per_launch"] = (2 * sum(v for _, v, _ in cf) / len(cf) + sum(v for _, v, _ in cw) / len(cw)) * 1024
+    traffic["ntt_fwd_cols_mixed_bytes_per_launch"] = (2 * sum(v for _, v, _ in cf) / len(cf) + sum(v for _, v, _ in cw) / len(cw)) * 1024
 json.dump(traffic, open(os.path.join(out_dir, f"traffic_{tag}.json"), "w"), indent=1)
 print(traffic)
