@@ -185,6 +185,15 @@ int lf_ks_moddown_batch(const int64_t *const *s, int64_t *const *out, const int6
 int lf_galois_batch(const int64_t *const *a, int64_t *const *dst, int count, int rows, int logN, int64_t p,
                     const int64_t *_2q, int device, void *stream);
 
+/* cc_mult's opening (ckks_engine.py:1085-1093): rescale `count` (<= 8) polynomials and transform them, i.e.
+ * lf_rescale_batch(in, row0, {x + i*rows*N}, ...) followed by lf_ntt(x, count, ...) with the same constants.
+ * For two-pass ring degrees (logN 13..16) the rescale is evaluated inside the first NTT pass: no launch and no
+ * trip through HBM of its own; other degrees run the two steps one after the other.  Same results either way. */
+int lf_rescale_ntt(const int64_t *const *in, const int64_t *const *row0, int count, int64_t *x, int rows, int logN,
+                   const int64_t *scales, int64_t round_at, const int64_t *psi_br, const double *psi_dp,
+                   const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *_2q, const int64_t *ql,
+                   const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Samplers: the reference's csprng extensions, src/liberate/csprng/.
  * A ChaCha20 state is 16 int64 words holding 32-bit values (csprng.py:124-160); words 12/13 are

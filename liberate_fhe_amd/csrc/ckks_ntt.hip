@@ -126,6 +126,32 @@ void launch_cols_mixed(int K, unsigned per_limb, hipStream_t st, i64 *base, cons
     }
 }
 
+template <int K>
+void launch_cols_mixed_rs_k(unsigned blocks, hipStream_t st, i64 *base, const PassGeom &g, const ClassLists &cl,
+                            const RescaleSrc &rsrc, const int64_t *psi_br, const double *psi_dp, const i64 *rs,
+                            const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh) {
+    hipLaunchKernelGGL((ntt_fwd_cols_mixed_rs<K>), dim3(blocks), dim3(NTT_COL_THREADS), 0, st, base, g, cl, rsrc,
+                       (const i64 *)psi_br, psi_dp, rs, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+}
+
+void launch_cols_mixed_rs(int K, unsigned per_limb, hipStream_t st, i64 *base, const PassGeom &g, const RowList &in,
+                          const RowList &dp, const RescaleSrc &rsrc, const int64_t *psi_br, const double *psi_dp,
+                          const i64 *rs, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh) {
+    const ClassLists cl = class_lists(in, dp, per_limb * (unsigned)in.n);
+    const unsigned blocks = (unsigned)cl.in_blocks + per_limb * (unsigned)dp.n;
+    switch (K) {
+        case 1: launch_cols_mixed_rs_k<1>(blocks, st, base, g, cl, rsrc, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+        case 2: launch_cols_mixed_rs_k<2>(blocks, st, base, g, cl, rsrc, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+        case 3: launch_cols_mixed_rs_k<3>(blocks, st, base, g, cl, rsrc, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+        case 4: launch_cols_mixed_rs_k<4>(blocks, st, base, g, cl, rsrc, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+    }
+}
+
+// forward transform of a stack; `rsrc` (optional): the column pass takes its input from a rescale on the fly
+int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
+                const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *ql, const int64_t *qh,
+                const int64_t *kl, const int64_t *kh, int device, void *stream, const RescaleSrc *rsrc);
+
 }  // namespace
 
 extern "C" {
@@ -145,6 +171,40 @@ int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, con
            const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *_2q, const int64_t *ql,
            const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
     (void)_2q;
+    return ntt_forward(a, batch, rows, logN, psi_br, psi_dp, q_host, Rs, flags, ql, qh, kl, kh, device, stream, nullptr);
+}
+
+int lf_rescale_ntt(const int64_t *const *in, const int64_t *const *row0, int count, int64_t *x, int rows, int logN,
+                   const int64_t *scales, int64_t round_at, const int64_t *psi_br, const double *psi_dp,
+                   const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *_2q, const int64_t *ql,
+                   const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    (void)_2q;
+    if (count < 0 || count > LF_NTT_RS_MAX || rows < 0 || rows > MAX_LIST_ROWS || logN < 1 || logN > 2 * NTT_TILE_LOG_MAX)
+        return LF_ERR_ARG;
+    if (count == 0 || rows == 0) return 0;
+    const int S1 = logN - NTT_TILE_LOG_MAX;
+    if (S1 >= 1 && S1 <= 4 && cols_enabled() && !getenv("LF_NO_RESCALE_FUSION")) {
+        RescaleSrc rsrc;
+        for (int i = 0; i < count; ++i) rsrc.in[i] = (const i64 *)in[i], rsrc.row0[i] = (const i64 *)row0[i];
+        rsrc.scales = (const i64 *)scales;
+        rsrc.round_at = (i64)round_at;
+        return ntt_forward(x, count, rows, logN, psi_br, psi_dp, q_host, Rs, flags, ql, qh, kl, kh, device, stream, &rsrc);
+    }
+    // sizes without a column pass: the two steps one after the other
+    int64_t *outs[LF_NTT_RS_MAX];
+    for (int i = 0; i < count; ++i) outs[i] = x + ((int64_t)i * rows << logN);
+    if (int e = lf_rescale_batch(in, row0, outs, count, rows, (int64_t)1 << logN, scales, round_at, ql, qh, kl, kh, device, stream))
+        return e;
+    return ntt_forward(x, count, rows, logN, psi_br, psi_dp, q_host, Rs, flags, ql, qh, kl, kh, device, stream, nullptr);
+}
+
+}  // extern "C"
+
+namespace {
+
+int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
+                const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *ql, const int64_t *qh,
+                const int64_t *kl, const int64_t *kh, int device, void *stream, const RescaleSrc *rsrc) {
     if (batch < 0 || rows < 0 || rows > MAX_LIST_ROWS || logN < 1 || logN > 2 * NTT_TILE_LOG_MAX) return LF_ERR_ARG;
     if (batch == 0 || rows == 0) return 0;
     if (int e = lf_set_device(device)) return e;
@@ -155,7 +215,7 @@ int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, con
     RowList dp, in;
     classify(rows, q_host, psi_dp, dp, in);
     hipStream_t st = (hipStream_t)stream;
-    const bool mixed = dp.n && in.n && mixed_enabled();   // both classes in one launch per pass
+    const bool mixed = rsrc || (dp.n && in.n && mixed_enabled());   // both classes in one launch per pass
     SideStream *side = (dp.n && in.n && !mixed) ? side_stream(device) : nullptr;
     hipStream_t st_int = side ? side->stream : st;
     if (side) {
@@ -166,7 +226,7 @@ int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, con
     // transform.  The result is then NOT a transform; bench.py uses it to time the dominant kernel alone.
     const char *only_env = S1 > 0 ? getenv("LF_NTT_ONLY_PASS") : nullptr;
     const int only_pass = only_env ? atoi(only_env) : 0;
-    const int chunk = chunk_polys(batch, rows, logN, S1 > 0);
+    const int chunk = rsrc ? batch : chunk_polys(batch, rows, logN, S1 > 0);   // the rescale source indexes whole-batch polynomials
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int nb = batch - b0 < chunk ? batch - b0 : chunk;
         i64 *base = (i64 *)a + ((i64)b0 * rows << logN);
@@ -178,6 +238,10 @@ int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, con
             const i64 *rs = (pass == 0 || S1 == 0) ? (const i64 *)Rs : nullptr;
             if (pass == 0 && S1 <= 4 && cols_enabled()) {   // leading stages: one register step per column
                 const unsigned col_blocks = (unsigned)nb * ((1u << (logN - S1)) / NTT_COL_THREADS);
+                if (rsrc) {
+                    launch_cols_mixed_rs(S1, col_blocks, st, base, g, in, dp, *rsrc, psi_br, psi_dp, rs, ql, qh, kl, kh);
+                    continue;
+                }
                 if (mixed) {
                     launch_cols_mixed(S1, col_blocks, st, base, g, in, dp, psi_br, psi_dp, rs, ql, qh, kl, kh);
                     continue;
@@ -209,6 +273,10 @@ int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, con
     }
     return (int)hipGetLastError();
 }
+
+}  // namespace
+
+extern "C" {
 
 int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, const double *ipsi_dp,
             const int64_t *q_host, const int64_t *Ninv, int tail, int flags, const int64_t *_2q, const int64_t *ql,

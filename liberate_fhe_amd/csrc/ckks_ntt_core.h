@@ -719,12 +719,23 @@ __device__ __forceinline__ void cols_fwd_stages(typename A::T (&x)[1 << K], cons
     }
 }
 
-template <bool DP, int K>
+// Optional source of the column pass: the words are produced on the fly by the engine's rescale
+// (ckks_engine.py:1029-1041: reduce_q(REDC((in - row0) * scale) + [row0 > q_l / 2])) from another tensor, so
+// cc_mult's rescale costs no launch and no pass over HBM of its own.
+#define LF_NTT_RS_MAX 8
+struct RescaleSrc {
+    const i64 *in[LF_NTT_RS_MAX];     // per polynomial: first surviving row of the source component, [rows, N]
+    const i64 *row0[LF_NTT_RS_MAX];   // per polynomial: the dropped limb's row, [N]
+    const i64 *scales;                // per surviving row: q_l^-1 * R mod q_row
+    i64 round_at;
+};
+
+template <bool DP, int K, bool RS = false>
 __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const PassGeom &g, const RowList &rl,
                                               const i64 *__restrict__ psi_br, const double *__restrict__ psi_dp,
                                               const i64 *__restrict__ Rs, const i64 *__restrict__ ql,
                                               const i64 *__restrict__ qh, const i64 *__restrict__ kl,
-                                              const i64 *__restrict__ kh) {
+                                              const i64 *__restrict__ kh, const RescaleSrc *rsrc = nullptr) {
     constexpr int R = 1 << K;
     const int logC = g.logN - K;
     const int chunks = (1 << logC) / NTT_COL_THREADS;
@@ -744,8 +755,21 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
     i64 *col = a + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS + threadIdx.x;
 
     i64 w[R];
+    if (RS) {
+        const i64 j = (i64)chunk * NTT_COL_THREADS + threadIdx.x;
+        const i64 *src = rsrc->in[poly] + ((i64)crow << g.logN) + j;
+        const i64 *z0 = rsrc->row0[poly] + j;
+        const i64 sc = rsrc->scales[crow], qq = (i64)c.m.q;
 #pragma unroll
-    for (int k = 0; k < R; ++k) w[k] = col[(i64)k << logC];
+        for (int k = 0; k < R; ++k) {
+            const i64 z = z0[(i64)k << logC];
+            const i64 v = mm62s(src[(i64)k << logC] - z, sc, c.m.q, c.m.k) + (i64)(z > rsrc->round_at);
+            w[k] = v < qq ? v : v - qq;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) w[k] = col[(i64)k << logC];
+    }
     int odd = 0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -806,6 +830,21 @@ __global__ void __launch_bounds__(NTT_COL_THREADS) ntt_fwd_cols_mixed(i64 *__res
         if (b < cl.in_real) fwd_cols_body<false, K>(b, a, g, cl.in, psi_br, psi_dp, Rs, ql, qh, kl, kh);
     } else {
         fwd_cols_body<true, K>(b - cl.in_blocks, a, g, cl.dp, psi_br, psi_dp, Rs, ql, qh, kl, kh);
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(NTT_COL_THREADS) ntt_fwd_cols_mixed_rs(i64 *__restrict__ a, PassGeom g, ClassLists cl,
+                                                                        RescaleSrc rsrc, const i64 *__restrict__ psi_br,
+                                                                        const double *__restrict__ psi_dp,
+                                                                        const i64 *__restrict__ Rs, const i64 *__restrict__ ql,
+                                                                        const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                                                        const i64 *__restrict__ kh) {
+    const int b = blockIdx.x;
+    if (b < cl.in_blocks) {
+        if (b < cl.in_real) fwd_cols_body<false, K, true>(b, a, g, cl.in, psi_br, psi_dp, Rs, ql, qh, kl, kh, &rsrc);
+    } else {
+        fwd_cols_body<true, K, true>(b - cl.in_blocks, a, g, cl.dp, psi_br, psi_dp, Rs, ql, qh, kl, kh, &rsrc);
     }
 }
 

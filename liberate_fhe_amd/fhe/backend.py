@@ -65,6 +65,14 @@ class HipBackend:
         check(lib.lf_ntt(_p(buf), batch, rows, logN, _p(psi), dp, c.qptr(), _p(Rs), (1 if relaxed else 0) | (2 if relaxed and plain else 0), _p(c._2q),
                          *c.mont(), dev, st), "lf_ntt")
 
+    def rescale_ntt(self, srcs, row0s, buf, rows, logN, scales, round_at, psi, Rs, c: Consts, relaxed=False, plain=False):
+        """Rescale len(srcs) polynomials into buf[i] and transform them (cc_mult's opening) in one call."""
+        dev, st = _ds(buf)
+        dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
+        check(lib.lf_rescale_ntt(_parr(srcs), _parr(row0s), len(srcs), _p(buf), rows, logN, _p(scales), round_at, _p(psi), dp,
+                                 c.qptr(), _p(Rs), (1 if relaxed else 0) | (2 if relaxed and plain else 0), _p(c._2q),
+                                 *c.mont(), dev, st), "lf_rescale_ntt")
+
     def intt(self, buf, batch, rows, logN, ipsi, Ninv, tail, c: Consts, relaxed=False, plain=False):
         dev, st = _ds(buf)
         dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)

@@ -589,11 +589,11 @@ class ckks_engine(EvaluatorOps):
         """Rescale ct (level l) writing component c of local device d into outs[c][d] ([rows, N] views)."""
         self._rescale_many([ct], [outs], exact_rounding)
 
-    def _rescale_many(self, cts, outs_list, exact_rounding=True):
-        """Rescale several ciphertexts of one level; outs_list[k][c][d] receives component c of cts[k] on local
-        device d.  All their polynomials go through ONE launch per device (cc_mult: four).
-        Without exact rounding the [row0 > q_l / 2] term is dropped (eng.py:1017-1027, 1036-1038): the kernel's
-        threshold is put out of reach."""
+    def _rescale_operands(self, cts, exact_rounding=True):
+        """What the rescale of several ciphertexts of one level reads, per local device of the next level:
+        {d: (sources, dropped-limb rows)} in the order (ct 0 comp 0, ct 0 comp 1, ct 1 comp 0, ..), and the
+        rounding threshold.  Without exact rounding the [row0 > q_l / 2] term is dropped (eng.py:1017-1027,
+        1036-1038): the kernels' threshold is put out of reach."""
         level = cts[0].level
         nxt = level + 1
         owner = self.ntt.p.rescaler_loc[level]
@@ -615,15 +615,26 @@ class ckks_engine(EvaluatorOps):
             else:
                 i = loc_before.index(owner)
                 rows0.append([self._share_rows(ct.data[comp][i][0], owner, targets, (N,)) for comp in range(2)])
+        per_dev = {}
         for d in self._loc(nxt):
             i = loc_before.index(d)
-            srcs, r0s, dsts = [], [], []
+            srcs, r0s = [], []
             for k, ct in enumerate(cts):
                 for comp in range(2):
                     src = ct.data[comp][i]
                     srcs.append(src[1:] if d == owner else src)
                     r0s.append(rows0[k][comp][d])
-                    dsts.append(outs_list[k][comp][d])
+            per_dev[d] = (srcs, r0s)
+        return per_dev, round_at
+
+    def _rescale_many(self, cts, outs_list, exact_rounding=True):
+        """Rescale several ciphertexts of one level; outs_list[k][c][d] receives component c of cts[k] on local
+        device d.  All their polynomials go through ONE launch per device."""
+        level = cts[0].level
+        nxt = level + 1
+        per_dev, round_at = self._rescale_operands(cts, exact_rounding)
+        for d, (srcs, r0s) in per_dev.items():
+            dsts = [outs_list[k][comp][d] for k in range(len(cts)) for comp in range(2)]
             self.backend.rescale_batch(srcs, r0s, dsts, self._rows(d, nxt, False), self.rescale_scales[level][d], round_at,
                                        self._consts(d, nxt, False))
 
@@ -654,17 +665,19 @@ class ckks_engine(EvaluatorOps):
         N, logN = self.ctx.N, self.ctx.logN
         d0, d1, d2 = [], [], []
         stacks = {d: self._ws("mult4", (4, self._rows(d, level, False), N), d) for d in loc}
-        # x0, x1, y0, y1 are written by the two rescales straight into one [4, rows, N] stack per device
-        self._rescale_many([a, b], [[{d: stacks[d][0] for d in loc}, {d: stacks[d][1] for d in loc}],
-                                    [{d: stacks[d][2] for d in loc}, {d: stacks[d][3] for d in loc}]])
+        # x0, x1, y0, y1: both rescales and the four forward transforms are one backend call per device (for
+        # two-pass ring degrees the rescale is evaluated inside the first NTT pass).  With relinearisation the
+        # triplet never leaves this method: only residues matter, so the 40-bit limbs take the relaxed
+        # plain-domain transforms (one fp64 product per tensor term)
+        per_dev, round_at = self._rescale_operands([a, b])
         for d in loc:
             rows = self._rows(d, level, False)
             c = self._consts(d, level, False)
             x = stacks[d]
-            # with relinearisation the triplet never leaves this method: only residues matter, so the 40-bit
-            # limbs take the relaxed plain-domain transforms (one fp64 product per tensor term)
-            self.backend.ntt(x, 4, rows, logN, self._tw(d, level, False), self._vec("Rs", d, level, False), c,
-                             relaxed=relin, plain=relin)
+            srcs, r0s = per_dev[d]
+            self.backend.rescale_ntt(srcs, r0s, x, rows, logN, self.rescale_scales[a.level][d], round_at,
+                                     self._tw(d, level, False), self._vec("Rs", d, level, False), c,
+                                     relaxed=relin, plain=relin)
             out = torch.empty((3, rows, N), dtype=torch.int64, device=self.ntt.devices[d])
             self.backend.tensor(x[0], x[1], x[2], x[3], out[0], out[1], out[2], rows, c, plain=relin)
             d0.append(out[0]); d1.append(out[1]); d2.append(out[2])

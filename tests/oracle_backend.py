@@ -198,6 +198,10 @@ class OracleBackend:
         for src, row0, out in zip(srcs, row0s, outs):
             self.rescale(src, row0, out, rows, scales, round_at, c)
 
+    def rescale_ntt(self, srcs, row0s, buf, rows, logN, scales, round_at, psi, Rs, c, relaxed=False, plain=False):
+        self.rescale_batch(srcs, row0s, [buf[i] for i in range(len(srcs))], rows, scales, round_at, c)
+        self.ntt(buf, len(srcs), rows, logN, psi, Rs, c, relaxed=relaxed, plain=plain)
+
     def ks_moddown_batch(self, ss, outs, addends, ell, K, PiR, Rs, c, PiP=None):
         for s_, out, add in zip(ss, outs, addends):
             self.ks_moddown(s_, out, add, ell, K, PiR, Rs, c, PiP=PiP)
