@@ -188,3 +188,36 @@ def test_reference_shaped_tables_are_accepted(mods):
     assert torch.equal(a[0], b[0])
     orc.intt_tab(want, iev, iod, ipsi3, lim.Ninv, lim.rows, lim._2q, *lim.mont_args())
     assert (a[0].cpu().numpy() == want).all()
+
+
+@pytest.mark.parametrize("logN", [12, 13, 15, 16])
+@pytest.mark.parametrize("flags", [0, 1, 3])
+def test_rescale_ntt_equals_rescale_then_ntt(logN, flags):
+    """lf_rescale_ntt (rescale inside the first NTT pass for logN 13..16) against lf_rescale_batch + lf_ntt, both of
+    which are pinned to the oracle above: same words, exact / relaxed / relaxed+plain."""
+    import ctypes
+    from liberate_fhe_amd._native import lib, check
+    from liberate_fhe_amd.ntt import twiddles
+    lim = Limbs(logN, pick_primes(logN, 3, 2))
+    rows, N, count = lim.rows, lim.N, 4
+    rng = np.random.default_rng(logN * 10 + flags)
+    q_drop = int(lim.q[0]) | 1
+    srcs = [dev(np.stack([rng.integers(0, int(x), size=N, dtype=np.int64) for x in lim.q])) for _ in range(count)]
+    row0 = [dev(rng.integers(0, q_drop, size=N, dtype=np.int64)) for _ in range(count)]
+    scales = dev(np.array([rng.integers(1, int(x)) for x in lim.q], dtype=np.int64))
+    c = [dev(v) for v in (lim.ql, lim.qh, lim.kl, lim.kh)]
+    psi, Rs, q2 = dev(lim.mont_tables()[0]), dev(lim.Rs), dev(lim._2q)
+    st = torch.cuda.current_stream().cuda_stream
+    dp = twiddles.dp_pointer(psi, *c, 0, st)
+    q_host = np.array(lim.q, dtype=np.int64)
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    want = torch.empty((count, rows, N), dtype=torch.int64, device="cuda")
+    check(lib.lf_rescale_batch(arr(srcs), arr(row0), arr([want[i] for i in range(count)]), count, rows, N, scales.data_ptr(),
+                               q_drop // 2, *[t.data_ptr() for t in c], 0, st), "rescale")
+    check(lib.lf_ntt(want.data_ptr(), count, rows, logN, psi.data_ptr(), dp, q_host.ctypes.data, Rs.data_ptr(), flags,
+                     q2.data_ptr(), *[t.data_ptr() for t in c], 0, st), "ntt")
+    got = torch.empty_like(want)
+    check(lib.lf_rescale_ntt(arr(srcs), arr(row0), count, got.data_ptr(), rows, logN, scales.data_ptr(), q_drop // 2,
+                             psi.data_ptr(), dp, q_host.ctypes.data, Rs.data_ptr(), flags, q2.data_ptr(),
+                             *[t.data_ptr() for t in c], 0, st), "rescale_ntt")
+    assert torch.equal(got, want)
