@@ -180,8 +180,18 @@ int lf_rescale_batch(const int64_t *const *in, const int64_t *const *row0, int64
                      int64_t N, const int64_t *scales, int64_t round_at, const int64_t *ql, const int64_t *qh,
                      const int64_t *kl, const int64_t *kh, int device, void *stream);
 int lf_ks_moddown_batch(const int64_t *const *s, int64_t *const *out, const int64_t *const *addend, int count, int ell, int K,
-                        int64_t N, const int64_t *PiR, const double *PiP, const int64_t *Rs, const int64_t *ql,
-                        const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+                        int64_t N, const int64_t *PiR, const double *PiP, const int64_t *Rs, int64_t gal_pinv,
+                        const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
+                        int device, void *stream);
+
+/* Galois permutation in gather form, so that rotate / conjugate need no permutation pass of their own
+ * (switch_key / rotate_single, ckks_engine.py:939-961, 1180-1206; encdec.py:224-270):
+ *   lf_ks_digits_galois  = lf_ks_digits of a(X^p);  lf_ks_moddown_batch with gal_pinv != 0 adds addend(X^p).
+ * gal_pinv = p^-1 mod 2N (0: no permutation); gal_2q != NULL: the permuted words are made canonical as
+ * rotate_single does (make_unsigned + reduce_2q), NULL: they stay signed as conjugate leaves them. */
+int lf_ks_digits_galois(const int64_t *a, int64_t *state, int nparts, const int64_t *desc, const int64_t *tab, int64_t N,
+                        int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+                        const int64_t *kh, int device, void *stream);
 int lf_galois_batch(const int64_t *const *a, int64_t *const *dst, int count, int rows, int logN, int64_t p,
                     const int64_t *_2q, int device, void *stream);
 

@@ -47,7 +47,8 @@ _SIGNATURES = {
     "lf_ks_inner": [_P, _P, _L, _L, _L, _P, _P, _I, _I, _L, _P, _P, _P, _P, _I, _P],
     "lf_ks_moddown": [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_rescale_batch": [_P, _P, _P, _I, _I, _L, _P, _L, _P, _P, _P, _P, _I, _P],
-    "lf_ks_moddown_batch": [_P, _P, _P, _I, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lf_ks_moddown_batch": [_P, _P, _P, _I, _I, _I, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _P],
+    "lf_ks_digits_galois": [_P, _P, _I, _P, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P],
     "lf_galois_batch": [_P, _P, _I, _I, _I, _L, _P, _I, _P],
     "lf_rescale_ntt": [_P, _P, _I, _P, _I, _I, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P],
     "lf_chacha20": [_P, _P, _L, _U, _I, _P],

@@ -100,11 +100,28 @@ __global__ void __launch_bounds__(256) tensor_kernel(const i64 *__restrict__ x0,
     *reinterpret_cast<longlong2 *>(d2 + off) = o2;
 }
 
+// Coefficient j of a(X^p) read straight from a (gather form of the Galois permutation, encdec.py:224-270):
+// with n = p^-1 * j mod 2N it is a[n] for n < N and -a[n - N] otherwise; `q2` != 0 additionally makes it
+// canonical the way rotate_single does (make_unsigned + reduce_2q, eng.py:1198-1200).  pinv = 0: plain read.
+static __device__ __forceinline__ i64 galois_read(const i64 *row, i64 j, i64 N, i64 pinv, i64 q2) {
+    if (pinv == 0) return row[j];
+    const u64 n = ((u64)pinv * (u64)j) & (u64)(2 * N - 1);
+    i64 v = row[n & (u64)(N - 1)];
+    if (n >= (u64)N) v = -v;
+    if (q2) {
+        const i64 q = q2 >> 1;
+        v += q;
+        v = v < q ? v : v - q;
+    }
+    return v;
+}
+
 // ---- key-switch step 1: mixed-radix digits of each key-switch part (pre_extend, 654-705) ---------
 // desc[p] = {row_start, alpha, y_off, l_off}; Y_scalar[i] = tab[y_off + i];
 // L_scalar[i][j-(i+2)] = tab[l_off + running index in (i, j) order].
 __global__ void __launch_bounds__(256) ks_digits_kernel(const i64 *__restrict__ a, i64 *__restrict__ state,
                                                         const i64 *__restrict__ desc, const i64 *__restrict__ tab, i64 N,
+                                                        i64 gal_pinv, const i64 *__restrict__ gal_2q,
                                                         const i64 *__restrict__ ql, const i64 *__restrict__ qh,
                                                         const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
     const int p = blockIdx.y;
@@ -116,7 +133,8 @@ __global__ void __launch_bounds__(256) ks_digits_kernel(const i64 *__restrict__ 
     i64 x[KS_MAX_ALPHA], st[KS_MAX_ALPHA];
 #pragma unroll
     for (int i = 0; i < KS_MAX_ALPHA; ++i)
-        if (i < alpha) x[i] = a[(i64)(row_start + i) * N + j];
+        if (i < alpha)
+            x[i] = galois_read(a + (i64)(row_start + i) * N, j, N, gal_pinv, gal_2q ? gal_2q[row_start + i] : 0);
 #pragma unroll
     for (int i = 0; i < KS_MAX_ALPHA; ++i) st[i] = x[0];
     int lc = 0;
@@ -202,7 +220,8 @@ __global__ void __launch_bounds__(256) ks_inner_kernel(const i64 *__restrict__ e
 // eliminated last-first; PiR[P_ind][row] = P_j^-1 * R mod q_row.  Optional `addend` (relinearize's
 // d0/d1 or the rotated c0): out = reduce_q(result + addend)  (ckks_engine.py:1135-1140, 952-953).
 #define MD_ROWS 8
-__global__ void __launch_bounds__(256) ks_moddown_kernel(PtrBatch pb, int ell, int K, i64 N,
+__global__ void __launch_bounds__(256) ks_moddown_kernel(PtrBatch pb, int ell, int K, i64 N, i64 gal_pinv,
+                                                         const i64 *__restrict__ gal_2q,
                                                          const i64 *__restrict__ PiR, const double *__restrict__ PiP,
                                                          const i64 *__restrict__ Rs,
                                                          const i64 *__restrict__ ql, const i64 *__restrict__ qh,
@@ -276,7 +295,7 @@ __global__ void __launch_bounds__(256) ks_moddown_kernel(PtrBatch pb, int ell, i
             d = d < (i64)m.q ? d : d - (i64)m.q;
         }
         if (addend) {
-            d += addend[(i64)r * N + j];
+            d += galois_read(addend + (i64)r * N, j, N, gal_pinv, gal_2q ? gal_2q[r] : 0);
             d = d < (i64)m.q ? d : d - (i64)m.q;
         }
         out[(i64)r * N + j] = d;
@@ -320,6 +339,20 @@ int lf_tensor(const int64_t *x0, const int64_t *x1, const int64_t *y0, const int
     return (int)hipGetLastError();
 }
 
+int lf_ks_digits_galois(const int64_t *a, int64_t *state, int nparts, const int64_t *desc, const int64_t *tab, int64_t N,
+                        int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+                        const int64_t *kh, int device, void *stream) {
+    if (nparts < 0 || N < 1 || gal_pinv < 0 || gal_pinv >= 2 * N || (gal_pinv && !(gal_pinv & 1)) || (N & (N - 1)))
+        return LF_ERR_ARG;
+    if (nparts == 0) return 0;
+    if (int e = lf_set_device(device)) return e;
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)nparts);
+    hipLaunchKernelGGL(ks_digits_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const i64 *)a, (i64 *)state, (const i64 *)desc,
+                       (const i64 *)tab, (i64)N, (i64)gal_pinv, (const i64 *)gal_2q, (const i64 *)ql, (const i64 *)qh,
+                       (const i64 *)kl, (const i64 *)kh);
+    return (int)hipGetLastError();
+}
+
 int lf_ks_digits(const int64_t *a, int64_t *state, int nparts, const int64_t *desc, const int64_t *tab, int64_t N,
                  const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
     if (nparts < 0 || N < 1) return LF_ERR_ARG;
@@ -327,7 +360,8 @@ int lf_ks_digits(const int64_t *a, int64_t *state, int nparts, const int64_t *de
     if (int e = lf_set_device(device)) return e;
     dim3 grid((unsigned)((N + 255) / 256), (unsigned)nparts);
     hipLaunchKernelGGL(ks_digits_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const i64 *)a, (i64 *)state, (const i64 *)desc,
-                       (const i64 *)tab, (i64)N, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+                       (const i64 *)tab, (i64)N, (i64)0, (const i64 *)nullptr, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl,
+                       (const i64 *)kh);
     return (int)hipGetLastError();
 }
 
@@ -356,16 +390,19 @@ int lf_ks_inner(const int64_t *ext, const int64_t *ksk, int64_t part_stride, int
 }
 
 int lf_ks_moddown_batch(const int64_t *const *s, int64_t *const *out, const int64_t *const *addend, int count, int ell, int K,
-                        int64_t N, const int64_t *PiR, const double *PiP, const int64_t *Rs, const int64_t *ql,
-                        const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+                        int64_t N, const int64_t *PiR, const double *PiP, const int64_t *Rs, int64_t gal_pinv,
+                        const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
+                        int device, void *stream) {
     if (count < 0 || count > LF_BATCH_MAX || ell < 0 || K < 1 || K > KS_MAX_K || N < 1) return LF_ERR_ARG;
+    if (gal_pinv < 0 || gal_pinv >= 2 * N || (gal_pinv && (!(gal_pinv & 1) || (N & (N - 1))))) return LF_ERR_ARG;
     if (count == 0 || ell == 0) return 0;
     if (int e = lf_set_device(device)) return e;
     PtrBatch pb;
     for (int i = 0; i < count; ++i)
         pb.in[i] = (const i64 *)s[i], pb.aux[i] = addend ? (const i64 *)addend[i] : nullptr, pb.out[i] = (i64 *)out[i];
     dim3 grid((unsigned)((N + 255) / 256), (unsigned)((ell + MD_ROWS - 1) / MD_ROWS), (unsigned)count);
-    hipLaunchKernelGGL(ks_moddown_kernel, grid, dim3(256), 0, (hipStream_t)stream, pb, ell, K, (i64)N, (const i64 *)PiR, PiP,
+    hipLaunchKernelGGL(ks_moddown_kernel, grid, dim3(256), 0, (hipStream_t)stream, pb, ell, K, (i64)N, (i64)gal_pinv,
+                       (const i64 *)gal_2q, (const i64 *)PiR, PiP,
                        (const i64 *)Rs, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     return (int)hipGetLastError();
 }
@@ -373,7 +410,7 @@ int lf_ks_moddown_batch(const int64_t *const *s, int64_t *const *out, const int6
 int lf_ks_moddown(const int64_t *s, int64_t *out, const int64_t *addend, int ell, int K, int64_t N, const int64_t *PiR,
                   const double *PiP, const int64_t *Rs, const int64_t *ql, const int64_t *qh, const int64_t *kl,
                   const int64_t *kh, int device, void *stream) {
-    return lf_ks_moddown_batch(&s, &out, &addend, 1, ell, K, N, PiR, PiP, Rs, ql, qh, kl, kh, device, stream);
+    return lf_ks_moddown_batch(&s, &out, &addend, 1, ell, K, N, PiR, PiP, Rs, 0, nullptr, ql, qh, kl, kh, device, stream);
 }
 
 }  // extern "C"

@@ -94,10 +94,12 @@ class HipBackend:
         check(lib.lf_rescale_batch(_parr(srcs), _parr(row0s), _parr(outs), len(srcs), rows, outs[0].size(-1), _p(scales),
                                    round_at, *c.mont(), dev, st), "lf_rescale_batch")
 
-    def ks_moddown_batch(self, ss, outs, addends, ell, K, PiR, Rs, c: Consts, PiP=None):
+    def ks_moddown_batch(self, ss, outs, addends, ell, K, PiR, Rs, c: Consts, PiP=None, galois=None):
+        """galois = (p^-1 mod 2N, _2q or None): the addends are added as addend(X^p), read in gather form."""
         dev, st = _ds(outs[0])
+        pinv, g2q = (0, None) if galois is None else galois
         check(lib.lf_ks_moddown_batch(_parr(ss), _parr(outs), _parr(addends), len(ss), ell, K, outs[0].size(-1), _p(PiR),
-                                      0 if PiP is None else PiP.data_ptr(), _p(Rs), *c.mont(), dev, st),
+                                      0 if PiP is None else PiP.data_ptr(), _p(Rs), pinv, _p(g2q), *c.mont(), dev, st),
               "lf_ks_moddown_batch")
 
     def rescale(self, src, row0, out, rows, scales, round_at, c: Consts):
@@ -111,9 +113,14 @@ class HipBackend:
                             *c.mont(), dev, st),
               "lf_tensor")
 
-    def ks_digits(self, a, state, nparts, desc, tab, c: Consts):
+    def ks_digits(self, a, state, nparts, desc, tab, c: Consts, galois=None):
+        """galois = (p^-1 mod 2N, _2q or None): the digits of a(X^p), read in gather form (no permutation pass)."""
         dev, st = _ds(a)
-        check(lib.lf_ks_digits(_p(a), _p(state), nparts, _p(desc), _p(tab), a.size(-1), *c.mont(), dev, st), "lf_ks_digits")
+        if galois is None:
+            check(lib.lf_ks_digits(_p(a), _p(state), nparts, _p(desc), _p(tab), a.size(-1), *c.mont(), dev, st), "lf_ks_digits")
+        else:
+            check(lib.lf_ks_digits_galois(_p(a), _p(state), nparts, _p(desc), _p(tab), a.size(-1), galois[0], _p(galois[1]),
+                                          *c.mont(), dev, st), "lf_ks_digits_galois")
 
     def ks_extend(self, state, ext, nparts, rows, desc, E, c: Consts):
         dev, st = _ds(ext)

@@ -820,10 +820,13 @@ class ckks_engine(EvaluatorOps):
             out[t] = torch.cat(pieces)
         return out
 
-    def create_switcher(self, a: list[torch.Tensor], ksk: data_struct, level, exit_ntt=False, addends=None) -> tuple:
+    def create_switcher(self, a: list[torch.Tensor], ksk: data_struct, level, exit_ntt=False, addends=None,
+                        galois=None) -> tuple:
         """Key-switch the coefficient-domain polynomial `a` (one tensor per local device) under `ksk`.
         Returns (c0, c1) lists of canonical [rows, N] tensors.  `addends` = optional (list, list) added
-        to (c0, c1) inside the last kernel (relinearize's d0/d1, switch_key's rotated c0)."""
+        to (c0, c1) inside the last kernel (relinearize's d0/d1, switch_key's rotated c0).
+        `galois` = (p^-1 mod 2N, canonical): switch a(X^p) and add addends(X^p) instead — the permutation is applied
+        where the digits kernel and the mod-down kernel read their input (coefficient-domain `a` only)."""
         tabs = self._ks_tables(level)
         loc = self._loc(level)
         N, logN, K = self.ctx.N, self.ctx.logN, self.ntt.num_special_primes
@@ -841,7 +844,8 @@ class ckks_engine(EvaluatorOps):
                                   2, self._consts(d, level, False))
             st = self._ws("ks_state", (rows, N), d)
             nparts, desc, tab = tabs[("digits", d)]
-            self.backend.ks_digits(src, st, nparts, desc, tab, self._consts(d, level, False))
+            gal = None if galois is None else (galois[0], self._vec("_2q", d, level, False) if galois[1] else None)
+            self.backend.ks_digits(src, st, nparts, desc, tab, self._consts(d, level, False), galois=gal)
             states[d] = st
         # 2. digit gather
         digits = self._gather_digits(states, level, tabs)
@@ -877,8 +881,9 @@ class ckks_engine(EvaluatorOps):
                 if add is not None and not add.is_contiguous():
                     add = add.contiguous()
                 adds.append(add)
+            gal = None if galois is None else (galois[0], self._vec("_2q", d, level, False) if galois[1] else None)
             self.backend.ks_moddown_batch([s[0], s[1]], [out[0], out[1]], adds, ell, K, tabs[("pir", d)], rs, cs,
-                                          PiP=tabs[("pip", d)])
+                                          PiP=tabs[("pip", d)], galois=gal)
             c0.append(out[0]); c1.append(out[1])
         return c0, c1
 
@@ -896,8 +901,15 @@ class ckks_engine(EvaluatorOps):
     def _automorphism(self, ct, exponent, key, canonical):
         """X -> X^exponent on both components, then key-switch back.  `canonical`: fold the reference's
         make_unsigned + reduce_2q (rotate_single does that, eng.py:1198-1200; conjugate does not and
-        key-switches the signed words, eng.py:1718-1734)."""
+        key-switches the signed words, eng.py:1718-1734).
+        Coefficient-domain ciphertexts (the normal case) never see a permutation pass: the key switch reads
+        c1(X^p) and adds c0(X^p) in gather form inside its first and last kernels."""
         level = ct.level
+        if not ct.ntt_state and not ct.include_special:
+            pinv = pow(exponent, -1, 2 * self.ctx.N)
+            c0, c1 = self.create_switcher(ct.data[1], key, level, addends=(ct.data[0], None), galois=(pinv, canonical))
+            return data_struct(data=(c0, c1), include_special=False, ntt_state=False,
+                               montgomery_state=ct.montgomery_state, origin=types.origins["ct"], level=level, hash=self.hash)
         loc = self._loc(level, special=ct.include_special)
         rot0, rot1 = [], []
         for i, d in enumerate(loc):

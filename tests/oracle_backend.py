@@ -202,8 +202,18 @@ class OracleBackend:
         self.rescale_batch(srcs, row0s, [buf[i] for i in range(len(srcs))], rows, scales, round_at, c)
         self.ntt(buf, len(srcs), rows, logN, psi, Rs, c, relaxed=relaxed, plain=plain)
 
-    def ks_moddown_batch(self, ss, outs, addends, ell, K, PiR, Rs, c, PiP=None):
+    def _permuted(self, t, rows, galois):
+        """t(X^p) as a new tensor, with the reference's scatter (oracle galois), p from p^-1."""
+        pinv, g2q = galois
+        N = t.size(-1)
+        out = torch.empty_like(t[:rows])
+        self.galois(t[:rows].contiguous(), out, rows, N.bit_length() - 1, pow(pinv, -1, 2 * N), g2q)
+        return out
+
+    def ks_moddown_batch(self, ss, outs, addends, ell, K, PiR, Rs, c, PiP=None, galois=None):
         for s_, out, add in zip(ss, outs, addends):
+            if add is not None and galois is not None:
+                add = self._permuted(add, ell, galois)
             self.ks_moddown(s_, out, add, ell, K, PiR, Rs, c, PiP=PiP)
 
     def galois_batch(self, srcs, dsts, rows, logN, p, _2q):
@@ -222,7 +232,9 @@ class OracleBackend:
         orc.mont_mult(a1, b1, t0, rows, *self._m(c)); _np(d2)[:rows] = t0
 
     # ---- pre_extend: ckks_engine.py:654-705 ----
-    def ks_digits(self, a, state, nparts, desc, tab, c):
+    def ks_digits(self, a, state, nparts, desc, tab, c, galois=None):
+        if galois is not None:
+            a = self._permuted(a, a.size(0), galois)
         A, S = _np(a), _np(state)
         ql, qh, kl, kh = self._m(c)
         D, T = _np(desc).reshape(-1, 4), _np(tab)
