@@ -221,3 +221,55 @@ def test_rescale_ntt_equals_rescale_then_ntt(logN, flags):
                              psi.data_ptr(), dp, q_host.ctypes.data, Rs.data_ptr(), flags, q2.data_ptr(),
                              *[t.data_ptr() for t in c], 0, st), "rescale_ntt")
     assert torch.equal(got, want)
+
+
+def test_batch_entry_points_edge_cases():
+    """count = 0 is a no-op, count > 8 and bad Galois exponents are argument errors, single-set batches equal the
+    scalar entry points."""
+    import ctypes
+    from liberate_fhe_amd._native import lib
+    logN = 12
+    lim = Limbs(logN, pick_primes(logN, 2, 1))
+    rows, N = lim.rows, lim.N
+    c = [dev(v) for v in (lim.ql, lim.qh, lim.kl, lim.kh)]
+    cp = [t.data_ptr() for t in c]
+    st = torch.cuda.current_stream().cuda_stream
+    none = (ctypes.c_void_p * 1)()
+    scales = dev(np.ones(rows, dtype=np.int64))
+    assert lib.lf_rescale_batch(none, none, none, 0, rows, N, scales.data_ptr(), 1, *cp, 0, st) == 0
+    nine = (ctypes.c_void_p * 9)()
+    assert lib.lf_rescale_batch(nine, nine, nine, 9, rows, N, scales.data_ptr(), 1, *cp, 0, st) == 10001
+    assert lib.lf_galois_batch(nine, nine, 9, rows, logN, 5, 0, 0, st) == 10001
+    a = dev(lim.uniform(1))
+    d1, d2 = torch.empty_like(a), torch.empty_like(a)
+    q2 = dev(lim._2q)
+    arr = lambda t: (ctypes.c_void_p * 1)(t.data_ptr())
+    assert lib.lf_galois_batch(arr(a), arr(a), 1, rows, logN, 5, 0, 0, st) == 10001            # in place
+    assert lib.lf_galois_batch(arr(a), arr(d1), 1, rows, logN, 4, 0, 0, st) == 10001           # even exponent
+    assert lib.lf_galois(a.data_ptr(), d1.data_ptr(), rows, logN, 5, q2.data_ptr(), 0, st) == 0
+    assert lib.lf_galois_batch(arr(a), arr(d2), 1, rows, logN, 5, q2.data_ptr(), 0, st) == 0
+    assert torch.equal(d1, d2)
+
+
+@pytest.mark.parametrize("canonical", [True, False])
+def test_galois_gather_equals_scatter(canonical):
+    """lf_ks_digits_galois / the gather addend of lf_ks_moddown_batch read a(X^p) exactly as lf_galois writes it:
+    checked on the digit kernel with a single one-limb digit (its Garner state is the input word itself)."""
+    from liberate_fhe_amd._native import lib, check
+    logN = 12
+    lim = Limbs(logN, pick_primes(logN, 2, 1))
+    rows, N = lim.rows, lim.N
+    c = [dev(v) for v in (lim.ql, lim.qh, lim.kl, lim.kh)]
+    cp = [t.data_ptr() for t in c]
+    st = torch.cuda.current_stream().cuda_stream
+    a = dev(lim.uniform(7))
+    q2 = dev(lim._2q)
+    p = pow(3, 5, 2 * N)
+    want = torch.empty_like(a)
+    check(lib.lf_galois(a.data_ptr(), want.data_ptr(), rows, logN, p, q2.data_ptr() if canonical else 0, 0, st), "galois")
+    desc = dev(np.array([[r, 1, 0, 0] for r in range(rows)], dtype=np.int64))     # one single-limb digit per row
+    tab = dev(np.zeros(1, dtype=np.int64))
+    got = torch.empty_like(a)
+    check(lib.lf_ks_digits_galois(a.data_ptr(), got.data_ptr(), rows, desc.data_ptr(), tab.data_ptr(), N, pow(p, -1, 2 * N),
+                                  q2.data_ptr() if canonical else 0, *cp, 0, st), "digits_galois")
+    assert torch.equal(got, want)
