@@ -296,15 +296,15 @@ int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64
         const unsigned per_row = (unsigned)nparts << (logN - tl);
         if (mixed) {
             const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
-            hipLaunchKernelGGL(ntt_fwd_pass_mixed, dim3((unsigned)cl.in_blocks + per_row * dp.n), dim3(NTT_THREADS), 0, st,
+            hipLaunchKernelGGL((ntt_fwd_pass_mixed<true>), dim3((unsigned)cl.in_blocks + per_row * dp.n), dim3(NTT_THREADS), 0, st,
                                (i64 *)tmp, g, cl, (const i64 *)psi_br, psi_dp, (const i64 *)nullptr, (const i64 *)ql,
                                (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
         } else if (dp.n)
-            hipLaunchKernelGGL(ntt_fwd_pass<true>, dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, (i64 *)tmp, g, dp,
+            hipLaunchKernelGGL((ntt_fwd_pass<true, true>), dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, (i64 *)tmp, g, dp,
                                (const i64 *)psi_br, psi_dp, (const i64 *)nullptr, (const i64 *)ql, (const i64 *)qh,
                                (const i64 *)kl, (const i64 *)kh);
         if (in.n && !mixed)
-            hipLaunchKernelGGL(ntt_fwd_pass<false>, dim3(per_row * in.n), dim3(NTT_THREADS), 0, st, (i64 *)tmp, g, in,
+            hipLaunchKernelGGL((ntt_fwd_pass<false, true>), dim3(per_row * in.n), dim3(NTT_THREADS), 0, st, (i64 *)tmp, g, in,
                                (const i64 *)psi_br, psi_dp, (const i64 *)nullptr, (const i64 *)ql, (const i64 *)qh,
                                (const i64 *)kl, (const i64 *)kh);
     }
@@ -337,17 +337,17 @@ int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64
         }
         if (mixed) {
             const ClassLists cl = class_lists(in, dp, per_row2 * (unsigned)in.n);
-            hipLaunchKernelGGL(ntt_inv_pass_mixed, dim3((unsigned)cl.in_blocks + per_row2 * dp.n), dim3(NTT_THREADS), 0, st,
+            hipLaunchKernelGGL((ntt_inv_pass_mixed<true>), dim3((unsigned)cl.in_blocks + per_row2 * dp.n), dim3(NTT_THREADS), 0, st,
                                (const i64 *)s, (i64 *)s, g, cl, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv,
                                pass == 1 ? 2 : TAIL_NONE, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
             continue;
         }
         if (dp.n)
-            hipLaunchKernelGGL(ntt_inv_pass_io<true>, dim3(per_row2 * dp.n), dim3(NTT_THREADS), 0, st, (const i64 *)s, (i64 *)s,
+            hipLaunchKernelGGL((ntt_inv_pass_io<true, true>), dim3(per_row2 * dp.n), dim3(NTT_THREADS), 0, st, (const i64 *)s, (i64 *)s,
                                g, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, pass == 1 ? 2 : TAIL_NONE,
                                (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
         if (in.n)
-            hipLaunchKernelGGL(ntt_inv_pass_io<false>, dim3(per_row2 * in.n), dim3(NTT_THREADS), 0, st, (const i64 *)s, (i64 *)s,
+            hipLaunchKernelGGL((ntt_inv_pass_io<false, true>), dim3(per_row2 * in.n), dim3(NTT_THREADS), 0, st, (const i64 *)s, (i64 *)s,
                                g, in, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, pass == 1 ? 2 : TAIL_NONE,
                                (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     }

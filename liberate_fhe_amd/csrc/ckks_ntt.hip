@@ -234,7 +234,7 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
         for (int pass = (S1 > 0 ? 0 : 1); pass < 2; ++pass) {
             if (only_pass && pass + 1 != only_pass) continue;   // measurement only: time one pass kernel by itself
             const PassGeom g = pass == 0 ? PassGeom{logN, tl, 1, S1, 0, tl - S1, rows, nb, relaxed, 0, plain, 1, 0}
-                                         : PassGeom{logN, tl, 0, tl, S1, 0, rows, nb, relaxed, 1, plain, 1, 0};
+                                         : PassGeom{logN, tl, 0, tl, S1, 0, rows, nb, relaxed, 1, plain, 1, 0, regtile_disabled()};
             const i64 *rs = (pass == 0 || S1 == 0) ? (const i64 *)Rs : nullptr;
             if (pass == 0 && S1 <= 4 && cols_enabled()) {   // leading stages: one register step per column
                 const unsigned col_blocks = (unsigned)nb * ((1u << (logN - S1)) / NTT_COL_THREADS);
@@ -252,17 +252,17 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
             }
             if (mixed) {
                 const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
-                hipLaunchKernelGGL(ntt_fwd_pass_mixed, dim3((unsigned)cl.in_blocks + per_row * dp.n), dim3(NTT_THREADS), 0, st,
+                LF_LAUNCH_MIXED(ntt_fwd_pass_mixed, relaxed, dim3((unsigned)cl.in_blocks + per_row * dp.n), dim3(NTT_THREADS), 0, st,
                                    base, g, cl, (const i64 *)psi_br, psi_dp, rs, (const i64 *)ql, (const i64 *)qh,
                                    (const i64 *)kl, (const i64 *)kh);
                 continue;
             }
             if (dp.n)
-                hipLaunchKernelGGL(ntt_fwd_pass<true>, dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, base, g, dp,
+                LF_LAUNCH_CLASS(ntt_fwd_pass, true, relaxed, dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, base, g, dp,
                                    (const i64 *)psi_br, psi_dp, rs, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl,
                                    (const i64 *)kh);
             if (in.n)
-                hipLaunchKernelGGL(ntt_fwd_pass<false>, dim3(per_row * in.n), dim3(NTT_THREADS), 0, st_int, base, g, in,
+                LF_LAUNCH_CLASS(ntt_fwd_pass, false, relaxed, dim3(per_row * in.n), dim3(NTT_THREADS), 0, st_int, base, g, in,
                                    (const i64 *)psi_br, psi_dp, rs, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl,
                                    (const i64 *)kh);
         }
@@ -307,7 +307,7 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
         i64 *base = (i64 *)a + ((i64)b0 * rows << logN);
         const unsigned per_row = (unsigned)nb << (logN - tl);
         for (int pass = 0; pass < (SB > 0 ? 2 : 1); ++pass) {
-            const PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, nb, relaxed, SB == 0, plain, 1, 0}
+            const PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, nb, relaxed, SB == 0, plain, 1, 0, regtile_disabled()}
                                          : PassGeom{logN, tl, 1, SB, tl, tl - SB, rows, nb, relaxed, 1, plain, 1, 0};
             const int t = g.last ? tail : TAIL_NONE;
             if (pass == 1 && SB <= 4 && cols_enabled()) {   // trailing stages + chain tail: one register step per column
@@ -326,17 +326,17 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
             }
             if (mixed) {
                 const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
-                hipLaunchKernelGGL(ntt_inv_pass_mixed, dim3((unsigned)cl.in_blocks + per_row * dp.n), dim3(NTT_THREADS), 0, st,
+                LF_LAUNCH_MIXED(ntt_inv_pass_mixed, relaxed, dim3((unsigned)cl.in_blocks + per_row * dp.n), dim3(NTT_THREADS), 0, st,
                                    (const i64 *)base, base, g, cl, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t,
                                    (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
                 continue;
             }
             if (dp.n)
-                hipLaunchKernelGGL(ntt_inv_pass_io<true>, dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, (const i64 *)base, base, g, dp,
+                LF_LAUNCH_CLASS(ntt_inv_pass_io, true, relaxed, dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, (const i64 *)base, base, g, dp,
                                    (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t, (const i64 *)ql, (const i64 *)qh,
                                    (const i64 *)kl, (const i64 *)kh);
             if (in.n)
-                hipLaunchKernelGGL(ntt_inv_pass_io<false>, dim3(per_row * in.n), dim3(NTT_THREADS), 0, st_int, (const i64 *)base, base, g, in,
+                LF_LAUNCH_CLASS(ntt_inv_pass_io, false, relaxed, dim3(per_row * in.n), dim3(NTT_THREADS), 0, st_int, (const i64 *)base, base, g, in,
                                    (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t, (const i64 *)ql, (const i64 *)qh,
                                    (const i64 *)kl, (const i64 *)kh);
         }

@@ -56,6 +56,7 @@ struct PassGeom {
                    // (Rs applies to integer-class limbs only), inverse tail multiplies by N^-1 instead of N^-1 R^-1
     int nsum;      // relaxed only: the input tile is the sum of `nsum` stacks (<= 1: plain load)
     i64 sum_stride;  // words between those stacks
+    int noreg;     // experiment knob (LF_NTT_REGTILE=0): 4096-word contiguous passes in the LDS-resident form
 };
 
 // tile-local index -> coefficient index of the row
@@ -367,13 +368,9 @@ struct StepTw {
     }
 };
 
+// the three stages of a forward radix-8 step on 8 words held in registers (x[e] = word at distance e << LOGDL)
 template <class A, int LOGDL>
-__device__ __forceinline__ void fwd_step8(typename A::T *sm, const StepTw<A, LOGDL> &tw, const Ctx &c) {
-    const int w = threadIdx.x;
-    const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
-    typename A::T x[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = sm[PAD(p + (e << LOGDL))];
+__device__ __forceinline__ void fwd_regs8(typename A::T (&x)[8], const StepTw<A, LOGDL> &tw, const Ctx &c) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) A::fwd(c, x[t], x[t + 4], tw.w0[0], tw.i0);
 #pragma unroll
@@ -383,6 +380,16 @@ __device__ __forceinline__ void fwd_step8(typename A::T *sm, const StepTw<A, LOG
 #pragma unroll
     for (int j = 0; j < 4; ++j) A::fwd(c, x[2 * j], x[2 * j + 1], tw.w2[j], (tw.i0 << 2) + j);
     A::fwd_end(c, x);
+}
+
+template <class A, int LOGDL>
+__device__ __forceinline__ void fwd_step8(typename A::T *sm, const StepTw<A, LOGDL> &tw, const Ctx &c) {
+    const int w = threadIdx.x;
+    const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
+    typename A::T x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = sm[PAD(p + (e << LOGDL))];
+    fwd_regs8<A, LOGDL>(x, tw, c);
 #pragma unroll
     for (int e = 0; e < 8; ++e) sm[PAD(p + (e << LOGDL))] = x[e];
 }
@@ -434,13 +441,9 @@ struct StepTwInv {
     }
 };
 
+// the three stages of an inverse radix-8 step on 8 words held in registers
 template <class A, int LOGDL>
-__device__ __forceinline__ void inv_step8(typename A::T *sm, const StepTwInv<A, LOGDL> &tw, const Ctx &c) {
-    const int w = threadIdx.x;
-    const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
-    typename A::T x[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = sm[PAD(p + (e << LOGDL))];
+__device__ __forceinline__ void inv_regs8(typename A::T (&x)[8], const StepTwInv<A, LOGDL> &tw, const Ctx &c) {
 #pragma unroll
     for (int h = 0; h < 4; ++h) A::inv(c, x[2 * h], x[2 * h + 1], tw.w0[h], (tw.il << 2) + h);
 #pragma unroll
@@ -450,6 +453,16 @@ __device__ __forceinline__ void inv_step8(typename A::T *sm, const StepTwInv<A, 
 #pragma unroll
     for (int t = 0; t < 4; ++t) A::inv(c, x[t], x[t + 4], tw.w2[0], tw.il);
     A::inv_end(c, x);
+}
+
+template <class A, int LOGDL>
+__device__ __forceinline__ void inv_step8(typename A::T *sm, const StepTwInv<A, LOGDL> &tw, const Ctx &c) {
+    const int w = threadIdx.x;
+    const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
+    typename A::T x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = sm[PAD(p + (e << LOGDL))];
+    inv_regs8<A, LOGDL>(x, tw, c);
 #pragma unroll
     for (int e = 0; e < 8; ++e) sm[PAD(p + (e << LOGDL))] = x[e];
 }
@@ -573,25 +586,272 @@ __device__ __forceinline__ void store_tile_raw(const i64 *sm, i64 *row, const Pa
 }
 
 // ------------------------------------------------------------------------------------------------
+// Register-fed 4096-word contiguous pass (tl = 12, S = 12): the tile never sits in LDS as raw words.
+//   forward: the first radix-8 step (distance 512) takes its 8 words straight from global memory (8-byte
+//            loads, 512 contiguous bytes per wave), the last one (8 consecutive words per thread) hands its
+//            results to the stores through the wave's OWN 512-word LDS span — no block barrier;
+//   inverse: mirror image (16-byte loads -> wave-private span -> 8 consecutive words; last step stores
+//            8-byte words 512 apart straight from registers, chain tail applied in registers).
+// Against the LDS-resident form this halves the LDS round trips per word (4 instead of 6-7) and leaves
+// 3 block barriers per tile instead of 6-7.  A tile holding a word outside [0, 2q) is detected before
+// anything is stored; the caller then runs the generic path on it (returns false, block-uniform).
+// ------------------------------------------------------------------------------------------------
+static_assert(NTT_THREADS == 512, "one flag byte per wave fills the 8-byte flag word");
+
+// wave v owns byte v of the flag word: every wave writes its byte, so no reset and no reset barrier
+__device__ __forceinline__ void wave_flag_set(i64 *sm, int pred) {
+    const bool any = __builtin_amdgcn_ballot_w64(pred != 0) != 0;
+    if ((threadIdx.x & 63) == 0) reinterpret_cast<unsigned char *>(sm + NTT_FLAG_WORD)[threadIdx.x >> 6] = any ? 1 : 0;
+}
+
+// LDS traffic of one wave is processed in order: a wave-private exchange needs no s_barrier
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// steps of the forward tile; x[e] = word (w + 512 e) on entry, word (8 w + e) on exit
+template <class A>
+__device__ __forceinline__ bool fwd_tile12_core(typename A::T *smt, i64 *sm, typename A::T (&x)[8], int s, int E, int base,
+                                                const Ctx &c) {
+    const int w = threadIdx.x;
+    StepTw<A, 9> t9;
+    StepTw<A, 6> t6;
+    StepTw<A, 3> t3;
+    StepTw<A, 0> t0;
+    t9.load(c, s, E, base);
+    fwd_regs8<A, 9>(x, t9, c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) smt[PAD(w + (e << 9))] = x[e];
+    t6.load(c, s + 3, E, base);
+    lds_barrier();
+    if (sm[NTT_FLAG_WORD] != 0) {
+        lds_barrier();   // every wave has read the flag before the generic path resets it
+        return false;
+    }
+    fwd_step8<A, 6>(smt, t6, c);
+    t3.load(c, s + 6, E, base);
+    lds_barrier();
+    fwd_step8<A, 3>(smt, t3, c);
+    t0.load(c, s + 9, E, base);
+    lds_barrier();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = smt[9 * w + e];
+    fwd_regs8<A, 0>(x, t0, c);
+    return true;
+}
+
+// 8 consecutive result words per thread -> global, 16 B per lane and 1 KiB contiguous per wave instruction
+__device__ __forceinline__ void store_tile12_regs(i64 *sm, const i64 (&o)[8], i64 *dst) {
+    const int w = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm[9 * w + e] = o[e];
+    wave_lds_sync();
+    const int L0 = ((w >> 6) << 9) + ((w & 63) << 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int L = L0 + (i << 7);
+        longlong2 v;
+        v.x = sm[PAD(L)];
+        v.y = sm[PAD(L + 1)];
+        *reinterpret_cast<longlong2 *>(dst + L) = v;
+    }
+}
+
+template <bool DP>
+__device__ __forceinline__ bool fwd_tile12(i64 *sm, i64 *__restrict__ row, int tile, const PassGeom &g, const Ctx &c,
+                                           bool enter, i64 rs) {
+    const int w = threadIdx.x;
+    const int base = tile << 12;
+    const i64 q2 = c.m.q2;
+    i64 raw[8];
+    {
+        const i64 *src = row + base + w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) raw[e] = src[e << 9];
+    }
+    int odd = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if (g.relaxed) raw[e] = raw[e] < 0 ? raw[e] + q2 : raw[e];   // residues only: fold the signed-lazy words
+        odd |= ((u64)raw[e] >= (u64)q2);
+    }
+    i64 o[8];
+    if (DP) {
+        double *smd = reinterpret_cast<double *>(sm);
+        double x[8];
+        const double r1 = enter ? (double)((1ull << 62) % c.m.q) : 0.0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            double v = dp_from_word(raw[e]);
+            if (enter) {   // Montgomery entry, emulated exactly: REDC62(a * R^2)
+                v = dp_mulmod(v, r1, c.d);
+                if (!g.relaxed && v < LAZY_FIX_LIMIT) v = dp_lazy_fix(v, (u64)raw[e], (u64)rs, c.d.q);
+            }
+            x[e] = v;
+        }
+        wave_flag_set(sm, g.relaxed ? 0 : odd);   // relaxed tiles accept any non-negative representative
+        const bool ok = g.relaxed ? fwd_tile12_core<ArithDpR>(smd, sm, x, g.s0, g.logN, base, c)
+                                  : fwd_tile12_core<ArithDp>(smd, sm, x, g.s0, g.logN, base, c);
+        if (!ok) return false;
+        // the pass accumulated without subtractions: back to the lazy word in [0, 2q) (relaxed: canonical residue)
+        const double md = g.relaxed ? c.d.q : c.d.q2, mi = g.relaxed ? c.d.qinv : c.d.q2inv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = dp_to_word(dp_reduce(x[e], md, mi));
+    } else {
+        if (enter) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                raw[e] = mm62s(raw[e], rs, c.m.q, c.m.k);
+                odd |= ((u64)raw[e] >= (u64)q2);
+            }
+        }
+        wave_flag_set(sm, odd);
+        if (!fwd_tile12_core<ArithInt<false>>(sm, sm, raw, g.s0, g.logN, base, c)) return false;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = raw[e];
+    }
+    store_tile12_regs(sm, o, row + base);
+    return true;
+}
+
+// steps of the inverse tile; x[e] = word (8 w + e) on entry, word (w + 512 e) on exit
+template <class A>
+__device__ __forceinline__ bool inv_tile12_core(typename A::T *smt, i64 *sm, typename A::T (&x)[8], int s, int logN, int base,
+                                                const Ctx &c) {
+    const int w = threadIdx.x;
+    Ctx cc = c;
+    StepTwInv<A, 0> t0;
+    StepTwInv<A, 3> t3;
+    StepTwInv<A, 6> t6;
+    StepTwInv<A, 9> t9;
+    // fp64 class: words double per stage; reduced mod 2q at the end of every second step (run_inv_stages)
+    t0.load(c, s, 0, logN, base);
+    cc.inv_reduce = 0;
+    inv_regs8<A, 0>(x, t0, cc);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) smt[9 * w + e] = x[e];
+    t3.load(c, s + 3, 0, logN, base);
+    lds_barrier();
+    if (sm[NTT_FLAG_WORD] != 0) {
+        lds_barrier();
+        return false;
+    }
+    cc.inv_reduce = 1;
+    inv_step8<A, 3>(smt, t3, cc);
+    t6.load(c, s + 6, 0, logN, base);
+    lds_barrier();
+    cc.inv_reduce = 0;
+    inv_step8<A, 6>(smt, t6, cc);
+    t9.load(c, s + 9, 0, logN, base);
+    lds_barrier();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = smt[PAD(w + (e << 9))];
+    cc.inv_reduce = 1;
+    inv_regs8<A, 9>(x, t9, cc);
+    return true;
+}
+
+// integer chain tail of one word (K.cu:527-529, 754-902)
+__device__ __forceinline__ i64 inv_tail_int(i64 t, int tail, i64 ninv, const Ctx &c) {
+    if (tail == TAIL_NONE) return t;
+    const i64 qq = (i64)c.m.q;
+    i64 z = mm62s(t, ninv, c.m.q, c.m.k);
+    if (tail >= 1) z = redc62(z, c.m.q, c.m.k);
+    if (tail >= 2) z = z < qq ? z : z - qq;
+    if (tail >= 3) z = z <= (qq >> 1) ? z : z - qq;
+    return z;
+}
+
+template <bool DP>
+__device__ __forceinline__ bool inv_tile12(i64 *sm, const i64 *src_row, i64 *dst_row, int tile, const PassGeom &g, const Ctx &c,
+                                           const i64 *__restrict__ Ninv, int tail, int crow) {
+    const int w = threadIdx.x;
+    const int base = tile << 12;
+    const i64 q2 = c.m.q2;
+    // 16-byte loads, 1 KiB contiguous per wave instruction, exchanged through the wave's own LDS span
+    const int L0 = ((w >> 6) << 9) + ((w & 63) << 1);
+    int odd = 0;
+    {
+        longlong2 in[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) in[i] = *reinterpret_cast<const longlong2 *>(src_row + base + L0 + (i << 7));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            longlong2 v = in[i];
+            if (g.relaxed) {
+                v.x = v.x < 0 ? v.x + q2 : v.x;
+                v.y = v.y < 0 ? v.y + q2 : v.y;
+            }
+            odd |= ((u64)v.x >= (u64)q2) | ((u64)v.y >= (u64)q2);
+            const int L = L0 + (i << 7);
+            sm[PAD(L)] = v.x;
+            sm[PAD(L + 1)] = v.y;
+        }
+    }
+    wave_flag_set(sm, odd);
+    wave_lds_sync();
+    i64 raw[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) raw[e] = sm[9 * w + e];
+    wave_lds_sync();   // the span is rewritten (as doubles) by the first step
+    i64 *out = dst_row + base + w;
+    if (DP) {
+        double *smd = reinterpret_cast<double *>(sm);
+        double x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = dp_from_word(raw[e]);
+        const bool ok = g.relaxed ? inv_tile12_core<ArithDpR>(smd, sm, x, g.s0, g.logN, base, c)
+                                  : inv_tile12_core<ArithDp>(smd, sm, x, g.s0, g.logN, base, c);
+        if (!ok) return false;
+        const int t_eff = tail;   // the caller passes TAIL_NONE unless this is the last pass
+        // chain tail: z = REDC(t * Ninv); [redc]; [reduce]; [signed]    (K.cu:527-529, 754-902)
+        const i64 qq = (i64)c.m.q;
+        const double ninv_plain = c.d.q - (double)((c.m.q - 1) >> g.logN);                  // N^-1 mod q
+        const double rinv = (double)(u64)((((u128)c.m.k * (u128)c.m.q) + 1) >> 62);         // R^-1 mod q
+        const double c2 = g.plain ? ninv_plain : dp_mulmod(ninv_plain, rinv, c.d);          // N^-1 (R^-1) mod q
+        const i64 ninv_mont = (t_eff != TAIL_NONE) ? Ninv[crow] : 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const double t = x[e];
+            double z;
+            if (t_eff == TAIL_NONE) {
+                z = g.relaxed ? dp_addmask(t, c.d.q) : t;   // relaxed words are balanced residues
+            } else if (t_eff >= 2) {
+                z = dp_mulmod(t, c2, c.d);
+                if (t_eff >= 3) z = z <= (double)(qq >> 1) ? z : z - c.d.q;
+            } else {
+                z = dp_mulmod(t, ninv_plain, c.d);
+                if (z < LAZY_FIX_LIMIT) z = dp_lazy_fix(z, (u64)t, (u64)ninv_mont, c.d.q);
+                if (t_eff == 1) z = (z == c.d.q) ? c.d.q : dp_mulmod(z, rinv, c.d);   // redc(q) = q (K.cu:587-606)
+            }
+            out[e << 9] = (t_eff >= 3) ? (i64)z : dp_to_word(z);
+        }
+    } else {
+        if (!inv_tile12_core<ArithInt<false>>(sm, sm, raw, g.s0, g.logN, base, c)) return false;
+        const int t_eff = tail;   // the caller passes TAIL_NONE unless this is the last pass
+        const i64 ninv = (t_eff != TAIL_NONE) ? Ninv[crow] : 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[e << 9] = inv_tail_int(raw[e], t_eff, ninv, c);
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward pass.  DP = true: fp64 class rows; false: integer class rows.
 // ------------------------------------------------------------------------------------------------
-template <bool DP>
-__device__ __forceinline__ void fwd_pass_body(i64 *sm, int b, i64 *__restrict__ a, const PassGeom &g, const RowList &rl,
+template <bool DP, bool RLX>
+__device__ __forceinline__ void fwd_pass_body(i64 *sm, int b, i64 *__restrict__ a, const PassGeom &g0, const RowList &rl,
                                               const i64 *__restrict__ psi_br, const double *__restrict__ psi_dp,
                                               const i64 *__restrict__ Rs, const i64 *__restrict__ ql,
                                               const i64 *__restrict__ qh, const i64 *__restrict__ kl,
                                               const i64 *__restrict__ kh) {
+    PassGeom g = g0;
+    g.relaxed = RLX ? 1 : 0;   // compile-time: each kernel carries one of the two arithmetic modes
     const int T = 1 << g.tl;
     const bool enter = (Rs != nullptr) && !(DP && g.plain);
-    // persistent block: a contiguous run of work items; the next tile's global loads are in flight
-    // while the current tile is transformed out of LDS
-    if (threadIdx.x == 0) sm[NTT_FLAG_WORD] = 0;   // both block_or flag words
-    lds_barrier();
-    longlong2 pre[NTT_PRE];
     int poly, crow, tile;
     block_coords(g, rl, b, poly, crow, tile);
-    prefetch_tile(pre, a + ((i64)(poly * g.rows + crow) << g.logN), g, tile);
-
     {
         const int item = 0;
         Ctx c;
@@ -600,9 +860,21 @@ __device__ __forceinline__ void fwd_pass_body(i64 *sm, int b, i64 *__restrict__ 
         c.tw_mont = psi_br + ((i64)crow << g.logN);
         c.tw_dp = DP ? psi_dp + ((i64)crow << g.logN) : nullptr;
         c.relaxed = g.relaxed;
+        c.inv_off = 0.0;
+        c.inv_reduce = 0;
         i64 *row = a + ((i64)(poly * g.rows + crow) << g.logN);
         const int cur_tile = tile;
         const i64 rs = enter ? Rs[crow] : 0;
+
+        // contiguous 4096-word pass: register-fed form; false = the tile holds a word outside [0, 2q)
+        if (g.tl == 12 && g.S == 12 && !g.strided && !g.noreg && g.nsum <= 1) {
+            if (fwd_tile12<DP>(sm, row, tile, g, c, enter, rs)) return;
+        }
+
+        if (threadIdx.x == 0) sm[NTT_FLAG_WORD] = 0;   // both block_or flag words
+        lds_barrier();
+        longlong2 pre[NTT_PRE];
+        prefetch_tile(pre, row, g, tile);
 
         const int odd_raw = stash_tile(sm, pre, g, c.m.q2);
         // relaxed fp64 tiles accept any non-negative residue representative
@@ -658,14 +930,14 @@ __device__ __forceinline__ void fwd_pass_body(i64 *sm, int b, i64 *__restrict__ 
     }
 }
 
-template <bool DP>
+template <bool DP, bool RLX>
 __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_fwd_pass(i64 *__restrict__ a, PassGeom g, RowList rl,
                                                             const i64 *__restrict__ psi_br, const double *__restrict__ psi_dp,
                                                             const i64 *__restrict__ Rs, const i64 *__restrict__ ql,
                                                             const i64 *__restrict__ qh, const i64 *__restrict__ kl,
                                                             const i64 *__restrict__ kh) {
     __shared__ i64 sm[NTT_LDS_WORDS + 1];
-    fwd_pass_body<DP>(sm, blockIdx.x, a, g, rl, psi_br, psi_dp, Rs, ql, qh, kl, kh);
+    fwd_pass_body<DP, RLX>(sm, blockIdx.x, a, g, rl, psi_br, psi_dp, Rs, ql, qh, kl, kh);
 }
 
 // Both arithmetic classes of one pass in ONE launch: the first `in_blocks` blocks (a multiple of 8, so the
@@ -677,6 +949,7 @@ struct ClassLists {
     int in_real;
 };
 
+template <bool RLX>
 __global__ void __launch_bounds__(NTT_THREADS, 6) ntt_fwd_pass_mixed(i64 *__restrict__ a, PassGeom g, ClassLists cl,
                                                                        const i64 *__restrict__ psi_br,
                                                                        const double *__restrict__ psi_dp,
@@ -686,9 +959,9 @@ __global__ void __launch_bounds__(NTT_THREADS, 6) ntt_fwd_pass_mixed(i64 *__rest
     __shared__ i64 sm[NTT_LDS_WORDS + 1];
     const int b = blockIdx.x;
     if (b < cl.in_blocks) {
-        if (b < cl.in_real) fwd_pass_body<false>(sm, b, a, g, cl.in, psi_br, psi_dp, Rs, ql, qh, kl, kh);
+        if (b < cl.in_real) fwd_pass_body<false, RLX>(sm, b, a, g, cl.in, psi_br, psi_dp, Rs, ql, qh, kl, kh);
     } else {
-        fwd_pass_body<true>(sm, b - cl.in_blocks, a, g, cl.dp, psi_br, psi_dp, Rs, ql, qh, kl, kh);
+        fwd_pass_body<true, RLX>(sm, b - cl.in_blocks, a, g, cl.dp, psi_br, psi_dp, Rs, ql, qh, kl, kh);
     }
 }
 
@@ -851,20 +1124,17 @@ __global__ void __launch_bounds__(NTT_COL_THREADS) ntt_fwd_cols_mixed_rs(i64 *__
 // ------------------------------------------------------------------------------------------------
 // inverse pass (+ fused chain tail on the last pass)
 // ------------------------------------------------------------------------------------------------
-template <bool DP>
-__device__ __forceinline__ void inv_pass_body(i64 *sm, int b, const i64 *src, i64 *dst, const PassGeom &g, const RowList &rl,
+template <bool DP, bool RLX>
+__device__ __forceinline__ void inv_pass_body(i64 *sm, int b, const i64 *src, i64 *dst, const PassGeom &g0, const RowList &rl,
                                               const i64 *__restrict__ ipsi_br, const double *__restrict__ ipsi_dp,
                                               const i64 *__restrict__ Ninv, int tail, const i64 *__restrict__ ql,
                                               const i64 *__restrict__ qh, const i64 *__restrict__ kl,
                                               const i64 *__restrict__ kh) {
+    PassGeom g = g0;
+    g.relaxed = RLX ? 1 : 0;
     const int T = 1 << g.tl;
-    if (threadIdx.x == 0) sm[NTT_FLAG_WORD] = 0;   // both block_or flag words
-    lds_barrier();
-    longlong2 pre[NTT_PRE];
     int poly, crow, tile;
     block_coords(g, rl, b, poly, crow, tile);
-    prefetch_tile(pre, src + ((i64)(poly * g.rows + crow) << g.logN), g, tile);
-
     {
         const int item = 0;
         Ctx c;
@@ -878,6 +1148,16 @@ __device__ __forceinline__ void inv_pass_body(i64 *sm, int b, const i64 *src, i6
         i64 *row = dst + ((i64)(poly * g.rows + crow) << g.logN);
         const int cur_tile = tile, cur_row = crow;
         const i64 qq = (i64)c.m.q;
+
+        // contiguous 4096-word pass: register-fed form; false = the tile holds a word outside [0, 2q)
+        if (g.tl == 12 && g.S == 12 && !g.strided && !g.noreg && g.nsum <= 1) {
+            if (inv_tile12<DP>(sm, src + ((i64)(poly * g.rows + crow) << g.logN), row, tile, g, c, Ninv, tail, crow)) return;
+        }
+
+        if (threadIdx.x == 0) sm[NTT_FLAG_WORD] = 0;   // both block_or flag words
+        lds_barrier();
+        longlong2 pre[NTT_PRE];
+        prefetch_tile(pre, src + ((i64)(poly * g.rows + crow) << g.logN), g, tile);
 
         const int odd_raw = stash_tile(sm, pre, g, c.m.q2);
         const bool odd = block_or(sm, odd_raw, item & 1);
@@ -947,16 +1227,17 @@ __device__ __forceinline__ void inv_pass_body(i64 *sm, int b, const i64 *src, i6
     }
 }
 
-template <bool DP>
+template <bool DP, bool RLX>
 __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_inv_pass_io(const i64 *src, i64 *dst, PassGeom g, RowList rl,
                                                             const i64 *__restrict__ ipsi_br,
                                                             const double *__restrict__ ipsi_dp, const i64 *__restrict__ Ninv,
                                                             int tail, const i64 *__restrict__ ql, const i64 *__restrict__ qh,
                                                             const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
     __shared__ i64 sm[NTT_LDS_WORDS + 1];
-    inv_pass_body<DP>(sm, blockIdx.x, src, dst, g, rl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh);
+    inv_pass_body<DP, RLX>(sm, blockIdx.x, src, dst, g, rl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh);
 }
 
+template <bool RLX>
 __global__ void __launch_bounds__(NTT_THREADS, 6) ntt_inv_pass_mixed(const i64 *src, i64 *dst, PassGeom g, ClassLists cl,
                                                                        const i64 *__restrict__ ipsi_br,
                                                                        const double *__restrict__ ipsi_dp,
@@ -966,9 +1247,9 @@ __global__ void __launch_bounds__(NTT_THREADS, 6) ntt_inv_pass_mixed(const i64 *
     __shared__ i64 sm[NTT_LDS_WORDS + 1];
     const int b = blockIdx.x;
     if (b < cl.in_blocks) {
-        if (b < cl.in_real) inv_pass_body<false>(sm, b, src, dst, g, cl.in, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh);
+        if (b < cl.in_real) inv_pass_body<false, RLX>(sm, b, src, dst, g, cl.in, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh);
     } else {
-        inv_pass_body<true>(sm, b - cl.in_blocks, src, dst, g, cl.dp, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh);
+        inv_pass_body<true, RLX>(sm, b - cl.in_blocks, src, dst, g, cl.dp, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh);
     }
 }
 
@@ -990,17 +1271,6 @@ __device__ __forceinline__ void cols_inv_stages(typename A::T (&x)[1 << K], cons
             for (int t = 0; t < du; ++t) A::inv(c, x[e0 + t], x[e0 + t + du], wv, idx);
         }
     }
-}
-
-// integer chain tail of one word (K.cu:527-529, 754-902)
-__device__ __forceinline__ i64 inv_tail_int(i64 t, int tail, i64 ninv, const Ctx &c) {
-    if (tail == TAIL_NONE) return t;
-    const i64 qq = (i64)c.m.q;
-    i64 z = mm62s(t, ninv, c.m.q, c.m.k);
-    if (tail >= 1) z = redc62(z, c.m.q, c.m.k);
-    if (tail >= 2) z = z < qq ? z : z - qq;
-    if (tail >= 3) z = z <= (qq >> 1) ? z : z - qq;
-    return z;
 }
 
 template <bool DP, int K>
@@ -1163,6 +1433,28 @@ inline bool cols_enabled() {
         on = e ? atoi(e) != 0 : 1;
     }
     return on != 0;
+}
+
+// the tiled-pass kernels carry their arithmetic mode (exact lazy words / relaxed residues) as a template parameter
+#define LF_LAUNCH_MIXED(KERN, relaxed, ...)                                   \
+    do {                                                                      \
+        if (relaxed) hipLaunchKernelGGL((KERN<true>), __VA_ARGS__);           \
+        else hipLaunchKernelGGL((KERN<false>), __VA_ARGS__);                  \
+    } while (0)
+#define LF_LAUNCH_CLASS(KERN, DP, relaxed, ...)                               \
+    do {                                                                      \
+        if (relaxed) hipLaunchKernelGGL((KERN<DP, true>), __VA_ARGS__);       \
+        else hipLaunchKernelGGL((KERN<DP, false>), __VA_ARGS__);              \
+    } while (0)
+
+// experiment knob: LF_NTT_REGTILE=0 runs the 4096-word contiguous passes in the LDS-resident form
+inline int regtile_disabled() {
+    static int off = -1;
+    if (off < 0) {
+        const char *e = getenv("LF_NTT_REGTILE");
+        off = (e && atoi(e) == 0) ? 1 : 0;
+    }
+    return off;
 }
 
 // plain canonical twiddles as doubles from the Montgomery table: w = reduce(redc(S))

@@ -147,6 +147,47 @@ def test_ntt_family_bit_exact(mods, logN):
             assert (want_i == xc).all(), "round trip must be the identity"
 
 
+@pytest.mark.parametrize("logN", [12, 13, 16])
+def test_ntt_tiles_with_out_of_range_words(mods, logN):
+    """A 4096-word tile holding a word outside [0, 2q) leaves the register-fed fp64 form before anything is
+    stored and is redone by the signed integer routine; its neighbours stay on the fast form.  Both must equal
+    the oracle (which follows the reference's signed arithmetic literally)."""
+    nc, orc = mods
+    lim = Limbs(logN, pick_primes(logN, 2, 1))
+    C = lim.rows
+    psi, ipsi = lim.mont_tables()
+    d = lambda v: [dev(v)]
+    consts = [d(lim._2q), d(lim.ql), d(lim.qh), d(lim.kl), d(lim.kh)]
+    x = lim.uniform(77 + logN, lazy=True)
+    for r, q in enumerate(lim.q):
+        x[r, 5] = -(q - 3)                 # negative lazy word in the first tile
+        x[r, lim.N - 4096 + 4095] = 2 * q + 1 if r != 1 else x[r, lim.N - 1]   # one row keeps a clean last tile
+        if lim.N > 8192:
+            x[r, 4096 + 513] = 2 * q       # boundary word, second tile
+    want = x.copy()
+    orc.ntt(want, psi, C, logN, lim._2q, *lim.mont_args())
+    t = d(x)
+    nc.ntt(t, [None], [None], d(psi), *consts)
+    assert (t[0].cpu().numpy() == want).all(), "ntt"
+
+    y = lim.uniform(78 + logN, lazy=True)
+    for r, q in enumerate(lim.q):
+        y[r, 9] = -1
+        y[r, lim.N - 7] = 2 * q + 5
+    for tail, name in enumerate(("intt", "intt_exit", "intt_exit_reduce", "intt_exit_reduce_signed")):
+        want_i = y.copy()
+        orc.intt(want_i, ipsi, lim.Ninv, C, logN, lim._2q, *lim.mont_args())
+        if tail >= 1:
+            orc.mont_redc(want_i, C, *lim.mont_args())
+        if tail >= 2:
+            orc.reduce_2q(want_i, C, lim._2q)
+        if tail >= 3:
+            orc.make_signed(want_i, C, lim._2q)
+        t = d(y)
+        getattr(nc, name)(t, [None], [None], d(ipsi), d(lim.Ninv), *consts)
+        assert (t[0].cpu().numpy() == want_i).all(), name
+
+
 def test_ntt_extent_is_constant_rows(mods):
     """NTT-family ops transform ql.size(0) rows and leave further rows of `a` alone (K.cu:298)."""
     nc, orc = mods
