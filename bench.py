@@ -195,8 +195,10 @@ def main():
     psi_dp = twiddles.dp_pointer(psi, ql, qh, kl, kh, local_rank, stream)
     q_host = np.array([ctx.q[i] for i in rows_idx], dtype=np.int64)
 
+    ntt_flags = int(os.environ.get("LF_BENCH_NTT_FLAGS", "0"))   # experiments only: 1 = relaxed transform (not the metric)
+
     def step():
-        check(lib.lf_ntt(x.data_ptr(), B, L_LIMBS, LOGN, psi.data_ptr(), psi_dp, q_host.ctypes.data, 0, 0, q2.data_ptr(), ql.data_ptr(),
+        check(lib.lf_ntt(x.data_ptr(), B, L_LIMBS, LOGN, psi.data_ptr(), psi_dp, q_host.ctypes.data, 0, ntt_flags, q2.data_ptr(), ql.data_ptr(),
                          qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), local_rank, stream), "lf_ntt")
 
     for _ in range(args.warmup):

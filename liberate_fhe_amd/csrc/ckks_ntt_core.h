@@ -176,12 +176,19 @@ __device__ __forceinline__ double dp_reduce_bal(double x, const RowDp &m) {
     return __builtin_fma(-__builtin_rint(x * m.qinv), m.q, x);
 }
 
-// x mod m for 0 <= x < 2^52 (m = q or 2q, minv its reciprocal)
+// x mod m in [0, m) for an integer x (either sign) with |x| < 64 m, m = q or 2q < 2^43, minv its reciprocal: three
+// fp64 instructions.  floor(x * minv + 2^-44) IS floor(x / m): the fma's total error is below 2^-46 for quotients
+// under 64, the bias lifts exact multiples of m over their integer, and a remainder of m - 1 still stays 2^-43 short
+// of the next one.  (rint + fma + the three-instruction sign fix cost six.)
+#define DP_FLOOR_BIAS 5.684341886080802e-14   // 2^-44
 __device__ __forceinline__ double dp_reduce(double x, double m, double minv) {
-    const double quo = __builtin_rint(x * minv);
-    const double r = __builtin_fma(-quo, m, x);
-    return dp_addmask(r, m);
+    const double quo = __builtin_floor(__builtin_fma(x, minv, DP_FLOOR_BIAS));
+    return __builtin_fma(-quo, m, x);
 }
+
+// v < 2^22 for a canonical v >= 0, as one 32-bit compare on the high word (an fp64 compare costs twice as much);
+// -0.0 counts as below, like +0.0
+__device__ __forceinline__ bool dp_below_fix_limit(double v) { return __double2hiint(v) < 0x41500000; }
 
 // The reference's lazy representative of REDC62(A*B) given its canonical value t0 (< 2^22):
 // t0 + q iff t0 * 2^62 < A*B (integer operands A, B as the reference multiplies them).
@@ -264,7 +271,7 @@ struct ArithDp {
     // lazy REDC62(S * O) for O = o (any representative < 2^52 of the lazy word mod 2q)
     static __device__ __forceinline__ T mul(const Ctx &c, W w, T o, int idx) {
         T v = dp_mulmod(o, w, c.d);
-        if (!c.relaxed && v < LAZY_FIX_LIMIT)
+        if (!c.relaxed && dp_below_fix_limit(v))
             v = dp_lazy_fix(v, (u64)c.tw_mont[idx], (u64)dp_reduce(o, c.d.q2, c.d.q2inv), c.d.q);
         return v;
     }
@@ -686,7 +693,7 @@ __device__ __forceinline__ bool fwd_tile12(i64 *sm, i64 *__restrict__ row, int t
             double v = dp_from_word(raw[e]);
             if (enter) {   // Montgomery entry, emulated exactly: REDC62(a * R^2)
                 v = dp_mulmod(v, r1, c.d);
-                if (!g.relaxed && v < LAZY_FIX_LIMIT) v = dp_lazy_fix(v, (u64)raw[e], (u64)rs, c.d.q);
+                if (!g.relaxed && dp_below_fix_limit(v)) v = dp_lazy_fix(v, (u64)raw[e], (u64)rs, c.d.q);
             }
             x[e] = v;
         }
@@ -822,7 +829,7 @@ __device__ __forceinline__ bool inv_tile12(i64 *sm, const i64 *src_row, i64 *dst
                 if (t_eff >= 3) z = z <= (double)(qq >> 1) ? z : z - c.d.q;
             } else {
                 z = dp_mulmod(t, ninv_plain, c.d);
-                if (z < LAZY_FIX_LIMIT) z = dp_lazy_fix(z, (u64)t, (u64)ninv_mont, c.d.q);
+                if (dp_below_fix_limit(z)) z = dp_lazy_fix(z, (u64)t, (u64)ninv_mont, c.d.q);
                 if (t_eff == 1) z = (z == c.d.q) ? c.d.q : dp_mulmod(z, rinv, c.d);   // redc(q) = q (K.cu:587-606)
             }
             out[e << 9] = (t_eff >= 3) ? (i64)z : dp_to_word(z);
@@ -891,7 +898,7 @@ __device__ __forceinline__ void fwd_pass_body(i64 *sm, int b, i64 *__restrict__ 
                     double v = dp_from_word(raw);
                     if (enter) {
                         v = dp_mulmod(v, r1, c.d);
-                        if (!g.relaxed && v < LAZY_FIX_LIMIT) v = dp_lazy_fix(v, (u64)raw, (u64)rs, c.d.q);
+                        if (!g.relaxed && dp_below_fix_limit(v)) v = dp_lazy_fix(v, (u64)raw, (u64)rs, c.d.q);
                     }
                     smd[PAD(L + e)] = v;
                 }
@@ -1057,7 +1064,7 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
             double v = dp_from_word(w[k]);
             if (enter) {   // Montgomery entry, emulated exactly: REDC62(a * R^2)
                 v = dp_mulmod(v, r1, c.d);
-                if (!g.relaxed && v < LAZY_FIX_LIMIT) v = dp_lazy_fix(v, (u64)w[k], (u64)rs, c.d.q);
+                if (!g.relaxed && dp_below_fix_limit(v)) v = dp_lazy_fix(v, (u64)w[k], (u64)rs, c.d.q);
             }
             x[k] = v;
         }
@@ -1192,7 +1199,7 @@ __device__ __forceinline__ void inv_pass_body(i64 *sm, int b, const i64 *src, i6
                         if (tail >= 3) z = z <= (double)(qq >> 1) ? z : z - c.d.q;
                     } else {
                         z = dp_mulmod(t, ninv_plain, c.d);
-                        if (z < LAZY_FIX_LIMIT) z = dp_lazy_fix(z, (u64)t, (u64)ninv_mont, c.d.q);
+                        if (dp_below_fix_limit(z)) z = dp_lazy_fix(z, (u64)t, (u64)ninv_mont, c.d.q);
                         if (tail == 1) z = (z == c.d.q) ? c.d.q : dp_mulmod(z, rinv, c.d);   // redc(q) = q (K.cu:587-606)
                     }
                     o[e] = (tail >= 3) ? (i64)z : dp_to_word(z);
@@ -1326,7 +1333,7 @@ __device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const 
             } else {
                 const double tr = dp_reduce(t, c.d.q2, c.d.q2inv);   // the reference's lazy word
                 z = dp_mulmod(tr, ninv_plain, c.d);
-                if (z < LAZY_FIX_LIMIT) z = dp_lazy_fix(z, (u64)tr, (u64)ninv_mont, c.d.q);
+                if (dp_below_fix_limit(z)) z = dp_lazy_fix(z, (u64)tr, (u64)ninv_mont, c.d.q);
                 if (tail == 1) z = (z == c.d.q) ? c.d.q : dp_mulmod(z, rinv, c.d);   // redc(q) = q (K.cu:587-606)
             }
             col[(i64)k << logC] = (tail >= 3) ? (i64)z : dp_to_word(z);
