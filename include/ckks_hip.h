@@ -184,6 +184,16 @@ int lf_ks_moddown_batch(const int64_t *const *s, int64_t *const *out, const int6
                         const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
                         int device, void *stream);
 
+/* lf_ks_moddown_batch with a caller-provided workspace `ws` of at least lf_ks_moddown_ws_words(count, ell, K, N)
+ * int64 words: the elimination among the K special rows (ckks_engine.py:850-870) is evaluated once per coefficient
+ * by a first launch instead of once per row chunk, and the fp64-class rows take the closed form
+ * (s - sum_j p_j prod_{i<j} P_i) / P.  Same canonical outputs; s is not modified. */
+int64_t lf_ks_moddown_ws_words(int count, int ell, int K, int64_t N);
+int lf_ks_moddown_ws(const int64_t *const *s, int64_t *const *out, const int64_t *const *addend, int count, int ell, int K,
+                     int64_t N, int64_t *ws, int64_t ws_words, const int64_t *PiR, const double *PiP, const int64_t *Rs,
+                     int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+                     const int64_t *kh, int device, void *stream);
+
 /* Galois permutation in gather form, so that rotate / conjugate need no permutation pass of their own
  * (switch_key / rotate_single, ckks_engine.py:939-961, 1180-1206; encdec.py:224-270):
  *   lf_ks_digits_galois  = lf_ks_digits of a(X^p);  lf_ks_moddown_batch with gal_pinv != 0 adds addend(X^p).

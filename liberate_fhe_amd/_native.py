@@ -48,6 +48,8 @@ _SIGNATURES = {
     "lf_ks_moddown": [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_rescale_batch": [_P, _P, _P, _I, _I, _L, _P, _L, _P, _P, _P, _P, _I, _P],
     "lf_ks_moddown_batch": [_P, _P, _P, _I, _I, _I, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _P],
+    "lf_ks_moddown_ws": [_P, _P, _P, _I, _I, _I, _L, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _P],
+    "lf_ks_moddown_ws_words": [_I, _I, _I, _L],
     "lf_ks_digits_galois": [_P, _P, _I, _P, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P],
     "lf_galois_batch": [_P, _P, _I, _I, _I, _L, _P, _I, _P],
     "lf_rescale_ntt": [_P, _P, _I, _P, _I, _I, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P],
@@ -63,7 +65,7 @@ _SIGNATURES = {
 for _name, _args in _SIGNATURES.items():
     _fn = getattr(lib, _name)
     _fn.argtypes = _args
-    _fn.restype = ctypes.c_int
+    _fn.restype = ctypes.c_int64 if _name.endswith("_words") else ctypes.c_int
 
 
 class HipError(RuntimeError):

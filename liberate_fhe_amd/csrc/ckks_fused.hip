@@ -9,6 +9,7 @@
 // stays in registers across the whole chain instead of round-tripping through HBM per op.
 #include "../../include/ckks_hip.h"
 #include "ckks_common.h"
+#include <stdlib.h>
 
 #define KS_MAX_ALPHA 8   // limbs per key-switch digit (= number of special primes, <= 6 in the presets)
 #define KS_MAX_K 8
@@ -302,9 +303,179 @@ __global__ void __launch_bounds__(256) ks_moddown_kernel(PtrBatch pb, int ell, i
     }
 }
 
+// ---- mod-down with a workspace: the special-prime chain is evaluated ONCE per coefficient -----------------
+// ks_moddown_kernel recomputes the chain among the K special rows in every 8-row chunk (5 times at gold: half
+// of its instructions).  Here a first small launch leaves, in a caller-provided workspace,
+//   piv[c][j][.]  the pivots p_0 .. p_{K-1} of every coefficient (mixed-radix digits of the special part:
+//                 X = p_0 + P_0 (p_1 + P_1 (p_2 + ..))), and
+//   per ordinary fp64-class row r the plain constants
+//                 B_j[r] = prod_{i<j} P_i mod q_r,  A_j[r] = 2^31 B_j[r] mod q_r,  Pinv[r] = prod_j P_j^-1 mod q_r;
+// the second launch then evaluates, two coefficients per thread,
+//   fp64 class : out = (s_r - sum_j (ph_j A_j + pl_j B_j)) * Pinv  — 2K balanced products and one canonical product
+//                per word instead of the chained form's 2K canonical ones; the canonical residue is the same number;
+//   integer    : the reference's chain with REDC62, word for word (ckks_engine.py:850-901).
+// (A single-launch form — wave 0 of a 64-coefficient block runs the chain, one barrier, four waves share the rows
+// — was measured slower than the chunked kernel, 63 vs 53 us at gold: one word per lane and the chain's latency
+// in front of every block.)
+#define MD3_ROWS 4
+
+// workspace layout (words): [count][K][N] pivots, then (2K + 1) x ell doubles
+__global__ void __launch_bounds__(256) ks_pivots_kernel(PtrBatch pb, int count, int ell, int K, i64 N, i64 *__restrict__ ws,
+                                                        const i64 *__restrict__ PiR, const double *__restrict__ PiP,
+                                                        const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                        const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    const int rows = ell + K;
+    if ((int)blockIdx.y == count) {
+        // constants of the ordinary rows (one block)
+        if (blockIdx.x != 0 || PiP == nullptr) return;
+        double *cst = reinterpret_cast<double *>(ws + (i64)count * K * N);
+        const double two31 = 2147483648.0;
+        for (int r = threadIdx.x; r < ell; r += 256) {
+            const RowMod m = load_mod(ql, qh, kl, kh, r);
+            const bool dp = m.q < (1ull << 41);
+            const double q = (double)m.q, qinv = 1.0 / q;
+            double B = 1.0, pinv = 1.0;
+            for (int pi = 0; pi < K; ++pi) {
+                cst[(2 * pi) * ell + r] = dp ? dp_mulmod_q(B, two31, q, qinv) : 0.0;   // A_pi
+                cst[(2 * pi + 1) * ell + r] = dp ? B : 0.0;                             // B_pi
+                if (dp) {
+                    // P_pi mod q_r from its 31-bit halves, then the running product
+                    const int t = ell + K - 1 - pi;
+                    double Pm = dp_mulmod_q((double)qh[t], two31, q, qinv) + (double)ql[t];
+                    Pm = Pm >= q ? Pm - q : Pm;
+                    Pm = Pm >= q ? Pm - q : Pm;
+                    B = dp_mulmod_q(B, Pm, q, qinv);
+                    pinv = dp_mulmod_q(pinv, PiP[(i64)pi * rows + r], q, qinv);
+                }
+            }
+            cst[(2 * K) * ell + r] = dp ? pinv : 0.0;
+        }
+        return;
+    }
+    const i64 *__restrict__ s = pb.in[blockIdx.y];
+    const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    i64 sp[KS_MAX_K];
+#pragma unroll
+    for (int t = 0; t < KS_MAX_K; ++t)
+        if (t < K) sp[t] = s[(i64)(ell + t) * N + j];
+    // special rows among themselves (plain form): the reference's elimination, last prime first
+#pragma unroll
+    for (int pi = 0; pi < KS_MAX_K; ++pi) {
+        if (pi < K) {
+            const int t = K - 1 - pi;
+            i64 P = 0;
+#pragma unroll
+            for (int u = 0; u < KS_MAX_K; ++u)
+                if (u == t) P = sp[u];
+            ws[((i64)blockIdx.y * K + pi) * N + j] = P;
+#pragma unroll
+            for (int u = 0; u < KS_MAX_K; ++u) {
+                if (u < t) {
+                    const RowMod m = load_mod(ql, qh, kl, kh, ell + u);
+                    i64 d = csub(sp[u] + m.q2 - P, m.q2);
+                    d = mm62s(d, PiR[(i64)pi * rows + ell + u], m.q, m.k);
+                    sp[u] = d < (i64)m.q ? d : d - (i64)m.q;
+                }
+            }
+        }
+    }
+}
+
+// KK = K as a compile-time constant: the pivot halves live in 4 K doubles per thread, nothing is reserved for
+// the K the call does not have (8 slots cost 142 VGPRs = 3 waves per SIMD)
+template <int KK>
+__global__ void __launch_bounds__(256) ks_moddown_ws_kernel(PtrBatch pb, int count, int ell, i64 N, i64 gal_pinv,
+                                                            const i64 *__restrict__ gal_2q, const i64 *__restrict__ ws,
+                                                            const i64 *__restrict__ PiR, const i64 *__restrict__ Rs,
+                                                            int use_dp, const i64 *__restrict__ ql,
+                                                            const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                                            const i64 *__restrict__ kh) {
+    const i64 *__restrict__ s = pb.in[blockIdx.z];
+    const i64 *__restrict__ addend = pb.aux[blockIdx.z];
+    i64 *__restrict__ out = pb.out[blockIdx.z];
+    const i64 j = ((i64)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (j >= N) return;
+    const int rows = ell + KK;
+    const double *__restrict__ cst = reinterpret_cast<const double *>(ws + (i64)count * KK * N);
+    const i64 *__restrict__ piv = ws + (i64)blockIdx.z * KK * N + j;
+    double ph[KK][2], pl[KK][2];
+#pragma unroll
+    for (int pi = 0; pi < KK; ++pi) {
+        const longlong2 pv = *reinterpret_cast<const longlong2 *>(piv + (i64)pi * N);
+        ph[pi][0] = (double)(unsigned)(pv.x >> 31); pl[pi][0] = (double)(unsigned)(pv.x & 0x7fffffffll);
+        ph[pi][1] = (double)(unsigned)(pv.y >> 31); pl[pi][1] = (double)(unsigned)(pv.y & 0x7fffffffll);
+    }
+    const int r0 = blockIdx.y * MD3_ROWS;
+    const int r1 = r0 + MD3_ROWS < ell ? r0 + MD3_ROWS : ell;
+    longlong2 sv = *reinterpret_cast<const longlong2 *>(s + (i64)r0 * N + j);
+    for (int r = r0; r < r1; ++r) {
+        const int rn = r + 1 < r1 ? r + 1 : r;
+        const longlong2 sv_n = *reinterpret_cast<const longlong2 *>(s + (i64)rn * N + j);   // requested before this row's arithmetic
+        const RowMod m = load_mod(ql, qh, kl, kh, r);
+        i64 d[2];
+        if (use_dp && m.q < (1ull << 41)) {
+            const double q = (double)m.q, qinv = 1.0 / q;
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int pi = 0; pi < KK; ++pi) {
+                const double wa = cst[(2 * pi) * ell + r], wb = cst[(2 * pi + 1) * ell + r];
+                // balanced products (no sign fix): |.| <= q / 2 each
+                double hi = ph[pi][0] * wa, lo = __builtin_fma(ph[pi][0], wa, -hi);
+                acc0 += __builtin_fma(-__builtin_rint(hi * qinv), q, hi) + lo;
+                hi = pl[pi][0] * wb; lo = __builtin_fma(pl[pi][0], wb, -hi);
+                acc0 += __builtin_fma(-__builtin_rint(hi * qinv), q, hi) + lo;
+                hi = ph[pi][1] * wa; lo = __builtin_fma(ph[pi][1], wa, -hi);
+                acc1 += __builtin_fma(-__builtin_rint(hi * qinv), q, hi) + lo;
+                hi = pl[pi][1] * wb; lo = __builtin_fma(pl[pi][1], wb, -hi);
+                acc1 += __builtin_fma(-__builtin_rint(hi * qinv), q, hi) + lo;
+            }
+            const double pinv = cst[(2 * KK) * ell + r];
+            // s canonical (< 2^41): exact int <-> double through the 2^52 trick; |s - acc| <= (K + 1) q
+            const double s0 = __longlong_as_double(sv.x | 0x4330000000000000ll) - 4503599627370496.0;
+            const double s1 = __longlong_as_double(sv.y | 0x4330000000000000ll) - 4503599627370496.0;
+            d[0] = __double_as_longlong(dp_mulmod_q(s0 - acc0, pinv, q, qinv) + 4503599627370496.0) & 0x000FFFFFFFFFFFFFll;
+            d[1] = __double_as_longlong(dp_mulmod_q(s1 - acc1, pinv, q, qinv) + 4503599627370496.0) & 0x000FFFFFFFFFFFFFll;
+        } else {
+            const i64 rs = Rs[r];
+            d[0] = mm62s(sv.x, rs, m.q, m.k);
+            d[1] = mm62s(sv.y, rs, m.q, m.k);
+            for (int pi = 0; pi < KK; ++pi) {
+                const longlong2 pv = *reinterpret_cast<const longlong2 *>(piv + (i64)pi * N);   // rare rows: re-read
+                const i64 pir = PiR[(i64)pi * rows + r];
+                const i64 Q0 = mm62s(pv.x, rs, m.q, m.k), Q1 = mm62s(pv.y, rs, m.q, m.k);
+                d[0] = mm62s(csub(d[0] + m.q2 - Q0, m.q2), pir, m.q, m.k);
+                d[1] = mm62s(csub(d[1] + m.q2 - Q1, m.q2), pir, m.q, m.k);
+                d[0] = d[0] < (i64)m.q ? d[0] : d[0] - (i64)m.q;
+                d[1] = d[1] < (i64)m.q ? d[1] : d[1] - (i64)m.q;
+            }
+            d[0] = redc62(d[0], m.q, m.k);
+            d[1] = redc62(d[1], m.q, m.k);
+            d[0] = d[0] < (i64)m.q ? d[0] : d[0] - (i64)m.q;
+            d[1] = d[1] < (i64)m.q ? d[1] : d[1] - (i64)m.q;
+        }
+        if (addend) {
+            const i64 g2 = gal_2q ? gal_2q[r] : 0;
+            d[0] += galois_read(addend + (i64)r * N, j, N, gal_pinv, g2);
+            d[1] += galois_read(addend + (i64)r * N, j + 1, N, gal_pinv, g2);
+            d[0] = d[0] < (i64)m.q ? d[0] : d[0] - (i64)m.q;
+            d[1] = d[1] < (i64)m.q ? d[1] : d[1] - (i64)m.q;
+        }
+        longlong2 o;
+        o.x = d[0];
+        o.y = d[1];
+        *reinterpret_cast<longlong2 *>(out + (i64)r * N + j) = o;
+        sv = sv_n;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int64_t lf_ks_moddown_ws_words(int count, int ell, int K, int64_t N) {
+    return (int64_t)count * K * N + (int64_t)(2 * K + 1) * ell;
+}
 
 int lf_rescale_batch(const int64_t *const *in, const int64_t *const *row0, int64_t *const *out, int count, int rows,
                      int64_t N, const int64_t *scales, int64_t round_at, const int64_t *ql, const int64_t *qh,
@@ -404,6 +575,37 @@ int lf_ks_moddown_batch(const int64_t *const *s, int64_t *const *out, const int6
     hipLaunchKernelGGL(ks_moddown_kernel, grid, dim3(256), 0, (hipStream_t)stream, pb, ell, K, (i64)N, (i64)gal_pinv,
                        (const i64 *)gal_2q, (const i64 *)PiR, PiP,
                        (const i64 *)Rs, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+    return (int)hipGetLastError();
+}
+
+int lf_ks_moddown_ws(const int64_t *const *s, int64_t *const *out, const int64_t *const *addend, int count, int ell, int K,
+                     int64_t N, int64_t *ws, int64_t ws_words, const int64_t *PiR, const double *PiP, const int64_t *Rs,
+                     int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+                     const int64_t *kh, int device, void *stream) {
+    if (count < 0 || count > LF_BATCH_MAX || ell < 0 || K < 1 || K > KS_MAX_K || N < 2 || (N & 1)) return LF_ERR_ARG;
+    if (gal_pinv < 0 || gal_pinv >= 2 * N || (gal_pinv && (!(gal_pinv & 1) || (N & (N - 1))))) return LF_ERR_ARG;
+    if (!ws || ws_words < lf_ks_moddown_ws_words(count, ell, K, N)) return LF_ERR_ARG;
+    if (count == 0 || ell == 0) return 0;
+    if (int e = lf_set_device(device)) return e;
+    PtrBatch pb;
+    for (int i = 0; i < count; ++i)
+        pb.in[i] = (const i64 *)s[i], pb.aux[i] = addend ? (const i64 *)addend[i] : nullptr, pb.out[i] = (i64 *)out[i];
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g1((unsigned)((N + 255) / 256), (unsigned)count + 1u);
+    hipLaunchKernelGGL(ks_pivots_kernel, g1, dim3(256), 0, st, pb, count, ell, K, (i64)N, (i64 *)ws, (const i64 *)PiR, PiP,
+                       (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+    dim3 g2((unsigned)((N / 2 + 255) / 256), (unsigned)((ell + MD3_ROWS - 1) / MD3_ROWS), (unsigned)count);
+#define LF_MD_CASE(KK)                                                                                               \
+    case KK:                                                                                                         \
+        hipLaunchKernelGGL((ks_moddown_ws_kernel<KK>), g2, dim3(256), 0, st, pb, count, ell, (i64)N, (i64)gal_pinv,  \
+                           (const i64 *)gal_2q, (const i64 *)ws, (const i64 *)PiR, (const i64 *)Rs,                  \
+                           PiP != nullptr ? 1 : 0, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl,                \
+                           (const i64 *)kh);                                                                         \
+        break;
+    switch (K) {
+        LF_MD_CASE(1) LF_MD_CASE(2) LF_MD_CASE(3) LF_MD_CASE(4) LF_MD_CASE(5) LF_MD_CASE(6) LF_MD_CASE(7) LF_MD_CASE(8)
+    }
+#undef LF_MD_CASE
     return (int)hipGetLastError();
 }
 

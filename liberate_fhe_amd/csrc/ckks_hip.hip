@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) galois_kernel(GaloisBatch gb, int logN, i
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int lf_abi_version(void) { return 4; }
+int lf_abi_version(void) { return 5; }
 
 int lf_mont_mult(const int64_t *a, const int64_t *b, int64_t *c, int rows, int64_t N, const int64_t *ql,
                  const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {

@@ -102,6 +102,19 @@ class HipBackend:
                                       0 if PiP is None else PiP.data_ptr(), _p(Rs), pinv, _p(g2q), *c.mont(), dev, st),
               "lf_ks_moddown_batch")
 
+    def ks_moddown_ws(self, ss, outs, addends, ell, K, ws, PiR, Rs, c: Consts, PiP=None, galois=None):
+        """ks_moddown_batch with a workspace tensor `ws` (int64, >= moddown_ws_words(..) words): the special-prime
+        chain is evaluated once per coefficient by a first launch."""
+        dev, st = _ds(outs[0])
+        pinv, g2q = (0, None) if galois is None else galois
+        check(lib.lf_ks_moddown_ws(_parr(ss), _parr(outs), _parr(addends), len(ss), ell, K, outs[0].size(-1), _p(ws),
+                                   ws.numel(), _p(PiR), 0 if PiP is None else PiP.data_ptr(), _p(Rs), pinv, _p(g2q),
+                                   *c.mont(), dev, st), "lf_ks_moddown_ws")
+
+    @staticmethod
+    def moddown_ws_words(count, ell, K, N):
+        return int(lib.lf_ks_moddown_ws_words(count, ell, K, N))
+
     def rescale(self, src, row0, out, rows, scales, round_at, c: Consts):
         dev, st = _ds(out)
         check(lib.lf_rescale(_p(src), _p(row0), _p(out), rows, out.size(-1), _p(scales), round_at, *c.mont(), dev, st),

@@ -882,8 +882,9 @@ class ckks_engine(EvaluatorOps):
                     add = add.contiguous()
                 adds.append(add)
             gal = None if galois is None else (galois[0], self._vec("_2q", d, level, False) if galois[1] else None)
-            self.backend.ks_moddown_batch([s[0], s[1]], [out[0], out[1]], adds, ell, K, tabs[("pir", d)], rs, cs,
-                                          PiP=tabs[("pip", d)], galois=gal)
+            ws = self._ws("ks_moddown", (self.backend.moddown_ws_words(2, ell, K, N),), d)
+            self.backend.ks_moddown_ws([s[0], s[1]], [out[0], out[1]], adds, ell, K, ws, tabs[("pir", d)], rs, cs,
+                                       PiP=tabs[("pip", d)], galois=gal)
             c0.append(out[0]); c1.append(out[1])
         return c0, c1
 

@@ -210,6 +210,13 @@ class OracleBackend:
         self.galois(t[:rows].contiguous(), out, rows, N.bit_length() - 1, pow(pinv, -1, 2 * N), g2q)
         return out
 
+    @staticmethod
+    def moddown_ws_words(count, ell, K, N):
+        return 1
+
+    def ks_moddown_ws(self, ss, outs, addends, ell, K, ws, PiR, Rs, c, PiP=None, galois=None):
+        self.ks_moddown_batch(ss, outs, addends, ell, K, PiR, Rs, c, PiP=PiP, galois=galois)
+
     def ks_moddown_batch(self, ss, outs, addends, ell, K, PiR, Rs, c, PiP=None, galois=None):
         for s_, out, add in zip(ss, outs, addends):
             if add is not None and galois is not None:

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared():
     text = open(os.path.join(ROOT, "include", "ckks_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(lf_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\bint(?:64_t)?\s+(lf_\w+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported():
@@ -20,7 +20,7 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(so, n), f"{n} declared in include/ckks_hip.h but not exported"
     assert sorted(_native.EXPORTED) == names, "python binding table out of sync with the header"
-    assert _native.lib.lf_abi_version() == 4     # pure host call, no HIP runtime use
+    assert _native.lib.lf_abi_version() == 5     # pure host call, no HIP runtime use
 
 
 def test_shim_exposes_the_fifteen_reference_functions():
