@@ -67,6 +67,26 @@ static __device__ __forceinline__ RowMod load_mod(const i64 *ql, const i64 *qh, 
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// int64 <-> fp64 without the generic 64-bit conversions (the fp64-class kernels hold integers below 2^52)
+// ------------------------------------------------------------------------------------------------
+// exact int <-> double for 0 <= x < 2^52 with one OR/AND on the high word and one fp64 add
+// (the compiler's generic 64-bit conversions cost 4-10 instructions each)
+#define DP_MAGIC 4503599627370496.0   // 2^52
+static __device__ __forceinline__ double dp_from_word(i64 x) {
+    return __longlong_as_double(x | 0x4330000000000000ll) - DP_MAGIC;
+}
+static __device__ __forceinline__ i64 dp_to_word(double d) {
+    return __double_as_longlong(d + DP_MAGIC) & 0x000FFFFFFFFFFFFFll;
+}
+
+// exact signed int -> double for |x| < 2^51: one 64-bit integer add and one fp64 add (the generic signed 64-bit
+// conversion costs ~9 instructions)
+static __device__ __forceinline__ double dp_from_signed(i64 x) {
+    return __longlong_as_double(x + 0x4338000000000000ll) - 6755399441055744.0;   // 2^52 + 2^51
+}
+
+
 static inline int lf_set_device(int device) {
     if (device >= 0) {
         hipError_t e = hipSetDevice(device);

@@ -74,15 +74,15 @@ __global__ void __launch_bounds__(256) tensor_kernel(const i64 *__restrict__ x0,
     if (plain && m.q < (1ull << 41)) {
         // plain canonical residues in, plain canonical residues out: one fp64 product per term
         const double q = (double)m.q, qinv = 1.0 / q;
-        const double A0[2] = {(double)a0.x, (double)a0.y}, A1[2] = {(double)a1.x, (double)a1.y};
-        const double B0[2] = {(double)b0.x, (double)b0.y}, B1[2] = {(double)b1.x, (double)b1.y};
+        const double A0[2] = {dp_from_word(a0.x), dp_from_word(a0.y)}, A1[2] = {dp_from_word(a1.x), dp_from_word(a1.y)};
+        const double B0[2] = {dp_from_word(b0.x), dp_from_word(b0.y)}, B1[2] = {dp_from_word(b1.x), dp_from_word(b1.y)};
         i64 r0[2], r1[2], r2[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            r0[e] = (i64)dp_mulmod_q(A0[e], B0[e], q, qinv);
+            r0[e] = dp_to_word(dp_mulmod_q(A0[e], B0[e], q, qinv));
             double t = dp_mulmod_q(A0[e], B1[e], q, qinv) + dp_mulmod_q(A1[e], B0[e], q, qinv);
-            r1[e] = (i64)(t >= q ? t - q : t);
-            r2[e] = (i64)dp_mulmod_q(A1[e], B1[e], q, qinv);
+            r1[e] = dp_to_word(t >= q ? t - q : t);
+            r2[e] = dp_to_word(dp_mulmod_q(A1[e], B1[e], q, qinv));
         }
         o0.x = r0[0]; o0.y = r0[1]; o1.x = r1[0]; o1.y = r1[1]; o2.x = r2[0]; o2.y = r2[1];
         *reinterpret_cast<longlong2 *>(d0 + off) = o0;
@@ -431,11 +431,9 @@ __global__ void __launch_bounds__(256) ks_moddown_ws_kernel(PtrBatch pb, int cou
                 acc1 += __builtin_fma(-__builtin_rint(hi * qinv), q, hi) + lo;
             }
             const double pinv = cst[(2 * KK) * ell + r];
-            // s canonical (< 2^41): exact int <-> double through the 2^52 trick; |s - acc| <= (K + 1) q
-            const double s0 = __longlong_as_double(sv.x | 0x4330000000000000ll) - 4503599627370496.0;
-            const double s1 = __longlong_as_double(sv.y | 0x4330000000000000ll) - 4503599627370496.0;
-            d[0] = __double_as_longlong(dp_mulmod_q(s0 - acc0, pinv, q, qinv) + 4503599627370496.0) & 0x000FFFFFFFFFFFFFll;
-            d[1] = __double_as_longlong(dp_mulmod_q(s1 - acc1, pinv, q, qinv) + 4503599627370496.0) & 0x000FFFFFFFFFFFFFll;
+            // s canonical (< 2^41): exact int <-> double through the 2^52 trick (ckks_common.h); |s - acc| <= (K + 1) q
+            d[0] = dp_to_word(dp_mulmod_q(dp_from_word(sv.x) - acc0, pinv, q, qinv));
+            d[1] = dp_to_word(dp_mulmod_q(dp_from_word(sv.y) - acc1, pinv, q, qinv));
         } else {
             const i64 rs = Rs[r];
             d[0] = mm62s(sv.x, rs, m.q, m.k);

@@ -96,11 +96,12 @@ __device__ __forceinline__ void ks_ext_body(i64 *sm, int b, const i64 *__restric
                 if (i < alpha) {
                     const longlong2 y = *reinterpret_cast<const longlong2 *>(state + (i64)(row_start + i) * kg.N + j);
                     if (!wide) {
-                        a0 += dp_mulmod_bal((double)y.x, cst[i], c.d);    // signed digit words: the formula is sign-agnostic
-                        a1 += dp_mulmod_bal((double)y.y, cst[i], c.d);
+                        a0 += dp_mulmod_bal(dp_from_signed(y.x), cst[i], c.d);    // signed digit words (|y| < 2^43): the formula is sign-agnostic
+                        a1 += dp_mulmod_bal(dp_from_signed(y.y), cst[i], c.d);
                     } else {
-                        a0 += dp_mulmod_bal((double)(y.x >> 31), cst31[i], c.d) + dp_mulmod_bal((double)(y.x & 0x7fffffffll), cst[i], c.d);
-                        a1 += dp_mulmod_bal((double)(y.y >> 31), cst31[i], c.d) + dp_mulmod_bal((double)(y.y & 0x7fffffffll), cst[i], c.d);
+                        // 31-bit halves through the native 32-bit conversions
+                        a0 += dp_mulmod_bal((double)(int)(y.x >> 31), cst31[i], c.d) + dp_mulmod_bal((double)(unsigned)(y.x & 0x7fffffffll), cst[i], c.d);
+                        a1 += dp_mulmod_bal((double)(int)(y.y >> 31), cst31[i], c.d) + dp_mulmod_bal((double)(unsigned)(y.y & 0x7fffffffll), cst[i], c.d);
                     }
                 }
             }
@@ -169,6 +170,17 @@ __global__ void __launch_bounds__(NTT_THREADS, 6) ks_ext_pass1_mixed(const i64 *
     }
 }
 
+// The key (gold: 429 MB per key switch) is read exactly once: nontemporal loads (global_load_dwordx4 .. nt) keep it
+// from displacing the digits, which the forward pass has just written, out of L2 / Infinity Cache
+// (measured at gold: 124.8 -> 96.2 us together with one 16-byte column per thread instead of two).
+#define KI_COLS 1
+__device__ __forceinline__ longlong2 ld_nt(const i64 *p) {
+    longlong2 v;
+    v.x = __builtin_nontemporal_load(p);
+    v.y = __builtin_nontemporal_load(p + 1);
+    return v;
+}
+
 // ---- K3: inner product with the key, summed over digits, on the relaxed NTT-domain words --------------
 // fp64 rows: words are plain canonical residues x; x * (k R) mod q is the Montgomery-form product the
 // reference's REDC(xR * kR) yields, one fp64 modular multiplication each.  Integer rows: REDC as the reference.
@@ -180,7 +192,7 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
                                                         const i64 *__restrict__ kh) {
     // each thread owns KI_V 16-byte column pairs 4 KiB apart: every block streams KI_V x 4 KiB contiguous runs
     // from 3 x nparts arrays, enough bytes in flight to keep HBM busy
-    constexpr int KI_V = 2;
+    constexpr int KI_V = KI_COLS;
     const int r = blockIdx.y;
     const i64 j0 = (i64)blockIdx.x * (512 * KI_V) + threadIdx.x * 2;
     if (j0 >= N) return;
@@ -198,8 +210,8 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
 #pragma unroll
             for (int v = 0; v < KI_V; ++v) {
                 x[v] = *reinterpret_cast<const longlong2 *>(e + (i64)p * rows * N + v * 512);
-                k0[v] = *reinterpret_cast<const longlong2 *>(k + (i64)p * part_stride + v * 512);
-                k1[v] = *reinterpret_cast<const longlong2 *>(k + (i64)p * part_stride + comp_stride + v * 512);
+                k0[v] = ld_nt(k + (i64)p * part_stride + v * 512);
+                k1[v] = ld_nt(k + (i64)p * part_stride + comp_stride + v * 512);
             }
 #pragma unroll
             for (int v = 0; v < KI_V; ++v) {
@@ -227,8 +239,8 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
 #pragma unroll
             for (int v = 0; v < KI_V; ++v) {
                 const longlong2 x = *reinterpret_cast<const longlong2 *>(e + (i64)p * rows * N + v * 512);
-                const longlong2 k0 = *reinterpret_cast<const longlong2 *>(k + (i64)p * part_stride + v * 512);
-                const longlong2 k1 = *reinterpret_cast<const longlong2 *>(k + (i64)p * part_stride + comp_stride + v * 512);
+                const longlong2 k0 = ld_nt(k + (i64)p * part_stride + v * 512);
+                const longlong2 k1 = ld_nt(k + (i64)p * part_stride + comp_stride + v * 512);
                 acc[0][v][0] = csub(acc[0][v][0] + mm62u((u64)x.x, (u64)k0.x, m.q, m.k), m.q2);
                 acc[0][v][1] = csub(acc[0][v][1] + mm62u((u64)x.y, (u64)k0.y, m.q, m.k), m.q2);
                 acc[1][v][0] = csub(acc[1][v][0] + mm62u((u64)x.x, (u64)k1.x, m.q, m.k), m.q2);
@@ -311,7 +323,7 @@ int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64
     // K3: inner product with the key, summed over the digits
     {
         const i64 N = (i64)1 << logN;
-        dim3 grid((unsigned)((N + 1023) / 1024), (unsigned)rows);
+        dim3 grid((unsigned)((N + 512 * KI_COLS - 1) / (512 * KI_COLS)), (unsigned)rows);
         hipLaunchKernelGGL(ks_inner2_kernel, grid, dim3(256), 0, st, (const i64 *)tmp, (const i64 *)ksk, (i64)part_stride,
                            (i64)comp_stride, (i64)row_off, (i64 *)s, nparts, rows, N, (const i64 *)ql, (const i64 *)qh,
                            (const i64 *)kl, (const i64 *)kh);

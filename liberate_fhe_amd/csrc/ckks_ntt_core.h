@@ -144,16 +144,6 @@ __device__ __forceinline__ double dp_addmask(double r, double m) {
     return __builtin_fma(-neg, m, r);
 }
 
-// exact int <-> double for 0 <= x < 2^52 with one OR/AND on the high word and one fp64 add
-// (the compiler's generic 64-bit conversions cost 4-10 instructions each)
-#define DP_MAGIC 4503599627370496.0   // 2^52
-__device__ __forceinline__ double dp_from_word(i64 x) {
-    return __longlong_as_double(x | 0x4330000000000000ll) - DP_MAGIC;
-}
-__device__ __forceinline__ i64 dp_to_word(double d) {
-    return __double_as_longlong(d + DP_MAGIC) & 0x000FFFFFFFFFFFFFll;
-}
-
 // (a * w) mod q, canonical, for a < 2^52, w < q: exact via the FMA low part.
 __device__ __forceinline__ double dp_mulmod(double a, double w, const RowDp &m) {
     const double hi = a * w;
