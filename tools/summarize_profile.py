@@ -66,7 +66,7 @@ for counter, sub, stem in (("FETCH_SIZE", f"pmc_fetch_{tag}", "fetch"), ("WRITE_
     per[counter] = disp
     per[counter + "_cols"] = q(db, "select dispatch_id, value, duration from counters_collection where kernel_name like '%ntt_fwd_cols_mixed%' order by dispatch_id")
     pm.append("")
-pm.append("# ntt_fwd_pass_mixed (30 limbs x 16 polynomials): the tiled pass (12 stages + twiddles), one dispatch per transform")
+pm.append("# ntt_fwd_pass_mixed (30 limbs x the bench batch): the tiled pass (12 stages + twiddles), one dispatch per transform")
 for (d, v, ns), (_, w, _) in zip(per["FETCH_SIZE"], per["WRITE_SIZE"]):
     pm.append(f"dispatch {d}: FETCH_SIZE={v:10.1f} KiB -> {2 * v * 1024 / 1e6:7.1f} MB read (corrected) | WRITE_SIZE={w:10.1f} KiB -> {w * 1024 / 1e6:7.1f} MB | {ns / 1e3:7.1f} us")
 pm.append("# ntt_fwd_cols_mixed<4> (same limbs): the column pass (4 leading stages), one dispatch per transform")
@@ -76,9 +76,13 @@ open(os.path.join(out_dir, f"{tag}_bench_pmc_hbm.txt"), "w").write("\n".join(pm)
 
 fetch = sum(v for _, v, _ in per["FETCH_SIZE"]) / len(per["FETCH_SIZE"])
 write = sum(v for _, v, _ in per["WRITE_SIZE"]) / len(per["WRITE_SIZE"])
-traffic = {"ntt_fwd_pass_mixed_bytes_per_launch": (2 * fetch + write) * 1024,
+try:
+    batch = int(json.load(open(os.path.join(src, f"bench_{tag}.json")))["config"]["batch_per_gpu"])
+except Exception:
+    batch = 128
+traffic = {"ntt_fwd_pass_mixed_bytes_per_launch": (2 * fetch + write) * 1024, "batch_per_gpu": batch,
            "fetch_kib_avg_raw": fetch, "write_kib_avg": write,
-           "note": "ntt_fwd_pass_mixed (tiled pass, 30 limbs x 16 polynomials) per launch; FETCH_SIZE doubled per the gfx950 1/2-count caveat"}
+           "note": "ntt_fwd_pass_mixed (tiled pass, 30 limbs x `batch_per_gpu` polynomials) per launch; FETCH_SIZE doubled per the gfx950 1/2-count caveat"}
 cf, cw = per["FETCH_SIZE_cols"], per["WRITE_SIZE_cols"]
 if cf and cw:
     traffic["ntt_fwd_cols_mixed_bytes_per_launch"] = (2 * sum(v for _, v, _ in cf) / len(cf) + sum(v for _, v, _ in cw) / len(cw)) * 1024
