@@ -18,6 +18,16 @@
 
 namespace {
 
+// Thread index rebuilt from the wave's index (one SGPR) and the lane id (two v_mbcnt): nothing has to stay in a
+// VGPR across the out-of-line calls of the exact fp64 path, where the compiler otherwise spills it (8 bytes per
+// thread and tile = +10 % HBM write traffic on the tiled pass, measured with the WRITE_SIZE counter).
+__device__ __forceinline__ int lf_tid() {
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    int lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    return (wave << 6) | lane;
+}
+
 // Workgroup barrier that waits for LDS traffic only.  __syncthreads() also drains the vector-memory
 // queue (s_waitcnt vmcnt(0)), which would serialise the register prefetch of the next tile behind
 // every barrier of the current one.
@@ -356,7 +366,7 @@ struct StepTw {
     typename A::W w0[1], w1[2], w2[4];
     int i0;
     __device__ __forceinline__ void load(const Ctx &c, int s, int E, int base) {
-        const int w = threadIdx.x;
+        const int w = lf_tid();
         const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
         i0 = (1 << s) + ((base + p) >> (E - s));
         A::tw_group(c, i0, 1, w0);
@@ -381,7 +391,7 @@ __device__ __forceinline__ void fwd_regs8(typename A::T (&x)[8], const StepTw<A,
 
 template <class A, int LOGDL>
 __device__ __forceinline__ void fwd_step8(typename A::T *sm, const StepTw<A, LOGDL> &tw, const Ctx &c) {
-    const int w = threadIdx.x;
+    const int w = lf_tid();
     const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
     typename A::T x[8];
 #pragma unroll
@@ -429,7 +439,7 @@ struct StepTwInv {
     typename A::W w0[4], w1[2], w2[1];
     int il;
     __device__ __forceinline__ void load(const Ctx &c, int s, int adj, int logN, int base) {
-        const int w = threadIdx.x;
+        const int w = lf_tid();
         const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
         il = (1 << (logN - s - 3)) + ((base + p) >> (s + 3 - adj));
         A::tw_group(c, il << 2, 4, w0);
@@ -454,7 +464,7 @@ __device__ __forceinline__ void inv_regs8(typename A::T (&x)[8], const StepTwInv
 
 template <class A, int LOGDL>
 __device__ __forceinline__ void inv_step8(typename A::T *sm, const StepTwInv<A, LOGDL> &tw, const Ctx &c) {
-    const int w = threadIdx.x;
+    const int w = lf_tid();
     const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
     typename A::T x[8];
 #pragma unroll
@@ -598,7 +608,8 @@ static_assert(NTT_THREADS == 512, "one flag byte per wave fills the 8-byte flag 
 // wave v owns byte v of the flag word: every wave writes its byte, so no reset and no reset barrier
 __device__ __forceinline__ void wave_flag_set(i64 *sm, int pred) {
     const bool any = __builtin_amdgcn_ballot_w64(pred != 0) != 0;
-    if ((threadIdx.x & 63) == 0) reinterpret_cast<unsigned char *>(sm + NTT_FLAG_WORD)[threadIdx.x >> 6] = any ? 1 : 0;
+    const int t = lf_tid();
+    if ((t & 63) == 0) reinterpret_cast<unsigned char *>(sm + NTT_FLAG_WORD)[t >> 6] = any ? 1 : 0;
 }
 
 // LDS traffic of one wave is processed in order: a wave-private exchange needs no s_barrier
@@ -611,7 +622,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 template <class A>
 __device__ __forceinline__ bool fwd_tile12_core(typename A::T *smt, i64 *sm, typename A::T (&x)[8], int s, int E, int base,
                                                 const Ctx &c) {
-    const int w = threadIdx.x;
+    const int w = lf_tid();
     StepTw<A, 9> t9;
     StepTw<A, 6> t6;
     StepTw<A, 3> t3;
@@ -640,7 +651,7 @@ __device__ __forceinline__ bool fwd_tile12_core(typename A::T *smt, i64 *sm, typ
 
 // 8 consecutive result words per thread -> global, 16 B per lane and 1 KiB contiguous per wave instruction
 __device__ __forceinline__ void store_tile12_regs(i64 *sm, const i64 (&o)[8], i64 *dst) {
-    const int w = threadIdx.x;
+    const int w = lf_tid();
 #pragma unroll
     for (int e = 0; e < 8; ++e) sm[9 * w + e] = o[e];
     wave_lds_sync();
@@ -658,7 +669,7 @@ __device__ __forceinline__ void store_tile12_regs(i64 *sm, const i64 (&o)[8], i6
 template <bool DP>
 __device__ __forceinline__ bool fwd_tile12(i64 *sm, i64 *__restrict__ row, int tile, const PassGeom &g, const Ctx &c,
                                            bool enter, i64 rs) {
-    const int w = threadIdx.x;
+    const int w = lf_tid();
     const int base = tile << 12;
     const i64 q2 = c.m.q2;
     i64 raw[8];
@@ -716,7 +727,7 @@ __device__ __forceinline__ bool fwd_tile12(i64 *sm, i64 *__restrict__ row, int t
 template <class A>
 __device__ __forceinline__ bool inv_tile12_core(typename A::T *smt, i64 *sm, typename A::T (&x)[8], int s, int logN, int base,
                                                 const Ctx &c) {
-    const int w = threadIdx.x;
+    const int w = lf_tid();
     Ctx cc = c;
     StepTwInv<A, 0> t0;
     StepTwInv<A, 3> t3;
@@ -763,7 +774,7 @@ __device__ __forceinline__ i64 inv_tail_int(i64 t, int tail, i64 ninv, const Ctx
 template <bool DP>
 __device__ __forceinline__ bool inv_tile12(i64 *sm, const i64 *src_row, i64 *dst_row, int tile, const PassGeom &g, const Ctx &c,
                                            const i64 *__restrict__ Ninv, int tail, int crow) {
-    const int w = threadIdx.x;
+    const int w = lf_tid();
     const int base = tile << 12;
     const i64 q2 = c.m.q2;
     // 16-byte loads, 1 KiB contiguous per wave instruction, exchanged through the wave's own LDS span
