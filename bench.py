@@ -97,6 +97,14 @@ def engine_rates(dev, quick):
         out[f"cc_mult_evk_{name}_ops_per_s"] = 1e3 / ms
         ms = event_time_ms(lambda: eng.rotate_single(a, rotk), n)
         out[f"rotate_single_{name}_ops_per_s"] = 1e3 / ms
+        # configs[4]: a batch of ciphertexts rotated by the same step (one key): groups of 4 per key-switch launch set
+        nb = 16
+        cts = [synth.ciphertext(eng, 100 + i, 0) for i in range(nb)]
+        eng.rotate_single_batch(cts, rotk)
+        torch.cuda.synchronize()
+        ms = event_time_ms(lambda: eng.rotate_single_batch(cts, rotk), max(2, n // 4))
+        out[f"rotate_single_{name}_batch{nb}_rotations_per_s"] = nb * 1e3 / ms
+        del cts
         del eng, a, b, evk, rotk
         torch.cuda.empty_cache()
     return out

@@ -173,6 +173,16 @@ int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64
                const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
                const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 
+/* lf_ks_core for `nct` (1, 2 or 4) ciphertexts switched under the SAME key (a batch of rotations by one step,
+ * config "rotate batched 64 ciphertexts"): every launch covers all of them and the inner product reads each key
+ * word once for the whole batch.  state: nct digit states `state_stride` words apart; tmp scratch
+ * [nct][nparts][rows][N]; s out [nct][2][rows][N].  Results equal nct calls of lf_ks_core. */
+int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int nparts, int rows, int logN, const int64_t *desc,
+                     const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
+                     int64_t row_off, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
+                     const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
+                     const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+
 /* Batched forms: `count` (<= 8) independent operand sets in ONE launch — the two components of a ciphertext, the
  * four polynomials cc_mult rescales.  The arrays of pointers are HOST arrays of device pointers; constants are
  * shared by all sets.  addend may be NULL, or hold NULL entries. */

@@ -36,6 +36,8 @@ struct KsGeom {
     int nparts;      // digits
     int groups;      // part groups (partial sums) of the inner product
     i64 N;
+    int nct;         // ciphertexts switched under the same key in this call (lf_ks_core_batch)
+    i64 state_stride;   // words between their digit states
 };
 
 // ---- K2: extend + strided NTT pass -----------------------------------------------------------------
@@ -50,6 +52,12 @@ __device__ __forceinline__ void ks_ext_body(i64 *sm, int b, const i64 *__restric
                                             const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
     const int T = 1 << kg.tl;
     const int tiles = 1 << (kg.logN - kg.tl);
+    // ciphertexts of a batch are the outermost index: each one is the single-ciphertext grid over its own state
+    const int per_ct = tiles * kg.nparts * rl.n;
+    const int ct = b / per_ct;
+    b -= ct * per_ct;
+    state += (i64)ct * kg.state_stride;
+    tmp += ((i64)ct * kg.nparts * kg.rows) << kg.logN;
     // the blocks of one (digit, tile) pair differ in the target limb and re-read the same digit columns: they are
     // placed on ONE XCD (blocks b, b + 8, .. share an XCD), so those columns are fetched into one L2, once
     int ri, pt;
@@ -185,6 +193,8 @@ __device__ __forceinline__ longlong2 ld_nt(const i64 *p) {
 // fp64 rows: words are plain canonical residues x; x * (k R) mod q is the Montgomery-form product the
 // reference's REDC(xR * kR) yields, one fp64 modular multiplication each.  Integer rows: REDC as the reference.
 // grid = (N / 1024, rows); the digits' products are accumulated in registers, the key is read exactly once.
+// NCT ciphertexts switched under the same key share every key word: it is read once for all of them.
+template <int NCT>
 __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ ext, const i64 *__restrict__ ksk,
                                                         i64 part_stride, i64 comp_stride, i64 row_off, i64 *__restrict__ s,
                                                         int nparts, int rows, i64 N, const i64 *__restrict__ ql,
@@ -200,61 +210,62 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
     const RowDp d = make_dp(m);
     const i64 *e = ext + (i64)r * N + j0;
     const i64 *k = ksk + (row_off + r) * N + j0;
+    const i64 ct_ext = (i64)nparts * rows * N;   // words between the ciphertexts' extended digits
+    const i64 ct_s = 2 * (i64)rows * N;          // .. and between their output pairs
     if (m.q < SMALL_PRIME_LIMIT) {
-        double acc[2][KI_V][2];
+        double acc[NCT][2][2];
 #pragma unroll
-        for (int v = 0; v < KI_V; ++v) acc[0][v][0] = acc[0][v][1] = acc[1][v][0] = acc[1][v][1] = 0.0;
+        for (int t = 0; t < NCT; ++t) acc[t][0][0] = acc[t][0][1] = acc[t][1][0] = acc[t][1][1] = 0.0;
 #pragma unroll 2
         for (int p = 0; p < nparts; ++p) {
-            longlong2 x[KI_V], k0[KI_V], k1[KI_V];
+            longlong2 x[NCT];
 #pragma unroll
-            for (int v = 0; v < KI_V; ++v) {
-                x[v] = *reinterpret_cast<const longlong2 *>(e + (i64)p * rows * N + v * 512);
-                k0[v] = ld_nt(k + (i64)p * part_stride + v * 512);
-                k1[v] = ld_nt(k + (i64)p * part_stride + comp_stride + v * 512);
-            }
+            for (int t = 0; t < NCT; ++t) x[t] = *reinterpret_cast<const longlong2 *>(e + t * ct_ext + (i64)p * rows * N);
+            const longlong2 k0 = ld_nt(k + (i64)p * part_stride);
+            const longlong2 k1 = ld_nt(k + (i64)p * part_stride + comp_stride);
+            const double k0x = dp_from_word(k0.x), k0y = dp_from_word(k0.y), k1x = dp_from_word(k1.x), k1y = dp_from_word(k1.y);
 #pragma unroll
-            for (int v = 0; v < KI_V; ++v) {
-                const double x0 = dp_from_word(x[v].x), x1 = dp_from_word(x[v].y);
-                acc[0][v][0] += dp_mulmod_bal(x0, dp_from_word(k0[v].x), d);
-                acc[0][v][1] += dp_mulmod_bal(x1, dp_from_word(k0[v].y), d);
-                acc[1][v][0] += dp_mulmod_bal(x0, dp_from_word(k1[v].x), d);
-                acc[1][v][1] += dp_mulmod_bal(x1, dp_from_word(k1[v].y), d);
+            for (int t = 0; t < NCT; ++t) {
+                const double x0 = dp_from_word(x[t].x), x1 = dp_from_word(x[t].y);
+                acc[t][0][0] += dp_mulmod_bal(x0, k0x, d);
+                acc[t][0][1] += dp_mulmod_bal(x1, k0y, d);
+                acc[t][1][0] += dp_mulmod_bal(x0, k1x, d);
+                acc[t][1][1] += dp_mulmod_bal(x1, k1y, d);
             }
         }
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int t = 0; t < NCT; ++t)
 #pragma unroll
-            for (int v = 0; v < KI_V; ++v) {
+            for (int c = 0; c < 2; ++c) {
                 longlong2 o;
-                o.x = dp_to_word(dp_reduce(acc[c][v][0], d.q, d.qinv));
-                o.y = dp_to_word(dp_reduce(acc[c][v][1], d.q, d.qinv));
-                *reinterpret_cast<longlong2 *>(s + ((i64)c * rows + r) * N + j0 + v * 512) = o;
+                o.x = dp_to_word(dp_reduce(acc[t][c][0], d.q, d.qinv));
+                o.y = dp_to_word(dp_reduce(acc[t][c][1], d.q, d.qinv));
+                *reinterpret_cast<longlong2 *>(s + t * ct_s + ((i64)c * rows + r) * N + j0) = o;
             }
     } else {
-        i64 acc[2][KI_V][2];
+        i64 acc[NCT][2][2];
 #pragma unroll
-        for (int v = 0; v < KI_V; ++v) acc[0][v][0] = acc[0][v][1] = acc[1][v][0] = acc[1][v][1] = 0;
+        for (int t = 0; t < NCT; ++t) acc[t][0][0] = acc[t][0][1] = acc[t][1][0] = acc[t][1][1] = 0;
         for (int p = 0; p < nparts; ++p) {
+            const longlong2 k0 = ld_nt(k + (i64)p * part_stride);
+            const longlong2 k1 = ld_nt(k + (i64)p * part_stride + comp_stride);
 #pragma unroll
-            for (int v = 0; v < KI_V; ++v) {
-                const longlong2 x = *reinterpret_cast<const longlong2 *>(e + (i64)p * rows * N + v * 512);
-                const longlong2 k0 = ld_nt(k + (i64)p * part_stride + v * 512);
-                const longlong2 k1 = ld_nt(k + (i64)p * part_stride + comp_stride + v * 512);
-                acc[0][v][0] = csub(acc[0][v][0] + mm62u((u64)x.x, (u64)k0.x, m.q, m.k), m.q2);
-                acc[0][v][1] = csub(acc[0][v][1] + mm62u((u64)x.y, (u64)k0.y, m.q, m.k), m.q2);
-                acc[1][v][0] = csub(acc[1][v][0] + mm62u((u64)x.x, (u64)k1.x, m.q, m.k), m.q2);
-                acc[1][v][1] = csub(acc[1][v][1] + mm62u((u64)x.y, (u64)k1.y, m.q, m.k), m.q2);
+            for (int t = 0; t < NCT; ++t) {
+                const longlong2 x = *reinterpret_cast<const longlong2 *>(e + t * ct_ext + (i64)p * rows * N);
+                acc[t][0][0] = csub(acc[t][0][0] + mm62u((u64)x.x, (u64)k0.x, m.q, m.k), m.q2);
+                acc[t][0][1] = csub(acc[t][0][1] + mm62u((u64)x.y, (u64)k0.y, m.q, m.k), m.q2);
+                acc[t][1][0] = csub(acc[t][1][0] + mm62u((u64)x.x, (u64)k1.x, m.q, m.k), m.q2);
+                acc[t][1][1] = csub(acc[t][1][1] + mm62u((u64)x.y, (u64)k1.y, m.q, m.k), m.q2);
             }
         }
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int t = 0; t < NCT; ++t)
 #pragma unroll
-            for (int v = 0; v < KI_V; ++v) {
+            for (int c = 0; c < 2; ++c) {
                 longlong2 o;
-                o.x = acc[c][v][0];
-                o.y = acc[c][v][1];
-                *reinterpret_cast<longlong2 *>(s + ((i64)c * rows + r) * N + j0 + v * 512) = o;
+                o.x = acc[t][c][0];
+                o.y = acc[t][c][1];
+                *reinterpret_cast<longlong2 *>(s + t * ct_s + ((i64)c * rows + r) * N + j0) = o;
             }
     }
 }
@@ -271,41 +282,42 @@ void classify_rows(int rows, const int64_t *q_host, RowList &dp, RowList &in) {
 
 extern "C" {
 
-int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,
-               const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
-               int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
-               const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
-               const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int nparts, int rows, int logN, const int64_t *desc,
+                     const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
+                     int64_t row_off, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
+                     const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
+                     const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
     if (nparts < 1 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
-        !q_host || !psi_dp || !ipsi_dp || !Ed)
+        !q_host || !psi_dp || !ipsi_dp || !Ed || (nct != 1 && nct != 2 && nct != 4))
         return LF_ERR_ARG;
     if (int e = lf_set_device(device)) return e;
     hipStream_t st = (hipStream_t)stream;
     const int tl = NTT_TILE_LOG_MAX, S1 = logN - tl;
-    const KsGeom kg{logN, tl, S1, rows, nparts, 1, (i64)1 << logN};
+    const KsGeom kg{logN, tl, S1, rows, nparts, 1, (i64)1 << logN, nct, (i64)state_stride};
     RowList dp, in;
     classify_rows(rows, q_host, dp, in);
     const unsigned tiles = 1u << (logN - tl);
+    const unsigned polys = (unsigned)nparts * (unsigned)nct;   // extended digits of all ciphertexts: one stack
 
     const bool mixed = dp.n && in.n && mixed_enabled();   // both arithmetic classes in one launch per step
     // K2: extend + strided pass
     if (mixed) {
-        const ClassLists cl = class_lists(in, dp, tiles * in.n * nparts);
-        hipLaunchKernelGGL(ks_ext_pass1_mixed, dim3((unsigned)cl.in_blocks + tiles * dp.n * nparts), dim3(NTT_THREADS), 0, st,
+        const ClassLists cl = class_lists(in, dp, tiles * in.n * polys);
+        hipLaunchKernelGGL(ks_ext_pass1_mixed, dim3((unsigned)cl.in_blocks + tiles * dp.n * polys), dim3(NTT_THREADS), 0, st,
                            (const i64 *)state, (i64 *)tmp, kg, cl, (const i64 *)desc, (const i64 *)E, Ed, (const i64 *)psi_br,
                            psi_dp, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     } else if (dp.n)
-        hipLaunchKernelGGL(ks_ext_pass1<true>, dim3(tiles * dp.n * nparts), dim3(NTT_THREADS), 0, st, (const i64 *)state,
+        hipLaunchKernelGGL(ks_ext_pass1<true>, dim3(tiles * dp.n * polys), dim3(NTT_THREADS), 0, st, (const i64 *)state,
                            (i64 *)tmp, kg, dp, (const i64 *)desc, (const i64 *)E, Ed, (const i64 *)psi_br, psi_dp,
                            (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     if (in.n && !mixed)
-        hipLaunchKernelGGL(ks_ext_pass1<false>, dim3(tiles * in.n * nparts), dim3(NTT_THREADS), 0, st, (const i64 *)state,
+        hipLaunchKernelGGL(ks_ext_pass1<false>, dim3(tiles * in.n * polys), dim3(NTT_THREADS), 0, st, (const i64 *)state,
                            (i64 *)tmp, kg, in, (const i64 *)desc, (const i64 *)E, Ed, (const i64 *)psi_br, psi_dp,
                            (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     // contiguous forward pass, in place on tmp (relaxed)
     {
-        const PassGeom g{logN, tl, 0, tl, S1, 0, rows, nparts, 1, 1, 0, 1, 0};
-        const unsigned per_row = (unsigned)nparts << (logN - tl);
+        const PassGeom g{logN, tl, 0, tl, S1, 0, rows, (int)polys, 1, 1, 0, 1, 0};
+        const unsigned per_row = polys << (logN - tl);
         if (mixed) {
             const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
             hipLaunchKernelGGL((ntt_fwd_pass_mixed<true>), dim3((unsigned)cl.in_blocks + per_row * dp.n), dim3(NTT_THREADS), 0, st,
@@ -324,26 +336,34 @@ int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64
     {
         const i64 N = (i64)1 << logN;
         dim3 grid((unsigned)((N + 512 * KI_COLS - 1) / (512 * KI_COLS)), (unsigned)rows);
-        hipLaunchKernelGGL(ks_inner2_kernel, grid, dim3(256), 0, st, (const i64 *)tmp, (const i64 *)ksk, (i64)part_stride,
-                           (i64)comp_stride, (i64)row_off, (i64 *)s, nparts, rows, N, (const i64 *)ql, (const i64 *)qh,
-                           (const i64 *)kl, (const i64 *)kh);
+#define LF_INNER_CASE(NCT)                                                                                             \
+    case NCT:                                                                                                          \
+        hipLaunchKernelGGL((ks_inner2_kernel<NCT>), grid, dim3(256), 0, st, (const i64 *)tmp, (const i64 *)ksk,         \
+                           (i64)part_stride, (i64)comp_stride, (i64)row_off, (i64 *)s, nparts, rows, N, (const i64 *)ql, \
+                           (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);                                         \
+        break;
+        switch (nct) {
+            LF_INNER_CASE(1) LF_INNER_CASE(2) LF_INNER_CASE(4)
+        }
+#undef LF_INNER_CASE
     }
     // K4: inverse transform -> canonical coefficients (relaxed, tail 2), in place on s
-    const unsigned per_row2 = 2u << (logN - tl);
+    const int inv_polys = 2 * nct;
+    const unsigned per_row2 = (unsigned)inv_polys << (logN - tl);
     for (int pass = 0; pass < 2; ++pass) {
-        PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, 2, 1, 0, 0, 1, 0}
-                               : PassGeom{logN, tl, 1, S1, tl, tl - S1, rows, 2, 1, 1, 0, 1, 0};
+        PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, inv_polys, 1, 0, 0, 1, 0}
+                               : PassGeom{logN, tl, 1, S1, tl, tl - S1, rows, inv_polys, 1, 1, 0, 1, 0};
         if (pass == 1 && S1 <= 4 && cols_enabled()) {
             if (mixed) {
-                launch_inv_cols_mixed(S1, 2, st, (i64 *)s, g, in, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,
+                launch_inv_cols_mixed(S1, inv_polys, st, (i64 *)s, g, in, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,
                                       (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
                 continue;
             }
             if (dp.n)
-                launch_inv_cols<true>(S1, 2, st, (i64 *)s, g, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,
+                launch_inv_cols<true>(S1, inv_polys, st, (i64 *)s, g, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,
                                       (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
             if (in.n)
-                launch_inv_cols<false>(S1, 2, st, (i64 *)s, g, in, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,
+                launch_inv_cols<false>(S1, inv_polys, st, (i64 *)s, g, in, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,
                                        (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
             continue;
         }
@@ -364,6 +384,15 @@ int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64
                                (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     }
     return (int)hipGetLastError();
+}
+
+int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,
+               const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
+               int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
+               const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
+               const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    return lf_ks_core_batch(state, 0, 1, nparts, rows, logN, desc, E, Ed, ksk, part_stride, comp_stride, row_off, tmp, s, psi_br,
+                            psi_dp, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh, kl, kh, device, stream);
 }
 
 }  // extern "C"

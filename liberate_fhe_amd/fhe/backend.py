@@ -163,6 +163,21 @@ class HipBackend:
                              row_off, _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
                              c.qptr(), *c.mont(), dev, st), "lf_ks_core")
 
+    ks_batch_sizes = (4, 2)   # ciphertexts per lf_ks_core_batch call (largest first)
+
+    def ks_core_batch(self, states, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv,
+                      c: Consts):
+        """ks_core for len(states) in (2, 4) ciphertexts under one key: states = [nct, state_rows, N] tensor,
+        tmp [nct, nparts, rows, N], s [nct, 2, rows, N]."""
+        dev, st = _ds(s)
+        part_stride, comp_stride = key.stride(0), key.stride(1)
+        base = key.data_ptr() + first_part * part_stride * 8
+        psi_dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
+        ipsi_dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
+        check(lib.lf_ks_core_batch(_p(states), states.stride(0), states.size(0), nparts, rows, logN, _p(desc), _p(E),
+                                   Ed.data_ptr(), base, part_stride, comp_stride, row_off, _p(tmp), _p(s), _p(psi), psi_dp,
+                                   _p(ipsi), ipsi_dp, _p(Ninv), c.qptr(), *c.mont(), dev, st), "lf_ks_core_batch")
+
     def ks_moddown(self, s, out, addend, ell, K, PiR, Rs, c: Consts, PiP=None):
         dev, st = _ds(out)
         check(lib.lf_ks_moddown(_p(s), _p(out), _p(addend), ell, K, out.size(-1), _p(PiR),

@@ -933,6 +933,83 @@ class ckks_engine(EvaluatorOps):
         delta = int(rotk.origin.split(":")[-1])
         return self._automorphism(ct, encdec.galois_exponent(self.ctx.N, delta), rotk, canonical=True)
 
+    def rotate_single_batch(self, cts: list, rotk: data_struct) -> list:
+        """rotate_single of several ciphertexts by the same step, i.e. under the same key (BASELINE config "rotate
+        batched 64 ciphertexts"; the reference has no batched entry and loops).  Returns
+        [rotate_single(ct, rotk) for ct in cts], bit for bit.  On one GPU, groups of up to 4 coefficient-domain
+        ciphertexts of one level go through the key switch together: one launch set per group (4x the blocks per
+        launch) and the key — two thirds of the inner product's HBM bytes — is read once per group."""
+        if types.origins["rotk"] not in rotk.origin:
+            raise errors.NotMatchType(origin=rotk.origin, to=types.origins["rotk"])
+        for ct in cts:
+            if ct.origin != types.origins["ct"]:
+                raise errors.NotMatchType(origin=ct.origin, to=types.origins["ct"])
+        out = [None] * len(cts)
+        sizes = getattr(self.backend, "ks_batch_sizes", ())
+        groups = {}
+        for i, ct in enumerate(cts):
+            ok = (sizes and not ct.ntt_state and not ct.include_special and self.len_devices[ct.level] == 1
+                  and len(self._loc(ct.level)) == 1 and self.ctx.logN >= self.backend.fused_ks_min_logN)
+            if ok:
+                groups.setdefault(ct.level, []).append(i)
+            else:
+                out[i] = self.rotate_single(ct, rotk)
+        delta = int(rotk.origin.split(":")[-1])
+        exponent = encdec.galois_exponent(self.ctx.N, delta)
+        for level, idx in groups.items():
+            pos = 0
+            while pos < len(idx):
+                n = next((k for k in sizes if k <= len(idx) - pos), 1)
+                if n == 1:
+                    out[idx[pos]] = self.rotate_single(cts[idx[pos]], rotk)
+                else:
+                    res = self._automorphism_batch([cts[i] for i in idx[pos:pos + n]], exponent, rotk, level)
+                    for i, r in zip(idx[pos:pos + n], res):
+                        out[i] = r
+                pos += n
+        return out
+
+    def _automorphism_batch(self, cts, exponent, key, level):
+        """X -> X^exponent + key switch of len(cts) in (2, 4) ciphertexts of one level on the single local device
+        (the rotate_single form: canonical words)."""
+        tabs = self._ks_tables(level)
+        d = self._loc(level)[0]
+        N, logN, K = self.ctx.N, self.ctx.logN, self.ntt.num_special_primes
+        nct = len(cts)
+        pinv = pow(exponent, -1, 2 * N)
+        rows, ell = self._rows(d, level, True), self._rows(d, level, False)
+        c_ord, cs = self._consts(d, level, False), self._consts(d, level, True)
+        gal = (pinv, self._vec("_2q", d, level, False))
+        # 1. mixed-radix digits of c1(X^p), one launch per ciphertext into a common stack
+        states = self._ws("ks_state_batch", (nct, ell, N), d)
+        nparts_d, desc_d, tab_d = tabs[("digits", d)]
+        for b, ct in enumerate(cts):
+            self.backend.ks_digits(ct.data[1][0], states[b], nparts_d, desc_d, tab_d, c_ord, galois=gal)
+        # 2. fused core over the whole group
+        nparts = len(tabs["order"])
+        ext = self._ws("ks_ext_batch", (nct, nparts, rows, N), d)
+        s = self._ws("ks_sum_batch", (nct, 2, rows, N), d)
+        desc, E, Ed = tabs[("extend", d)]
+        packs = self._key_pack(key)
+        kpack = packs[self._loc(0, special=True).index(d)]
+        self.backend.ks_core_batch(states, nparts, rows, logN, desc, E, Ed, kpack, tabs["first_part"],
+                                   self.ntt.starts[level][d], ext, s, self._tw(d, level, True),
+                                   self._tw(d, level, True, True), self._vec("Ninv", d, level, True), cs)
+        # 3. divide by P, c0(X^p) added in gather form: one launch pair for the 2 * nct polynomials
+        out = torch.empty((nct, 2, ell, N), dtype=torch.int64, device=self.ntt.devices[d])
+        ss = [s[b][comp] for b in range(nct) for comp in range(2)]
+        outs = [out[b][comp] for b in range(nct) for comp in range(2)]
+        adds = []
+        for ct in cts:
+            a0 = ct.data[0][0]
+            adds += [a0 if a0.is_contiguous() else a0.contiguous(), None]
+        ws = self._ws("ks_moddown_batch", (self.backend.moddown_ws_words(2 * nct, ell, K, N),), d)
+        self.backend.ks_moddown_ws(ss, outs, adds, ell, K, ws, tabs[("pir", d)], self._vec("Rs", d, level, True), cs,
+                                   PiP=tabs[("pip", d)], galois=gal)
+        return [data_struct(data=([out[b][0]], [out[b][1]]), include_special=False, ntt_state=False,
+                            montgomery_state=ct.montgomery_state, origin=types.origins["ct"], level=level, hash=self.hash)
+                for b, ct in enumerate(cts)]
+
     def rotate_galois(self, ct: data_struct, gk: data_struct, delta: int, return_circuit=False) -> data_struct:
         if ct.origin != types.origins["ct"]:
             raise errors.NotMatchType(origin=ct.origin, to=types.origins["ct"])

@@ -310,6 +310,12 @@ class OracleBackend:
         self.ks_inner(tmp, key, first_part, row_off, s[0], s[1], nparts, rows, c)
         self.intt(s, 2, rows, logN, ipsi, Ninv, 2, c)
 
+    ks_batch_sizes = (4, 2)
+
+    def ks_core_batch(self, states, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv, c):
+        for b in range(states.size(0)):
+            self.ks_core(states[b], nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp[b], s[b], psi, ipsi, Ninv, c)
+
     # ---- divide by P: ckks_engine.py:850-901 (+ relinearize 1135-1140 / switch_key 952-953) ----
     def ks_moddown(self, s, out, addend, ell, K, PiR, Rs, c, PiP=None):
         rows = ell + K

@@ -104,3 +104,42 @@ def test_hip_engine_end_to_end_decode_error():
     assert np.abs(eng.decrode(prod, sk) - m1 * m2).max() < 2e-7
     assert np.abs(eng.decrode(eng.rotate_single(prod, rotk), sk) - np.roll(m1 * m2, 11)).max() < 2e-7
     assert np.abs(eng.decrode(eng.cc_add(c1, c2), sk) - (m1 + m2)).max() < 1e-8
+
+
+def _rot_params():
+    # a small two-pass ring (the fused key-switch core needs logN >= 13) with two digits
+    return dict(logN=13, num_scales=5, num_special_primes=2, is_secured=False)
+
+
+def test_rotate_single_batch_checker_equals_loop():
+    """Host logic of rotate_single_batch (grouping 4 / 2 / 1, mixed levels, fallbacks) through the checker backend."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    from tests.oracle_backend import OracleBackend
+    eng = ckks_engine(devices=["cpu"], backend=OracleBackend(), **_rot_params())
+    rotk = synth.key_switch_key(eng, 7, origin="rotation key:3")
+    cts = [synth.ciphertext(eng, 200 + i, 0) for i in range(3)] + [synth.ciphertext(eng, 300, 1)]
+    want = [digest(eng.rotate_single(ct, rotk)) for ct in cts]
+    got = [digest(x) for x in eng.rotate_single_batch(cts, rotk)]
+    assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,count", [("small13", 7), ("silver", 6), ("gold", 4)])
+def test_hip_rotate_single_batch_equals_loop(name, count):
+    """configs[4] (rotate batched): groups of 4 / 2 ciphertexts through lf_ks_core_batch give, bit for bit, what
+    one rotate_single per ciphertext gives; for the small ring also what the checker composition gives."""
+    from liberate_fhe_amd.fhe import ckks_engine, presets
+    params = _rot_params() if name == "small13" else dict(presets.params[name])
+    params.pop("devices", None)
+    eng = ckks_engine(devices=["cuda:0"], **params)
+    rotk = synth.key_switch_key(eng, 7, origin="rotation key:3")
+    cts = [synth.ciphertext(eng, 200 + i, 0) for i in range(count - 1)] + [synth.ciphertext(eng, 300, 1)]
+    want = [digest(eng.rotate_single(ct, rotk)) for ct in cts]
+    got = [digest(x) for x in eng.rotate_single_batch(cts, rotk)]
+    assert got == want
+    if name == "small13":
+        from tests.oracle_backend import OracleBackend
+        chk = ckks_engine(devices=["cpu"], backend=OracleBackend(), **params)
+        rk = synth.key_switch_key(chk, 7, origin="rotation key:3")
+        cc = [synth.ciphertext(chk, 200 + i, 0) for i in range(count - 1)] + [synth.ciphertext(chk, 300, 1)]
+        assert [digest(chk.rotate_single(ct, rk)) for ct in cc] == want
