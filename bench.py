@@ -104,7 +104,12 @@ def engine_rates(dev, quick):
         torch.cuda.synchronize()
         ms = event_time_ms(lambda: eng.rotate_single_batch(cts, rotk), max(2, n // 4))
         out[f"rotate_single_{name}_batch{nb}_rotations_per_s"] = nb * 1e3 / ms
-        del cts
+        pairs = [(cts[i], cts[(i + 1) % nb]) for i in range(nb)]
+        eng.cc_mult_batch(pairs, evk)
+        torch.cuda.synchronize()
+        ms = event_time_ms(lambda: eng.cc_mult_batch(pairs, evk), max(2, n // 4))
+        out[f"cc_mult_evk_{name}_batch{nb}_ops_per_s"] = nb * 1e3 / ms
+        del cts, pairs
         del eng, a, b, evk, rotk
         torch.cuda.empty_cache()
     return out

@@ -972,19 +972,28 @@ class ckks_engine(EvaluatorOps):
     def _automorphism_batch(self, cts, exponent, key, level):
         """X -> X^exponent + key switch of len(cts) in (2, 4) ciphertexts of one level on the single local device
         (the rotate_single form: canonical words)."""
+        d = self._loc(level)[0]
+        pinv = pow(exponent, -1, 2 * self.ctx.N)
+        gal = (pinv, self._vec("_2q", d, level, False))
+        out = self._ks_batch([ct.data[1][0] for ct in cts], [(ct.data[0][0], None) for ct in cts], key, level, gal)
+        return [data_struct(data=([out[b][0]], [out[b][1]]), include_special=False, ntt_state=False,
+                            montgomery_state=ct.montgomery_state, origin=types.origins["ct"], level=level, hash=self.hash)
+                for b, ct in enumerate(cts)]
+
+    def _ks_batch(self, srcs, addends, key, level, gal=None):
+        """Key switch of len(srcs) in (2, 4) coefficient-domain polynomials ([ell, N] tensors on the single local
+        device of `level`) under one key; addends[b] = (add to c0, add to c1) or Nones.  Returns [nct, 2, ell, N]."""
         tabs = self._ks_tables(level)
         d = self._loc(level)[0]
         N, logN, K = self.ctx.N, self.ctx.logN, self.ntt.num_special_primes
-        nct = len(cts)
-        pinv = pow(exponent, -1, 2 * N)
+        nct = len(srcs)
         rows, ell = self._rows(d, level, True), self._rows(d, level, False)
         c_ord, cs = self._consts(d, level, False), self._consts(d, level, True)
-        gal = (pinv, self._vec("_2q", d, level, False))
-        # 1. mixed-radix digits of c1(X^p), one launch per ciphertext into a common stack
+        # 1. mixed-radix digits, one launch per polynomial into a common stack
         states = self._ws("ks_state_batch", (nct, ell, N), d)
         nparts_d, desc_d, tab_d = tabs[("digits", d)]
-        for b, ct in enumerate(cts):
-            self.backend.ks_digits(ct.data[1][0], states[b], nparts_d, desc_d, tab_d, c_ord, galois=gal)
+        for b, src in enumerate(srcs):
+            self.backend.ks_digits(src, states[b], nparts_d, desc_d, tab_d, c_ord, galois=gal)
         # 2. fused core over the whole group
         nparts = len(tabs["order"])
         ext = self._ws("ks_ext_batch", (nct, nparts, rows, N), d)
@@ -995,20 +1004,77 @@ class ckks_engine(EvaluatorOps):
         self.backend.ks_core_batch(states, nparts, rows, logN, desc, E, Ed, kpack, tabs["first_part"],
                                    self.ntt.starts[level][d], ext, s, self._tw(d, level, True),
                                    self._tw(d, level, True, True), self._vec("Ninv", d, level, True), cs)
-        # 3. divide by P, c0(X^p) added in gather form: one launch pair for the 2 * nct polynomials
+        # 3. divide by P (+ addends, in gather form under a Galois map): one launch pair for the 2 * nct polynomials
         out = torch.empty((nct, 2, ell, N), dtype=torch.int64, device=self.ntt.devices[d])
         ss = [s[b][comp] for b in range(nct) for comp in range(2)]
         outs = [out[b][comp] for b in range(nct) for comp in range(2)]
         adds = []
-        for ct in cts:
-            a0 = ct.data[0][0]
-            adds += [a0 if a0.is_contiguous() else a0.contiguous(), None]
+        for pair in addends:
+            for a in pair:
+                adds.append(a if a is None or a.is_contiguous() else a.contiguous())
         ws = self._ws("ks_moddown_batch", (self.backend.moddown_ws_words(2 * nct, ell, K, N),), d)
         self.backend.ks_moddown_ws(ss, outs, adds, ell, K, ws, tabs[("pir", d)], self._vec("Rs", d, level, True), cs,
                                    PiP=tabs[("pip", d)], galois=gal)
-        return [data_struct(data=([out[b][0]], [out[b][1]]), include_special=False, ntt_state=False,
-                            montgomery_state=ct.montgomery_state, origin=types.origins["ct"], level=level, hash=self.hash)
-                for b, ct in enumerate(cts)]
+        return out
+
+    def cc_mult_batch(self, pairs: list, evk: data_struct) -> list:
+        """cc_mult (+ relinearize) of several ciphertext pairs under one evaluation key: returns
+        [cc_mult(a, b, evk) for a, b in pairs], bit for bit.  On one GPU, groups of up to 4 pairs of one level share
+        the inverse transforms of their triplets (one launch) and the key switch (lf_ks_core_batch: one launch set,
+        the key read once per group)."""
+        out = [None] * len(pairs)
+        sizes = getattr(self.backend, "ks_batch_sizes", ())
+        groups = {}
+        for i, (a, b) in enumerate(pairs):
+            if a.origin != types.origins["ct"] or b.origin != types.origins["ct"]:
+                raise errors.NotMatchType(origin=f"{a.origin} and {b.origin}", to=types.origins["ct"])
+            lvl = a.level + 1
+            ok = (sizes and a.level == b.level and lvl < self.num_levels and self.len_devices[lvl] == 1
+                  and len(self._loc(lvl)) == 1 and self.len_devices[a.level] == 1
+                  and self.ctx.logN >= self.backend.fused_ks_min_logN
+                  and not (a.ntt_state or b.ntt_state or a.include_special or b.include_special))
+            if ok:
+                groups.setdefault(lvl, []).append(i)
+            else:
+                out[i] = self.cc_mult(a, b, evk)
+        for level, idx in groups.items():
+            pos = 0
+            while pos < len(idx):
+                n = next((k for k in sizes if k <= len(idx) - pos), 1)
+                if n == 1:
+                    a, b = pairs[idx[pos]]
+                    out[idx[pos]] = self.cc_mult(a, b, evk)
+                else:
+                    res = self._cc_mult_group([pairs[i] for i in idx[pos:pos + n]], evk, level)
+                    for i, r in zip(idx[pos:pos + n], res):
+                        out[i] = r
+                pos += n
+        return out
+
+    def _cc_mult_group(self, pairs, evk, level):
+        d = self._loc(level)[0]
+        N, logN = self.ctx.N, self.ctx.logN
+        nct = len(pairs)
+        rows = self._rows(d, level, False)
+        c = self._consts(d, level, False)
+        trip = torch.empty((nct, 3, rows, N), dtype=torch.int64, device=self.ntt.devices[d])
+        # rescale + forward transform of the operands, two pairs (8 polynomials) per launch
+        x = self._ws("mult8", (8, rows, N), d)
+        for t0 in range(0, nct, 2):
+            chunk = pairs[t0:t0 + 2]
+            per_dev, round_at = self._rescale_operands([ct for pair in chunk for ct in pair])
+            srcs, r0s = per_dev[d]
+            self.backend.rescale_ntt(srcs, r0s, x[:4 * len(chunk)], rows, logN, self.rescale_scales[level - 1][d], round_at,
+                                     self._tw(d, level, False), self._vec("Rs", d, level, False), c, relaxed=True, plain=True)
+            for k in range(len(chunk)):
+                t = t0 + k
+                self.backend.tensor(x[4 * k], x[4 * k + 1], x[4 * k + 2], x[4 * k + 3], trip[t][0], trip[t][1], trip[t][2],
+                                    rows, c, plain=True)
+        # the 3 * nct inverse transforms of the triplets: one launch
+        self.backend.intt(trip.view(3 * nct, rows, N), 3 * nct, rows, logN, self._tw(d, level, False, True),
+                          self._vec("Ninv", d, level, False), 2, c, relaxed=True, plain=True)
+        out = self._ks_batch([trip[t][2] for t in range(nct)], [(trip[t][0], trip[t][1]) for t in range(nct)], evk, level)
+        return [self._new(([out[t][0]], [out[t][1]]), types.origins["ct"], level=level) for t in range(nct)]
 
     def rotate_galois(self, ct: data_struct, gk: data_struct, delta: int, return_circuit=False) -> data_struct:
         if ct.origin != types.origins["ct"]:

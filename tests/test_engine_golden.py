@@ -143,3 +143,29 @@ def test_hip_rotate_single_batch_equals_loop(name, count):
         rk = synth.key_switch_key(chk, 7, origin="rotation key:3")
         cc = [synth.ciphertext(chk, 200 + i, 0) for i in range(count - 1)] + [synth.ciphertext(chk, 300, 1)]
         assert [digest(chk.rotate_single(ct, rk)) for ct in cc] == want
+
+
+def test_cc_mult_batch_checker_equals_loop():
+    from liberate_fhe_amd.fhe import ckks_engine
+    from tests.oracle_backend import OracleBackend
+    eng = ckks_engine(devices=["cpu"], backend=OracleBackend(), **_rot_params())
+    evk = synth.key_switch_key(eng, 9)
+    pairs = [(synth.ciphertext(eng, 400 + i, 0), synth.ciphertext(eng, 500 + i, 0)) for i in range(3)]
+    want = [digest(eng.cc_mult(a, b, evk)) for a, b in pairs]
+    assert [digest(x) for x in eng.cc_mult_batch(pairs, evk)] == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,count", [("small13", 7), ("silver", 6), ("gold", 4)])
+def test_hip_cc_mult_batch_equals_loop(name, count):
+    """Groups of 4 / 2 multiplications under one evaluation key (shared inverse-transform launch + lf_ks_core_batch)
+    equal one cc_mult per pair, bit for bit; mixed levels fall into separate groups."""
+    from liberate_fhe_amd.fhe import ckks_engine, presets
+    params = _rot_params() if name == "small13" else dict(presets.params[name])
+    params.pop("devices", None)
+    eng = ckks_engine(devices=["cuda:0"], **params)
+    evk = synth.key_switch_key(eng, 9)
+    pairs = [(synth.ciphertext(eng, 400 + i, 0), synth.ciphertext(eng, 500 + i, 0)) for i in range(count - 1)]
+    pairs.append((synth.ciphertext(eng, 600, 1), synth.ciphertext(eng, 601, 1)))
+    want = [digest(eng.cc_mult(a, b, evk)) for a, b in pairs]
+    assert [digest(x) for x in eng.cc_mult_batch(pairs, evk)] == want

@@ -20,4 +20,9 @@ def timed(fn, n=5):
     return e0.elapsed_time(e1) / n
 loop = timed(lambda: [eng.rotate_single(ct, rotk) for ct in cts])
 batch = timed(lambda: eng.rotate_single_batch(cts, rotk))
+evk = synth.key_switch_key(eng, 5)
+pairs = [(cts[i], cts[(i + 1) % B]) for i in range(B)]
+mloop = timed(lambda: [eng.cc_mult(a, b, evk) for a, b in pairs])
+mbatch = timed(lambda: eng.cc_mult_batch(pairs, evk))
+print(f"{name} x{B}: cc_mult loop {mloop*1e3/B:.1f} us/op ({B/mloop*1e3:.0f} ops/s)   batch {mbatch*1e3/B:.1f} us/op ({B/mbatch*1e3:.0f} ops/s)")
 print(f"{name} x{B}: loop {loop*1e3/B:.1f} us/ct ({B/loop*1e3:.0f} rot/s)   batch {batch*1e3/B:.1f} us/ct ({B/batch*1e3:.0f} rot/s)")
