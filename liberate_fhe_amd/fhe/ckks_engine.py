@@ -87,6 +87,8 @@ class ckks_engine(EvaluatorOps):
         self._tables = {}
         self._key_packs = {}
         self._workspace = {}
+        self._lane = 0          # pipeline lane whose workspaces / stream the batched ops currently use
+        self._lane_streams = {}
 
         ds, nd, ls = data_struct, np.ndarray, list
         self.mult_dispatch_dict = {
@@ -136,8 +138,8 @@ class ckks_engine(EvaluatorOps):
         return getattr(self.ntt, name)[dev][a:b]
 
     def _ws(self, key, shape, dev_id):
-        """Reusable scratch tensor (never returned to the caller)."""
-        k = (key, tuple(shape), dev_id)
+        """Reusable scratch tensor (never returned to the caller); one set per pipeline lane (see _lanes)."""
+        k = (key, tuple(shape), dev_id, self._lane)
         t = self._workspace.get(k)
         if t is None:
             t = torch.empty(shape, dtype=torch.int64, device=self.ntt.devices[dev_id])
@@ -957,17 +959,56 @@ class ckks_engine(EvaluatorOps):
         delta = int(rotk.origin.split(":")[-1])
         exponent = encdec.galois_exponent(self.ctx.N, delta)
         for level, idx in groups.items():
-            pos = 0
+            jobs, slots, pos = [], [], 0
             while pos < len(idx):
                 n = next((k for k in sizes if k <= len(idx) - pos), 1)
+                sel = idx[pos:pos + n]
                 if n == 1:
-                    out[idx[pos]] = self.rotate_single(cts[idx[pos]], rotk)
+                    jobs.append(lambda sel=sel: [self.rotate_single(cts[sel[0]], rotk)])
                 else:
-                    res = self._automorphism_batch([cts[i] for i in idx[pos:pos + n]], exponent, rotk, level)
-                    for i, r in zip(idx[pos:pos + n], res):
-                        out[i] = r
+                    jobs.append(lambda sel=sel: self._automorphism_batch([cts[i] for i in sel], exponent, rotk, level))
+                slots.append(sel)
                 pos += n
+            for sel, res in zip(slots, self._run_groups(jobs, self._loc(level)[0])):
+                for i, r in zip(sel, res):
+                    out[i] = r
         return out
+
+    def _run_groups(self, jobs, dev_id):
+        """Run independent group jobs (callables returning lists of data_structs) alternately on two streams of
+        the device: a group's memory-bound phases (the key stream of the inner product) overlap the other group's
+        instruction-bound ones, and launch tails fill.  Each lane has its own workspaces.  Returns the results in
+        order; the caller's stream waits for the side lane before returning."""
+        device = self.ntt.devices[dev_id]
+        if len(jobs) < 2 or not str(device).startswith("cuda") or os.environ.get("LF_ENGINE_LANES", "2") == "1":
+            return [job() for job in jobs]
+        main = torch.cuda.current_stream(device)
+        side = self._lane_streams.get(dev_id)
+        if side is None:
+            side = self._lane_streams[dev_id] = torch.cuda.Stream(device=device)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        side.wait_event(fork)
+        results = []
+        try:
+            for n, job in enumerate(jobs):
+                self._lane = n & 1
+                if self._lane:
+                    with torch.cuda.stream(side):
+                        res = job()
+                    for r in res:
+                        for comp in r.data:
+                            for t in comp:
+                                t.record_stream(main)
+                else:
+                    res = job()
+                results.append(res)
+        finally:
+            self._lane = 0
+        join = torch.cuda.Event()
+        join.record(side)
+        main.wait_event(join)
+        return results
 
     def _automorphism_batch(self, cts, exponent, key, level):
         """X -> X^exponent + key switch of len(cts) in (2, 4) ciphertexts of one level on the single local device
@@ -1038,17 +1079,19 @@ class ckks_engine(EvaluatorOps):
             else:
                 out[i] = self.cc_mult(a, b, evk)
         for level, idx in groups.items():
-            pos = 0
+            jobs, slots, pos = [], [], 0
             while pos < len(idx):
                 n = next((k for k in sizes if k <= len(idx) - pos), 1)
+                sel = idx[pos:pos + n]
                 if n == 1:
-                    a, b = pairs[idx[pos]]
-                    out[idx[pos]] = self.cc_mult(a, b, evk)
+                    jobs.append(lambda sel=sel: [self.cc_mult(pairs[sel[0]][0], pairs[sel[0]][1], evk)])
                 else:
-                    res = self._cc_mult_group([pairs[i] for i in idx[pos:pos + n]], evk, level)
-                    for i, r in zip(idx[pos:pos + n], res):
-                        out[i] = r
+                    jobs.append(lambda sel=sel: self._cc_mult_group([pairs[i] for i in sel], evk, level))
+                slots.append(sel)
                 pos += n
+            for sel, res in zip(slots, self._run_groups(jobs, self._loc(level)[0])):
+                for i, r in zip(sel, res):
+                    out[i] = r
         return out
 
     def _cc_mult_group(self, pairs, evk, level):
