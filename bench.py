@@ -138,7 +138,18 @@ def multi_gpu_rates(dev, world, rank, sharded):
         t = torch.tensor([ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         out["cc_mult_evk_gold_replicas_ops_per_s"] = world * 1e3 / float(t.item())
-        del eng, a, b, evk
+        # the same replicas multiplying batches of 16 pairs under their key (cc_mult_batch)
+        nb = 16
+        cts = [synth.ciphertext(eng, 100 + i, 0) for i in range(nb)]
+        pairs = [(cts[i], cts[(i + 1) % nb]) for i in range(nb)]
+        eng.cc_mult_batch(pairs, evk)
+        torch.cuda.synchronize()
+        dist.barrier()
+        ms = event_time_ms(lambda: eng.cc_mult_batch(pairs, evk), 3)
+        t = torch.tensor([ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out[f"cc_mult_evk_gold_replicas_batch{nb}_ops_per_s"] = world * nb * 1e3 / float(t.item())
+        del eng, a, b, evk, cts, pairs
         torch.cuda.empty_cache()
         if not sharded:
             return out
