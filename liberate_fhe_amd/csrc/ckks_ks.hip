@@ -34,7 +34,6 @@ struct KsGeom {
     int logN, tl, S1;
     int rows;        // target limbs on this device (with special)
     int nparts;      // digits
-    int groups;      // part groups (partial sums) of the inner product
     i64 N;
     int nct;         // ciphertexts switched under the same key in this call (lf_ks_core_batch)
     i64 state_stride;   // words between their digit states
@@ -71,7 +70,7 @@ __device__ __forceinline__ void ks_ext_body(i64 *sm, int b, const i64 *__restric
     }
     const int tile = pt % tiles, p = pt / tiles;
     const int crow = rl.id[ri];
-    const PassGeom g{kg.logN, kg.tl, 1, kg.S1, 0, kg.tl - kg.S1, kg.rows, kg.nparts, 1, 0, 0, 1, 0};
+    const PassGeom g{kg.logN, kg.tl, 1, kg.S1, 0, kg.tl - kg.S1, kg.rows, kg.nparts, 1, 0, 0};
 
     Ctx c;
     c.m = load_mod(ql, qh, kl, kh, crow);
@@ -79,7 +78,6 @@ __device__ __forceinline__ void ks_ext_body(i64 *sm, int b, const i64 *__restric
     c.tw_mont = psi_br + ((i64)crow << kg.logN);
     c.tw_dp = DP ? psi_dp + ((i64)crow << kg.logN) : nullptr;
     c.relaxed = 1;
-    c.inv_off = 0.0;
     c.inv_reduce = 0;
     // desc[p] = {row_start, alpha | wide << 8, e_off}; wide = the digit's words exceed 53 bits (a digit made of
     // 60-bit primes, i.e. the base-prime digit): they are split into 31-bit halves before entering fp64
@@ -293,7 +291,7 @@ int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int np
     if (int e = lf_set_device(device)) return e;
     hipStream_t st = (hipStream_t)stream;
     const int tl = NTT_TILE_LOG_MAX, S1 = logN - tl;
-    const KsGeom kg{logN, tl, S1, rows, nparts, 1, (i64)1 << logN, nct, (i64)state_stride};
+    const KsGeom kg{logN, tl, S1, rows, nparts, (i64)1 << logN, nct, (i64)state_stride};
     RowList dp, in;
     classify_rows(rows, q_host, dp, in);
     const unsigned tiles = 1u << (logN - tl);
@@ -316,7 +314,7 @@ int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int np
                            (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     // contiguous forward pass, in place on tmp (relaxed)
     {
-        const PassGeom g{logN, tl, 0, tl, S1, 0, rows, (int)polys, 1, 1, 0, 1, 0};
+        const PassGeom g{logN, tl, 0, tl, S1, 0, rows, (int)polys, 1, 1, 0};
         const unsigned per_row = polys << (logN - tl);
         if (mixed) {
             const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
@@ -351,8 +349,8 @@ int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int np
     const int inv_polys = 2 * nct;
     const unsigned per_row2 = (unsigned)inv_polys << (logN - tl);
     for (int pass = 0; pass < 2; ++pass) {
-        PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, inv_polys, 1, 0, 0, 1, 0}
-                               : PassGeom{logN, tl, 1, S1, tl, tl - S1, rows, inv_polys, 1, 1, 0, 1, 0};
+        PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, inv_polys, 1, 0, 0}
+                               : PassGeom{logN, tl, 1, S1, tl, tl - S1, rows, inv_polys, 1, 1, 0};
         if (pass == 1 && S1 <= 4 && cols_enabled()) {
             if (mixed) {
                 launch_inv_cols_mixed(S1, inv_polys, st, (i64 *)s, g, in, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,

@@ -233,8 +233,8 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
         const unsigned per_row = (unsigned)nb << (logN - tl);
         for (int pass = (S1 > 0 ? 0 : 1); pass < 2; ++pass) {
             if (only_pass && pass + 1 != only_pass) continue;   // measurement only: time one pass kernel by itself
-            const PassGeom g = pass == 0 ? PassGeom{logN, tl, 1, S1, 0, tl - S1, rows, nb, relaxed, 0, plain, 1, 0}
-                                         : PassGeom{logN, tl, 0, tl, S1, 0, rows, nb, relaxed, 1, plain, 1, 0, regtile_disabled()};
+            const PassGeom g = pass == 0 ? PassGeom{logN, tl, 1, S1, 0, tl - S1, rows, nb, relaxed, 0, plain}
+                                         : PassGeom{logN, tl, 0, tl, S1, 0, rows, nb, relaxed, 1, plain, regtile_disabled()};
             const i64 *rs = (pass == 0 || S1 == 0) ? (const i64 *)Rs : nullptr;
             if (pass == 0 && S1 <= 4 && cols_enabled()) {   // leading stages: one register step per column
                 const unsigned col_blocks = (unsigned)nb * ((1u << (logN - S1)) / NTT_COL_THREADS);
@@ -307,8 +307,8 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
         i64 *base = (i64 *)a + ((i64)b0 * rows << logN);
         const unsigned per_row = (unsigned)nb << (logN - tl);
         for (int pass = 0; pass < (SB > 0 ? 2 : 1); ++pass) {
-            const PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, nb, relaxed, SB == 0, plain, 1, 0, regtile_disabled()}
-                                         : PassGeom{logN, tl, 1, SB, tl, tl - SB, rows, nb, relaxed, 1, plain, 1, 0};
+            const PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, nb, relaxed, SB == 0, plain, regtile_disabled()}
+                                         : PassGeom{logN, tl, 1, SB, tl, tl - SB, rows, nb, relaxed, 1, plain};
             const int t = g.last ? tail : TAIL_NONE;
             if (pass == 1 && SB <= 4 && cols_enabled()) {   // trailing stages + chain tail: one register step per column
                 if (mixed) {

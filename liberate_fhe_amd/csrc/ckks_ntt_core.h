@@ -10,7 +10,6 @@
 #define NTT_LDS_WORDS ((1 << NTT_TILE_LOG_MAX) + (1 << (NTT_TILE_LOG_MAX - 3)))
 #define TAIL_NONE (-1)
 #define SMALL_PRIME_LIMIT (1ull << 41)
-#define LAZY_FIX_LIMIT 4194304.0   // 2^22 > (2q)^2 / 2^62 for q < 2^41
 #define MAX_LIST_ROWS 250
 
 #define PAD(L) ((L) + ((L) >> 3))
@@ -64,8 +63,6 @@ struct PassGeom {
     int last;      // 1: last pass of the transform
     int plain;     // relaxed only: fp64-class limbs work in the PLAIN domain — no Montgomery entry on the way in
                    // (Rs applies to integer-class limbs only), inverse tail multiplies by N^-1 instead of N^-1 R^-1
-    int nsum;      // relaxed only: the input tile is the sum of `nsum` stacks (<= 1: plain load)
-    i64 sum_stride;  // words between those stacks
     int noreg;     // experiment knob (LF_NTT_REGTILE=0): 4096-word contiguous passes in the LDS-resident form
 };
 
@@ -104,13 +101,7 @@ __device__ __forceinline__ void prefetch_tile(longlong2 (&pre)[NTT_PRE], const i
         const int L = (threadIdx.x + v * NTT_THREADS) * 2;
         if (L < T) {
             const i64 *src = row + tile_gaddr(g, tile, L);
-            longlong2 w = *reinterpret_cast<const longlong2 *>(src);
-            for (int k = 1; k < g.nsum; ++k) {   // partial sums of the fused key switch
-                const longlong2 t = *reinterpret_cast<const longlong2 *>(src + k * g.sum_stride);
-                w.x += t.x;
-                w.y += t.y;
-            }
-            pre[v] = w;
+            pre[v] = *reinterpret_cast<const longlong2 *>(src);
         }
     }
 }
@@ -124,13 +115,9 @@ __device__ __forceinline__ int stash_tile(i64 *sm, const longlong2 (&pre)[NTT_PR
         const int L = (threadIdx.x + v * NTT_THREADS) * 2;
         if (L < T) {
             longlong2 w = pre[v];
-            if (g.relaxed) {   // residues only: fold the signed-lazy words (and summed stacks) into [0, 2q)
+            if (g.relaxed) {   // residues only: fold the signed-lazy words into [0, 2q)
                 w.x = w.x < 0 ? w.x + q2 : w.x;
                 w.y = w.y < 0 ? w.y + q2 : w.y;
-                for (int k = 1; k < g.nsum; ++k) {
-                    w.x = w.x >= q2 ? w.x - q2 : w.x;
-                    w.y = w.y >= q2 ? w.y - q2 : w.y;
-                }
             }
             odd_word |= ((u64)w.x >= (u64)q2) | ((u64)w.y >= (u64)q2);
             sm[PAD(L)] = w.x;
@@ -186,7 +173,7 @@ __device__ __forceinline__ double dp_reduce(double x, double m, double minv) {
     return __builtin_fma(-quo, m, x);
 }
 
-// v < 2^22 for a canonical v >= 0, as one 32-bit compare on the high word (an fp64 compare costs twice as much);
+// v < 2^22 (> (2q)^2 / 2^62 for q < 2^41: below it the lazy REDC word may be T0 + q) for a canonical v >= 0, as one 32-bit compare on the high word (an fp64 compare costs twice as much);
 // -0.0 counts as below, like +0.0
 __device__ __forceinline__ bool dp_below_fix_limit(double v) { return __double2hiint(v) < 0x41500000; }
 
@@ -225,7 +212,6 @@ struct Ctx {
     const i64 *tw_mont;     // compact Montgomery twiddles of this limb (always valid)
     const double *tw_dp;    // compact plain twiddles as doubles (fp64 class)
     int relaxed;
-    double inv_off;         // fp64 inverse steps: offset keeping U - V non-negative (multiple of 2q)
     int inv_reduce;         // fp64 inverse steps: reduce mod 2q at the end of this step
 };
 
@@ -525,15 +511,12 @@ __device__ __forceinline__ void run_inv_stages(typename A::T *sm, const PassGeom
     const int base = g.strided ? 0 : (tile << g.tl);
     int s = g.s0, left = g.S, log_d = g.strided ? g.logC : 0;
     Ctx cc = c;
-    // fp64 class: words start < 2q; each step multiplies the bound by 2^K; reduce every second step
-    double bound = c.d.q2;
+    // fp64 class: words start < 2q and each step of K stages multiplies their bound by 2^K (<= 2^6 over two
+    // radix-8 steps, within dp_reduce's |x| < 64 * 2q): reduce at the end of every second step and of the last one
     int nstep = 0;
     auto arm = [&](int K) {
-        cc.inv_off = bound * (double)(1 << K);
-        bound = cc.inv_off;
         ++nstep;
         cc.inv_reduce = ((nstep & 1) == 0) || (left - K <= 0);
-        if (cc.inv_reduce) bound = c.d.q2;
     };
     if (FAST && g.tl == 12 && g.S == 12) {   // the next step's twiddles are requested before each barrier
         StepTwInv<A, 0> t0;
@@ -868,14 +851,13 @@ __device__ __forceinline__ void fwd_pass_body(i64 *sm, int b, i64 *__restrict__ 
         c.tw_mont = psi_br + ((i64)crow << g.logN);
         c.tw_dp = DP ? psi_dp + ((i64)crow << g.logN) : nullptr;
         c.relaxed = g.relaxed;
-        c.inv_off = 0.0;
         c.inv_reduce = 0;
         i64 *row = a + ((i64)(poly * g.rows + crow) << g.logN);
         const int cur_tile = tile;
         const i64 rs = enter ? Rs[crow] : 0;
 
         // contiguous 4096-word pass: register-fed form; false = the tile holds a word outside [0, 2q)
-        if (g.tl == 12 && g.S == 12 && !g.strided && !g.noreg && g.nsum <= 1) {
+        if (g.tl == 12 && g.S == 12 && !g.strided && !g.noreg) {
             if (fwd_tile12<DP>(sm, row, tile, g, c, enter, rs)) return;
         }
 
@@ -1030,7 +1012,6 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
     c.tw_mont = psi_br + ((i64)crow << g.logN);
     c.tw_dp = DP ? psi_dp + ((i64)crow << g.logN) : nullptr;
     c.relaxed = g.relaxed;
-    c.inv_off = 0.0;
     c.inv_reduce = 0;
     const i64 rs = enter ? Rs[crow] : 0;
     i64 *col = a + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS + threadIdx.x;
@@ -1151,14 +1132,13 @@ __device__ __forceinline__ void inv_pass_body(i64 *sm, int b, const i64 *src, i6
         c.tw_mont = ipsi_br + ((i64)crow << g.logN);
         c.tw_dp = DP ? ipsi_dp + ((i64)crow << g.logN) : nullptr;
         c.relaxed = g.relaxed;
-        c.inv_off = 0.0;
         c.inv_reduce = 0;
         i64 *row = dst + ((i64)(poly * g.rows + crow) << g.logN);
         const int cur_tile = tile, cur_row = crow;
         const i64 qq = (i64)c.m.q;
 
         // contiguous 4096-word pass: register-fed form; false = the tile holds a word outside [0, 2q)
-        if (g.tl == 12 && g.S == 12 && !g.strided && !g.noreg && g.nsum <= 1) {
+        if (g.tl == 12 && g.S == 12 && !g.strided && !g.noreg) {
             if (inv_tile12<DP>(sm, src + ((i64)(poly * g.rows + crow) << g.logN), row, tile, g, c, Ninv, tail, crow)) return;
         }
 
@@ -1298,7 +1278,6 @@ __device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const 
     c.tw_mont = ipsi_br + ((i64)crow << g.logN);
     c.tw_dp = DP ? ipsi_dp + ((i64)crow << g.logN) : nullptr;
     c.relaxed = g.relaxed;
-    c.inv_off = 0.0;
     c.inv_reduce = 0;
     const i64 ninv_mont = (tail != TAIL_NONE) ? Ninv[crow] : 0;
     i64 *col = a + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS + threadIdx.x;
