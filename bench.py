@@ -272,13 +272,16 @@ def main():
         del os.environ["LF_NTT_ONLY_PASS"]
     alg_bytes_per_launch = 8 * N * L_LIMBS * B                      # 16*N per limb per transform, two launches
     achieved = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
-    traffic = None
+    traffic = valu = None
     tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath))   # PMC bytes per launch at the profiled batch; a launch's traffic is linear in the batch
         traffic = tj.get("ntt_fwd_pass_mixed_bytes_per_launch")
         if traffic is not None:
             traffic = traffic * B / float(tj.get("batch_per_gpu", 16))
+        valu = tj.get("ntt_fwd_pass_mixed_valu_wave_instr_per_launch")
+        if valu is not None:
+            valu = valu * B / float(tj.get("batch_per_gpu", 16))
 
     result = {
         "metric": "NTTs/sec (forward negacyclic poly-NTT, logN=16, L=30 limbs, bit-exact vs reference semantics)",
@@ -295,7 +298,13 @@ def main():
                      "column_pass_launch_ms": cols_ms,
                      "column_pass_algorithmic_GBps": alg_bytes_per_launch / (cols_ms * 1e-3) / 1e9,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                     "whole_step_algorithmic_GBps": 16 * N * L_LIMBS * B / (dev_ms * 1e-3) / 1e9},
+                     "whole_step_algorithmic_GBps": 16 * N * L_LIMBS * B / (dev_ms * 1e-3) / 1e9,
+                     # what actually bounds the kernel: VALU issue.  Wave-instructions per launch from the PMC pass
+                     # in profiles/ (scaled to the batch) over the live launch time, against the measured rate of
+                     # back-to-back v_fma_f64 on this part (profiles/r01_ubench.txt)
+                     "valu_issue": None if valu is None else {
+                         "wave_instr_per_launch": valu, "achieved_G_per_s": valu / (k_ms * 1e-3) / 1e9,
+                         "peak_fma_f64_G_per_s": 455.6, "frac": valu / (k_ms * 1e-3) / 455.6e9}},
     }
     extra = {"limb_ntt_per_s": value * L_LIMBS, "device_ms_per_step": dev_ms}
     if rank == 0 and world == 1 and not args.no_extra:

@@ -86,5 +86,13 @@ traffic = {"ntt_fwd_pass_mixed_bytes_per_launch": (2 * fetch + write) * 1024, "b
 cf, cw = per["FETCH_SIZE_cols"], per["WRITE_SIZE_cols"]
 if cf and cw:
     traffic["ntt_fwd_cols_mixed_bytes_per_launch"] = (2 * sum(v for _, v, _ in cf) / len(cf) + sum(v for _, v, _ in cw) / len(cw)) * 1024
+# keep the instruction-count entries of an earlier PMC pass (tools/pmc_one.sh) if this run did not produce them
+try:
+    prev = json.load(open(os.path.join(out_dir, f"traffic_{tag}.json")))
+    for k in ("ntt_fwd_pass_mixed_valu_wave_instr_per_launch", "valu_note"):
+        if k in prev and k not in traffic:
+            traffic[k] = prev[k]
+except Exception:
+    pass
 json.dump(traffic, open(os.path.join(out_dir, f"traffic_{tag}.json"), "w"), indent=1)
 print(traffic)
