@@ -169,3 +169,32 @@ def test_hip_cc_mult_batch_equals_loop(name, count):
     pairs.append((synth.ciphertext(eng, 600, 1), synth.ciphertext(eng, 601, 1)))
     want = [digest(eng.cc_mult(a, b, evk)) for a, b in pairs]
     assert [digest(x) for x in eng.cc_mult_batch(pairs, evk)] == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [1, 2, 3, 5, 6])
+def test_moddown_ws_equals_chunked_kernel(K):
+    """lf_ks_moddown_ws (pivots once per coefficient + closed form, template on K) against lf_ks_moddown_batch (the
+    reference's chain per row chunk, itself pinned by the engine digests), with and without addends / Galois gather."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    eng = ckks_engine(devices=["cuda:0"], logN=13, num_scales=6, num_special_primes=K, is_secured=False)
+    level, d = 0, 0
+    tabs = eng._ks_tables(level)
+    N = eng.ctx.N
+    rows, ell = eng._rows(d, level, True), eng._rows(d, level, False)
+    cs = eng._consts(d, level, True)
+    dest = eng.ntt.p.destination_arrays_with_special[level][d]
+    rng = np.random.default_rng(50 + K)
+    def canon(n_rows, ids):
+        return torch.from_numpy(np.stack([rng.integers(0, eng.ctx.q[i], size=N, dtype=np.int64) for i in ids[:n_rows]])).cuda()
+    s = [canon(rows, dest) for _ in range(4)]
+    adds = [canon(ell, dest), None, canon(ell, dest), canon(ell, dest)]
+    rs = eng._vec("Rs", d, level, True)
+    for gal in (None, (pow(5, -1, 2 * N), eng._vec("_2q", d, level, False))):
+        want = [torch.empty((ell, N), dtype=torch.int64, device="cuda") for _ in range(4)]
+        got = [torch.empty((ell, N), dtype=torch.int64, device="cuda") for _ in range(4)]
+        eng.backend.ks_moddown_batch(s, want, adds, ell, K, tabs[("pir", d)], rs, cs, PiP=tabs[("pip", d)], galois=gal)
+        ws = torch.empty(eng.backend.moddown_ws_words(4, ell, K, N), dtype=torch.int64, device="cuda")
+        eng.backend.ks_moddown_ws(s, got, adds, ell, K, ws, tabs[("pir", d)], rs, cs, PiP=tabs[("pip", d)], galois=gal)
+        for w, g in zip(want, got):
+            assert torch.equal(w, g)
