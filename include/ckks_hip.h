@@ -173,6 +173,12 @@ int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64
                const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
                const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 
+/* lf_ks_digits(_galois) of `count` (<= 8) polynomials in one launch: a / state are HOST arrays of device pointers
+ * (gal_pinv = 0: no Galois map). */
+int lf_ks_digits_batch(const int64_t *const *a, int64_t *const *state, int count, int nparts, const int64_t *desc,
+                       const int64_t *tab, int64_t N, int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql,
+                       const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+
 /* lf_ks_core for `nct` (1, 2 or 4) ciphertexts switched under the SAME key (a batch of rotations by one step,
  * config "rotate batched 64 ciphertexts"): every launch covers all of them and the inner product reads each key
  * word once for the whole batch.  state: nct digit states `state_stride` words apart; tmp scratch

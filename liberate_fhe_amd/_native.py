@@ -50,6 +50,7 @@ _SIGNATURES = {
     "lf_ks_moddown_batch": [_P, _P, _P, _I, _I, _I, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _P],
     "lf_ks_moddown_ws": [_P, _P, _P, _I, _I, _I, _L, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _P],
     "lf_ks_moddown_ws_words": [_I, _I, _I, _L],
+    "lf_ks_digits_batch": [_P, _P, _I, _I, _P, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P],
     "lf_ks_digits_galois": [_P, _P, _I, _P, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P],
     "lf_galois_batch": [_P, _P, _I, _I, _I, _L, _P, _I, _P],
     "lf_rescale_ntt": [_P, _P, _I, _P, _I, _I, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P],

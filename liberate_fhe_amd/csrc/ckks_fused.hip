@@ -120,11 +120,14 @@ static __device__ __forceinline__ i64 galois_read(const i64 *row, i64 j, i64 N, 
 // ---- key-switch step 1: mixed-radix digits of each key-switch part (pre_extend, 654-705) ---------
 // desc[p] = {row_start, alpha, y_off, l_off}; Y_scalar[i] = tab[y_off + i];
 // L_scalar[i][j-(i+2)] = tab[l_off + running index in (i, j) order].
-__global__ void __launch_bounds__(256) ks_digits_kernel(const i64 *__restrict__ a, i64 *__restrict__ state,
+// blockIdx.z: one of up to LF_BATCH_MAX polynomials (pb.in[z] -> pb.out[z]) sharing the tables
+__global__ void __launch_bounds__(256) ks_digits_kernel(PtrBatch pb,
                                                         const i64 *__restrict__ desc, const i64 *__restrict__ tab, i64 N,
                                                         i64 gal_pinv, const i64 *__restrict__ gal_2q,
                                                         const i64 *__restrict__ ql, const i64 *__restrict__ qh,
                                                         const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    const i64 *__restrict__ a = pb.in[blockIdx.z];
+    i64 *__restrict__ state = pb.out[blockIdx.z];
     const int p = blockIdx.y;
     const i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
     if (j >= N) return;
@@ -508,30 +511,32 @@ int lf_tensor(const int64_t *x0, const int64_t *x1, const int64_t *y0, const int
     return (int)hipGetLastError();
 }
 
+int lf_ks_digits_batch(const int64_t *const *a, int64_t *const *state, int count, int nparts, const int64_t *desc,
+                       const int64_t *tab, int64_t N, int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql,
+                       const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (count < 0 || count > LF_BATCH_MAX || nparts < 0 || N < 1 || gal_pinv < 0 || gal_pinv >= 2 * N ||
+        (gal_pinv && (!(gal_pinv & 1) || (N & (N - 1)))))
+        return LF_ERR_ARG;
+    if (nparts == 0 || count == 0) return 0;
+    if (int e = lf_set_device(device)) return e;
+    PtrBatch pb;
+    for (int i = 0; i < count; ++i) pb.in[i] = (const i64 *)a[i], pb.aux[i] = nullptr, pb.out[i] = (i64 *)state[i];
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)nparts, (unsigned)count);
+    hipLaunchKernelGGL(ks_digits_kernel, grid, dim3(256), 0, (hipStream_t)stream, pb, (const i64 *)desc, (const i64 *)tab,
+                       (i64)N, (i64)gal_pinv, (const i64 *)gal_2q, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl,
+                       (const i64 *)kh);
+    return (int)hipGetLastError();
+}
+
 int lf_ks_digits_galois(const int64_t *a, int64_t *state, int nparts, const int64_t *desc, const int64_t *tab, int64_t N,
                         int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl,
                         const int64_t *kh, int device, void *stream) {
-    if (nparts < 0 || N < 1 || gal_pinv < 0 || gal_pinv >= 2 * N || (gal_pinv && !(gal_pinv & 1)) || (N & (N - 1)))
-        return LF_ERR_ARG;
-    if (nparts == 0) return 0;
-    if (int e = lf_set_device(device)) return e;
-    dim3 grid((unsigned)((N + 255) / 256), (unsigned)nparts);
-    hipLaunchKernelGGL(ks_digits_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const i64 *)a, (i64 *)state, (const i64 *)desc,
-                       (const i64 *)tab, (i64)N, (i64)gal_pinv, (const i64 *)gal_2q, (const i64 *)ql, (const i64 *)qh,
-                       (const i64 *)kl, (const i64 *)kh);
-    return (int)hipGetLastError();
+    return lf_ks_digits_batch(&a, &state, 1, nparts, desc, tab, N, gal_pinv, gal_2q, ql, qh, kl, kh, device, stream);
 }
 
 int lf_ks_digits(const int64_t *a, int64_t *state, int nparts, const int64_t *desc, const int64_t *tab, int64_t N,
                  const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
-    if (nparts < 0 || N < 1) return LF_ERR_ARG;
-    if (nparts == 0) return 0;
-    if (int e = lf_set_device(device)) return e;
-    dim3 grid((unsigned)((N + 255) / 256), (unsigned)nparts);
-    hipLaunchKernelGGL(ks_digits_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const i64 *)a, (i64 *)state, (const i64 *)desc,
-                       (const i64 *)tab, (i64)N, (i64)0, (const i64 *)nullptr, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl,
-                       (const i64 *)kh);
-    return (int)hipGetLastError();
+    return lf_ks_digits_batch(&a, &state, 1, nparts, desc, tab, N, 0, nullptr, ql, qh, kl, kh, device, stream);
 }
 
 int lf_ks_extend(const int64_t *state, int64_t *ext, int nparts, int rows, int64_t N, const int64_t *desc, const int64_t *E,

@@ -135,6 +135,13 @@ class HipBackend:
             check(lib.lf_ks_digits_galois(_p(a), _p(state), nparts, _p(desc), _p(tab), a.size(-1), galois[0], _p(galois[1]),
                                           *c.mont(), dev, st), "lf_ks_digits_galois")
 
+    def ks_digits_batch(self, srcs, states, nparts, desc, tab, c: Consts, galois=None):
+        """ks_digits of len(srcs) (<= 8) polynomials in one launch."""
+        dev, st = _ds(srcs[0])
+        pinv, g2q = (0, None) if galois is None else galois
+        check(lib.lf_ks_digits_batch(_parr(srcs), _parr(states), len(srcs), nparts, _p(desc), _p(tab), srcs[0].size(-1), pinv,
+                                     _p(g2q), *c.mont(), dev, st), "lf_ks_digits_batch")
+
     def ks_extend(self, state, ext, nparts, rows, desc, E, c: Consts):
         dev, st = _ds(ext)
         check(lib.lf_ks_extend(_p(state), _p(ext), nparts, rows, ext.size(-1), _p(desc), _p(E), *c.mont(), dev, st),

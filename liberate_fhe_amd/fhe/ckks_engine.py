@@ -1030,11 +1030,11 @@ class ckks_engine(EvaluatorOps):
         nct = len(srcs)
         rows, ell = self._rows(d, level, True), self._rows(d, level, False)
         c_ord, cs = self._consts(d, level, False), self._consts(d, level, True)
-        # 1. mixed-radix digits, one launch per polynomial into a common stack
+        # 1. mixed-radix digits of all polynomials, one launch, into a common stack
         states = self._ws("ks_state_batch", (nct, ell, N), d)
         nparts_d, desc_d, tab_d = tabs[("digits", d)]
-        for b, src in enumerate(srcs):
-            self.backend.ks_digits(src, states[b], nparts_d, desc_d, tab_d, c_ord, galois=gal)
+        srcs = [src if src.is_contiguous() else src.contiguous() for src in srcs]
+        self.backend.ks_digits_batch(srcs, [states[b] for b in range(nct)], nparts_d, desc_d, tab_d, c_ord, galois=gal)
         # 2. fused core over the whole group
         nparts = len(tabs["order"])
         ext = self._ws("ks_ext_batch", (nct, nparts, rows, N), d)

@@ -312,6 +312,10 @@ class OracleBackend:
 
     ks_batch_sizes = (4, 2)
 
+    def ks_digits_batch(self, srcs, states, nparts, desc, tab, c, galois=None):
+        for src, st in zip(srcs, states):
+            self.ks_digits(src, st, nparts, desc, tab, c, galois=galois)
+
     def ks_core_batch(self, states, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv, c):
         for b in range(states.size(0)):
             self.ks_core(states[b], nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp[b], s[b], psi, ipsi, Ninv, c)
