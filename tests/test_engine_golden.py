@@ -121,6 +121,13 @@ def test_rotate_single_batch_checker_equals_loop():
     want = [digest(eng.rotate_single(ct, rotk)) for ct in cts]
     got = [digest(x) for x in eng.rotate_single_batch(cts, rotk)]
     assert got == want
+    # edge cases: nothing to do, one ciphertext, a wrong key type
+    assert eng.rotate_single_batch([], rotk) == []
+    assert [digest(x) for x in eng.rotate_single_batch(cts[:1], rotk)] == want[:1]
+    from liberate_fhe_amd.fhe.presets import errors
+    with pytest.raises(errors.NotMatchType):
+        eng.rotate_single_batch(cts, synth.key_switch_key(eng, 8))
+    assert eng.cc_mult_batch([], synth.key_switch_key(eng, 8)) == []
 
 
 @pytest.mark.gpu
