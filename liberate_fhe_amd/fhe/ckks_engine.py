@@ -89,6 +89,7 @@ class ckks_engine(EvaluatorOps):
         self._workspace = {}
         self._lane = 0          # pipeline lane whose workspaces / stream the batched ops currently use
         self._lane_streams = {}
+        self._warm = set()      # (key id, level, op) pairs whose lazily built state exists (see _run_groups)
 
         ds, nd, ls = data_struct, np.ndarray, list
         self.mult_dispatch_dict = {
@@ -969,16 +970,19 @@ class ckks_engine(EvaluatorOps):
                     jobs.append(lambda sel=sel: self._automorphism_batch([cts[i] for i in sel], exponent, rotk, level))
                 slots.append(sel)
                 pos += n
-            for sel, res in zip(slots, self._run_groups(jobs, self._loc(level)[0])):
+            for sel, res in zip(slots, self._run_groups(jobs, self._loc(level)[0], (id(rotk), level, "rot"))):
                 for i, r in zip(sel, res):
                     out[i] = r
         return out
 
-    def _run_groups(self, jobs, dev_id):
+    def _run_groups(self, jobs, dev_id, warm_key=None):
         """Run independent group jobs (callables returning lists of data_structs) alternately on two streams of
         the device: a group's memory-bound phases (the key stream of the inner product) overlap the other group's
         instruction-bound ones, and launch tails fill.  Each lane has its own workspaces.  Returns the results in
-        order; the caller's stream waits for the side lane before returning."""
+        order; the caller's stream waits for the side lane before returning.
+        Lazily built shared state (key pack, per-level tables, fp64 twiddle twins) is produced by launches on the
+        stream of whichever job touches it first: the first time a (key, level) pair comes here, the first job runs
+        on the caller's stream BEFORE the side lane is forked, so the side lane never reads it half-built."""
         device = self.ntt.devices[dev_id]
         if len(jobs) < 2 or not str(device).startswith("cuda") or os.environ.get("LF_ENGINE_LANES", "2") == "1":
             return [job() for job in jobs]
@@ -986,12 +990,17 @@ class ckks_engine(EvaluatorOps):
         side = self._lane_streams.get(dev_id)
         if side is None:
             side = self._lane_streams[dev_id] = torch.cuda.Stream(device=device)
+        results = []
+        first = 0
+        if warm_key not in self._warm:
+            results.append(jobs[0]())
+            self._warm.add(warm_key)
+            first = 1
         fork = torch.cuda.Event()
         fork.record(main)
         side.wait_event(fork)
-        results = []
         try:
-            for n, job in enumerate(jobs):
+            for n, job in enumerate(jobs[first:]):
                 self._lane = n & 1
                 if self._lane:
                     with torch.cuda.stream(side):
@@ -1089,7 +1098,7 @@ class ckks_engine(EvaluatorOps):
                     jobs.append(lambda sel=sel: self._cc_mult_group([pairs[i] for i in sel], evk, level))
                 slots.append(sel)
                 pos += n
-            for sel, res in zip(slots, self._run_groups(jobs, self._loc(level)[0])):
+            for sel, res in zip(slots, self._run_groups(jobs, self._loc(level)[0], (id(evk), level, "mult"))):
                 for i, r in zip(sel, res):
                     out[i] = r
         return out

@@ -205,3 +205,22 @@ def test_moddown_ws_equals_chunked_kernel(K):
         eng.backend.ks_moddown_ws(s, got, adds, ell, K, ws, tabs[("pir", d)], rs, cs, PiP=tabs[("pip", d)], galois=gal)
         for w, g in zip(want, got):
             assert torch.equal(w, g)
+
+
+@pytest.mark.gpu
+def test_hip_batch_calls_on_a_cold_engine():
+    """The very first operations of an engine are batched ones: key pack, per-level tables and the fp64 twiddle twins
+    are built by the first group on the caller's stream before the second lane is forked."""
+    from liberate_fhe_amd.fhe import ckks_engine, presets
+    params = dict(presets.params["silver"])
+    params.pop("devices", None)
+    eng = ckks_engine(devices=["cuda:0"], **params)
+    rotk = synth.key_switch_key(eng, 7, origin="rotation key:5")
+    evk = synth.key_switch_key(eng, 9)
+    cts = [synth.ciphertext(eng, 700 + i, 0) for i in range(12)]
+    pairs = [(cts[i], cts[(i + 5) % 12]) for i in range(12)]
+    got_r = [digest(x) for x in eng.rotate_single_batch(cts, rotk)]
+    got_m = [digest(x) for x in eng.cc_mult_batch(pairs, evk)]
+    ref = ckks_engine(devices=["cuda:0"], **params)
+    assert got_r == [digest(ref.rotate_single(ct, rotk)) for ct in cts]
+    assert got_m == [digest(ref.cc_mult(a, b, evk)) for a, b in pairs]
