@@ -224,3 +224,26 @@ def test_hip_batch_calls_on_a_cold_engine():
     ref = ckks_engine(devices=["cuda:0"], **params)
     assert got_r == [digest(ref.rotate_single(ct, rotk)) for ct in cts]
     assert got_m == [digest(ref.cc_mult(a, b, evk)) for a, b in pairs]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [3, 8, 13])
+def test_hip_engine_equals_checker_engine_at_deeper_levels(level):
+    """Fewer live limbs: partial last digit, other part counts, other (ell, K) shapes of the mod-down — HIP vs checker
+    for cc_mult, rotate_single and their batched forms at silver levels the fixtures do not reach."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    from tests.oracle_backend import OracleBackend
+    params = GOLD["silver"]["params"]
+    hip = ckks_engine(devices=["cuda:0"], **params)
+    chk = ckks_engine(devices=["cpu"], backend=OracleBackend(), **params)
+    outs = []
+    for eng in (hip, chk):
+        a, b = synth.ciphertext(eng, 801, level), synth.ciphertext(eng, 802, level)
+        evk, rotk = synth.key_switch_key(eng, 803), synth.key_switch_key(eng, 804, origin="rotation key:17")
+        res = [eng.cc_mult(a, b, evk), eng.rotate_single(a, rotk)]
+        if eng is hip:
+            res += eng.cc_mult_batch([(a, b), (b, a)], evk) + eng.rotate_single_batch([a, b], rotk)
+        else:
+            res += [eng.cc_mult(a, b, evk), eng.cc_mult(b, a, evk), eng.rotate_single(a, rotk), eng.rotate_single(b, rotk)]
+        outs.append([digest(x) for x in res])
+    assert outs[0] == outs[1]
