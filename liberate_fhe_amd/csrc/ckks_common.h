@@ -33,14 +33,15 @@ static __device__ __forceinline__ i64 mm62s(i64 a, i64 b, u64 q, u64 k) {
 }
 
 // Same for operands known to be non-negative (butterflies: both in [0, 2q)).
+// One operand enters pre-shifted by 2 (a < 2^62, so 4a fits 64 bits): the 128-bit product 4ab then has
+// (ab >> 62) as its high word and 4 * (ab mod 2^62) as its low word, and low * k mod 2^64 IS 4 * s — the masks, the
+// 62-bit realignment of the product and the shift of s disappear (23 instead of 30 instructions).
 static __device__ __forceinline__ i64 mm62u(u64 a, u64 b, u64 q, u64 k) {
-    const u128 x = (u128)a * (u128)b;
-    const u64 lo = (u64)x;
-    const u64 hi = (u64)(x >> 64);
-    const u64 xl = lo & M62;
-    const u64 xh = (hi << 2) | (lo >> 62);
-    const u64 s = (xl * k) & M62;
-    return (i64)(xh + __umul64hi(s << 2, q) + (u64)(xl != 0));
+    const u128 x = (u128)(a << 2) * (u128)b;
+    const u64 lo = (u64)x;              // 4 * xl
+    const u64 xh = (u64)(x >> 64);      // (a * b) >> 62
+    const u64 s4 = lo * k;              // 4 * ((xl * k) mod 2^62), exactly (mod 2^64)
+    return (i64)(xh + __umul64hi(s4, q) + (u64)(lo != 0));
 }
 
 // mont_redc body (K.cu:587-606): (x + ((x*k) mod R) * q) / R for signed x, |x| < 2^62.
