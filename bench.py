@@ -16,7 +16,7 @@ The JSON line also carries
                  launches of a transform, 12 of its 16 stages) against the 8 TB/s HBM peak; algorithmic bytes
                  per launch = 8*N*limbs (a transform is 16*N bytes per limb, SURVEY.md §8d, spread over its two
                  launches); its launch duration is measured live with HIP events on the launch stream, the
-                 kernel launched alone (LF_NTT_ONLY_PASS=2) with the grid it has inside the full step;
+                 kernel launched alone (lf_ntt_pass, the measurement entry) with the grid it has inside the full step;
   cpu_baseline : the C oracle (strict reference-kernel semantics) on this box's host cores, same workload,
                  bounded sample;
   extra        : cc_mult(+relinearize) ops/s for silver and gold on this rank, rotate ops/s, limb-NTT/s.
@@ -252,24 +252,21 @@ def main():
 
     # Roofline of the dominant kernel, ntt_fwd_pass_mixed: the tiled pass (12 of the 16 stages) of all 30 limbs,
     # integer-class blocks first, then the fp64 class.  In the step above it follows the column pass, so it is
-    # timed on its own here: the same lf_ntt call with LF_NTT_ONLY_PASS=2 launches exactly that kernel, once,
-    # with the grid it has inside the full step.  (The result of such a call is not a transform; x is scratch.)
+    # timed on its own here: lf_ntt_pass(which = 2), the library's measurement entry, launches exactly that kernel,
+    # once, with the grid it has inside the full step.  (x is scratch afterwards.)
     n_roof = max(10, args.steps // 2)
-    os.environ["LF_NTT_ONLY_PASS"] = "2"
-    try:
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        k_ms = event_time_ms(step, n_roof)
-    finally:
-        del os.environ["LF_NTT_ONLY_PASS"]
-    os.environ["LF_NTT_ONLY_PASS"] = "1"
-    try:
-        step()
-        torch.cuda.synchronize()
-        cols_ms = event_time_ms(step, n_roof)
-    finally:
-        del os.environ["LF_NTT_ONLY_PASS"]
+
+    def one_pass(which):
+        check(lib.lf_ntt_pass(x.data_ptr(), B, L_LIMBS, LOGN, psi.data_ptr(), psi_dp, q_host.ctypes.data, 0, ntt_flags, which,
+                              ql.data_ptr(), qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), local_rank, stream), "lf_ntt_pass")
+
+    for _ in range(3):
+        one_pass(2)
+    torch.cuda.synchronize()
+    k_ms = event_time_ms(lambda: one_pass(2), n_roof)
+    one_pass(1)
+    torch.cuda.synchronize()
+    cols_ms = event_time_ms(lambda: one_pass(1), n_roof)
     alg_bytes_per_launch = 8 * N * L_LIMBS * B                      # 16*N per limb per transform, two launches
     achieved = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
     traffic = valu = None

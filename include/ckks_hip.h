@@ -34,8 +34,19 @@ extern "C" {
 
 #define LF_ERR_ARG 10001
 
-/* Library probe: returns the ABI version (currently 4). */
+/* Library probe: returns the ABI version (currently 6; __graft_entry__.build() asserts it). */
 int lf_abi_version(void);
+
+/* Compile-time capacities of the fused kernels, so that callers can refuse a parameter set BEFORE any launch
+ * (the digit width alpha and K live in device-side descriptors the ABI cannot check):
+ *   which = 0: limbs per key-switch digit (alpha), 1: special primes K, 2: limb rows per call (`rows`),
+ *           3: operand sets per batched call (count), 4: largest logN of the NTT family.  Other: -1. */
+#define LF_LIMIT_DIGIT_LIMBS 0
+#define LF_LIMIT_SPECIAL_PRIMES 1
+#define LF_LIMIT_ROWS 2
+#define LF_LIMIT_BATCH 3
+#define LF_LIMIT_LOGN 4
+int lf_limits(int which);
 
 /* ---- elementwise family --------------------------------------------------------------------- */
 
@@ -97,6 +108,14 @@ int lf_twiddle_dp(const int64_t *mont, double *out, int rows, int64_t N, const i
 int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
            const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *_2q, const int64_t *ql,
            const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+
+/* Measurement entry (not one of the reference's ops; the engine never calls it): launch exactly ONE of the two
+ * pass kernels of a two-pass forward transform (logN >= 13) with the grid it has inside lf_ntt —
+ * which = 1: the column pass, 2: the tiled pass — so that bench.py / tools can time the dominant kernel alone
+ * with HIP events.  `a` is scratch afterwards (half a transform).  lf_ntt itself has no knobs. */
+int lf_ntt_pass(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
+                const int64_t *q_host, const int64_t *Rs, int flags, int which, const int64_t *ql, const int64_t *qh,
+                const int64_t *kl, const int64_t *kh, int device, void *stream);
 
 /* ntt_cuda.intt / intt_exit / intt_exit_reduce / intt_exit_reduce_signed
  * (ntt.cpp:219-345, K.cu:433-548, 709-973): inverse NTT, bit-reversed in -> natural out, then

@@ -17,6 +17,13 @@ typedef __int128 i128;
 
 #define M62 ((1ull << 62) - 1ull)
 
+// capacities compiled into the kernels (reported by lf_limits)
+#define KS_MAX_ALPHA 8       // limbs per key-switch digit (= number of special primes, <= 6 in the presets)
+#define KS_MAX_K 8           // special primes
+#define MAX_LIST_ROWS 250    // limb rows per call
+#define LF_BATCH_MAX 8       // operand sets per batched call
+#define NTT_TILE_LOG_MAX 12  // log2 of the largest LDS tile; transforms go up to logN = 2 * NTT_TILE_LOG_MAX
+
 // ------------------------------------------------------------------------------------------------
 // Scalar arithmetic
 // ------------------------------------------------------------------------------------------------

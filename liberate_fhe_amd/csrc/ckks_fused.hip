@@ -11,8 +11,6 @@
 #include "ckks_common.h"
 #include <stdlib.h>
 
-#define KS_MAX_ALPHA 8   // limbs per key-switch digit (= number of special primes, <= 6 in the presets)
-#define KS_MAX_K 8
 
 namespace {
 
@@ -29,7 +27,6 @@ __device__ __forceinline__ double dp_mulmod_q(double a, double w, double q, doub
 // out = reduce_q( REDC(in - row0, q_l^-1 * R mod q_i) + [row0 > q_l/2] )
 // Up to LF_BATCH_MAX independent operand sets per launch (blockIdx.z): the two components of a ciphertext, or
 // the four polynomials cc_mult rescales, share one launch instead of paying a launch gap each.
-#define LF_BATCH_MAX 8
 struct PtrBatch {
     const i64 *in[LF_BATCH_MAX];
     const i64 *aux[LF_BATCH_MAX];

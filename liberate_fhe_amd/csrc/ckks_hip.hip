@@ -109,7 +109,19 @@ __global__ void __launch_bounds__(256) galois_kernel(GaloisBatch gb, int logN, i
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int lf_abi_version(void) { return 5; }
+int lf_abi_version(void) { return 6; }
+
+// capacities compiled into the kernels (ckks_common.h)
+int lf_limits(int which) {
+    switch (which) {
+        case LF_LIMIT_DIGIT_LIMBS: return KS_MAX_ALPHA;
+        case LF_LIMIT_SPECIAL_PRIMES: return KS_MAX_K;
+        case LF_LIMIT_ROWS: return MAX_LIST_ROWS;
+        case LF_LIMIT_BATCH: return LF_BATCH_MAX;
+        case LF_LIMIT_LOGN: return 2 * NTT_TILE_LOG_MAX;
+        default: return -1;
+    }
+}
 
 int lf_mont_mult(const int64_t *a, const int64_t *b, int64_t *c, int rows, int64_t N, const int64_t *ql,
                  const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {

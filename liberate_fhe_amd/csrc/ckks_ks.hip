@@ -25,7 +25,6 @@
 #include "../../include/ckks_hip.h"
 #include "ckks_ntt_core.h"
 
-#define KS_MAX_ALPHA 8
 #define KS_WORDS ((1 << NTT_TILE_LOG_MAX) / NTT_THREADS)   // tile words owned by one thread (8)
 
 namespace {

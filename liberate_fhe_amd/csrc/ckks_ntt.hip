@@ -72,19 +72,9 @@ SideStream *side_stream(int device) {
     return &s;
 }
 
-// polynomials per launch group: optional split of a batch into launch groups of `LF_NTT_CHUNK_MB` MiB (experiment knob, default off)
-int chunk_polys(int batch, int rows, int logN, bool two_pass) {
-    if (!two_pass) return batch;
-    static long chunk_mb = -1;
-    if (chunk_mb < 0) {
-        const char *e = getenv("LF_NTT_CHUNK_MB");
-        chunk_mb = e ? atol(e) : 0;   // measured on MI355X: chunking only adds launch tails (0 = off)
-    }
-    if (chunk_mb == 0) return batch;
-    const double poly_mb = (double)rows * (double)(8ull << logN) / (1024.0 * 1024.0);
-    int c = (int)((double)chunk_mb / poly_mb);
-    return c < 1 ? 1 : (c > batch ? batch : c);
-}
+// polynomials per launch group: the whole batch (splitting a batch so that its two passes meet in the Infinity
+// Cache was measured on MI355X and only adds launch tails)
+int chunk_polys(int batch, int, int, bool) { return batch; }
 
 template <bool DP>
 void launch_cols(int K, unsigned blocks, hipStream_t st, i64 *base, const PassGeom &g, const RowList &rl,
@@ -150,7 +140,7 @@ void launch_cols_mixed_rs(int K, unsigned per_limb, hipStream_t st, i64 *base, c
 // forward transform of a stack; `rsrc` (optional): the column pass takes its input from a rescale on the fly
 int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
                 const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *ql, const int64_t *qh,
-                const int64_t *kl, const int64_t *kh, int device, void *stream, const RescaleSrc *rsrc);
+                const int64_t *kl, const int64_t *kh, int device, void *stream, const RescaleSrc *rsrc, int only_pass = 0);
 
 }  // namespace
 
@@ -174,6 +164,17 @@ int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, con
     return ntt_forward(a, batch, rows, logN, psi_br, psi_dp, q_host, Rs, flags, ql, qh, kl, kh, device, stream, nullptr);
 }
 
+/* Measurement entry (NOT one of the reference's ops, not used by the engine): launch exactly ONE of the two pass
+ * kernels of a two-pass forward transform — which = 1 the column pass, 2 the tiled pass — with the grid it has
+ * inside lf_ntt, so that bench.py / tools can time the dominant kernel alone.  The buffer is scratch afterwards. */
+int lf_ntt_pass(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
+                const int64_t *q_host, const int64_t *Rs, int flags, int which, const int64_t *ql, const int64_t *qh,
+                const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (which != 1 && which != 2) return LF_ERR_ARG;
+    if (logN <= NTT_TILE_LOG_MAX) return LF_ERR_ARG;   // single-pass sizes have nothing to split
+    return ntt_forward(a, batch, rows, logN, psi_br, psi_dp, q_host, Rs, flags, ql, qh, kl, kh, device, stream, nullptr, which);
+}
+
 int lf_rescale_ntt(const int64_t *const *in, const int64_t *const *row0, int count, int64_t *x, int rows, int logN,
                    const int64_t *scales, int64_t round_at, const int64_t *psi_br, const double *psi_dp,
                    const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *_2q, const int64_t *ql,
@@ -183,7 +184,7 @@ int lf_rescale_ntt(const int64_t *const *in, const int64_t *const *row0, int cou
         return LF_ERR_ARG;
     if (count == 0 || rows == 0) return 0;
     const int S1 = logN - NTT_TILE_LOG_MAX;
-    if (S1 >= 1 && S1 <= 4 && cols_enabled() && !getenv("LF_NO_RESCALE_FUSION")) {
+    if (S1 >= 1 && S1 <= 4 && cols_enabled()) {
         RescaleSrc rsrc;
         for (int i = 0; i < count; ++i) rsrc.in[i] = (const i64 *)in[i], rsrc.row0[i] = (const i64 *)row0[i];
         rsrc.scales = (const i64 *)scales;
@@ -204,7 +205,7 @@ namespace {
 
 int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
                 const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *ql, const int64_t *qh,
-                const int64_t *kl, const int64_t *kh, int device, void *stream, const RescaleSrc *rsrc) {
+                const int64_t *kl, const int64_t *kh, int device, void *stream, const RescaleSrc *rsrc, int only_pass) {
     if (batch < 0 || rows < 0 || rows > MAX_LIST_ROWS || logN < 1 || logN > 2 * NTT_TILE_LOG_MAX) return LF_ERR_ARG;
     if (batch == 0 || rows == 0) return 0;
     if (int e = lf_set_device(device)) return e;
@@ -222,10 +223,7 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
         (void)hipEventRecord(side->fork, st);
         (void)hipStreamWaitEvent(side->stream, side->fork, 0);
     }
-    // LF_NTT_ONLY_PASS=1|2 (read per call): launch only the column pass / only the tiled pass of a two-pass
-    // transform.  The result is then NOT a transform; bench.py uses it to time the dominant kernel alone.
-    const char *only_env = S1 > 0 ? getenv("LF_NTT_ONLY_PASS") : nullptr;
-    const int only_pass = only_env ? atoi(only_env) : 0;
+    // only_pass = 1 | 2 (lf_ntt_pass, measurement only): launch only the column pass / only the tiled pass
     const int chunk = rsrc ? batch : chunk_polys(batch, rows, logN, S1 > 0);   // the rescale source indexes whole-batch polynomials
     for (int b0 = 0; b0 < batch; b0 += chunk) {
         const int nb = batch - b0 < chunk ? batch - b0 : chunk;

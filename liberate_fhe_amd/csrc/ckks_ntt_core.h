@@ -6,11 +6,9 @@
 #include <stdlib.h>
 
 #define NTT_THREADS 512
-#define NTT_TILE_LOG_MAX 12
 #define NTT_LDS_WORDS ((1 << NTT_TILE_LOG_MAX) + (1 << (NTT_TILE_LOG_MAX - 3)))
 #define TAIL_NONE (-1)
 #define SMALL_PRIME_LIMIT (1ull << 41)
-#define MAX_LIST_ROWS 250
 
 #define PAD(L) ((L) + ((L) >> 3))
 #define NTT_FLAG_WORD NTT_LDS_WORDS          // two flag words live behind the tile in the same LDS array
@@ -1370,15 +1368,9 @@ inline void launch_inv_cols(int K, int polys, hipStream_t st, i64 *base, const P
 #undef LF_ICOLS_CASE
 }
 
-// experiment knob: LF_NTT_MIXED=0 launches the two arithmetic classes separately (integer class on a side stream)
-inline bool mixed_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char *e = getenv("LF_NTT_MIXED");
-        on = e ? atoi(e) != 0 : 1;
-    }
-    return on != 0;
-}
+// both arithmetic classes of a pass go into one launch whenever both are present (the split form — integer class
+// on a side stream — was the round-1 A/B loser and is only used when a transform has a single class)
+inline bool mixed_enabled() { return true; }
 
 inline ClassLists class_lists(const RowList &in, const RowList &dp, unsigned in_blocks) {
     ClassLists cl;
@@ -1412,15 +1404,9 @@ inline void launch_inv_cols_mixed(int K, int polys, hipStream_t st, i64 *base, c
     }
 }
 
-// experiment knob: LF_NTT_COLS=0 falls back to the LDS-tiled strided passes
-inline bool cols_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char *e = getenv("LF_NTT_COLS");
-        on = e ? atoi(e) != 0 : 1;
-    }
-    return on != 0;
-}
+// the strided pass runs as a column kernel whenever it has at most 4 stages (logN <= 16); beyond that the
+// LDS-tiled strided pass takes over
+inline bool cols_enabled() { return true; }
 
 // the tiled-pass kernels carry their arithmetic mode (exact lazy words / relaxed residues) as a template parameter
 #define LF_LAUNCH_MIXED(KERN, relaxed, ...)                                   \
@@ -1434,15 +1420,9 @@ inline bool cols_enabled() {
         else hipLaunchKernelGGL((KERN<DP, false>), __VA_ARGS__);              \
     } while (0)
 
-// experiment knob: LF_NTT_REGTILE=0 runs the 4096-word contiguous passes in the LDS-resident form
-inline int regtile_disabled() {
-    static int off = -1;
-    if (off < 0) {
-        const char *e = getenv("LF_NTT_REGTILE");
-        off = (e && atoi(e) == 0) ? 1 : 0;
-    }
-    return off;
-}
+// 4096-word contiguous passes run in the register-fed form (the LDS-resident form is its fallback for tiles
+// holding words outside [0, 2q))
+inline int regtile_disabled() { return 0; }
 
 // plain canonical twiddles as doubles from the Montgomery table: w = reduce(redc(S))
 __global__ void __launch_bounds__(256) twiddle_dp_kernel(const i64 *__restrict__ mont, double *__restrict__ out, i64 N,

@@ -25,7 +25,21 @@ def _ds(t: torch.Tensor):
 def _p(t):
     if t is None:
         return 0
-    assert t.dtype == torch.int64 and t.is_contiguous(), (t.dtype, t.is_contiguous())
+    if t.dtype != torch.int64:
+        raise TypeError(f"HipBackend: int64 tensor required, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("HipBackend: contiguous tensor required (the kernels take a raw pointer and a row pitch of N words)")
+    return t.data_ptr()
+
+
+def _pd(t):
+    """Device pointer of a float64 table (None -> NULL)."""
+    if t is None:
+        return 0
+    if t.dtype != torch.float64:
+        raise TypeError(f"HipBackend: float64 tensor required, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("HipBackend: contiguous tensor required")
     return t.data_ptr()
 
 
@@ -55,6 +69,14 @@ class Consts:
 class HipBackend:
     name = "hip-gfx950"
     ops = ntt_cuda  # the 15 reference-shaped primitives
+    # capacities compiled into the fused kernels (include/ckks_hip.h: lf_limits)
+    limits = {"digit_limbs": int(lib.lf_limits(0)), "special_primes": int(lib.lf_limits(1)), "rows": int(lib.lf_limits(2)),
+              "batch": int(lib.lf_limits(3)), "logN": int(lib.lf_limits(4))}
+
+    def warm_twiddles(self, table, c: "Consts"):
+        """Build the fp64 twin of a twiddle table on the current stream (otherwise built by its first user)."""
+        dev, st = _ds(table)
+        twiddles.dp_pointer(table, c.ql, c.qh, c.kl, c.kh, dev, st)
 
     # ---- NTT family over [batch][rows][N] stacks ------------------------------------------------
     def ntt(self, buf, batch, rows, logN, psi, Rs, c: Consts, relaxed=False, plain=False):
@@ -99,7 +121,7 @@ class HipBackend:
         dev, st = _ds(outs[0])
         pinv, g2q = (0, None) if galois is None else galois
         check(lib.lf_ks_moddown_batch(_parr(ss), _parr(outs), _parr(addends), len(ss), ell, K, outs[0].size(-1), _p(PiR),
-                                      0 if PiP is None else PiP.data_ptr(), _p(Rs), pinv, _p(g2q), *c.mont(), dev, st),
+                                      _pd(PiP), _p(Rs), pinv, _p(g2q), *c.mont(), dev, st),
               "lf_ks_moddown_batch")
 
     def ks_moddown_ws(self, ss, outs, addends, ell, K, ws, PiR, Rs, c: Consts, PiP=None, galois=None):
@@ -108,7 +130,7 @@ class HipBackend:
         dev, st = _ds(outs[0])
         pinv, g2q = (0, None) if galois is None else galois
         check(lib.lf_ks_moddown_ws(_parr(ss), _parr(outs), _parr(addends), len(ss), ell, K, outs[0].size(-1), _p(ws),
-                                   ws.numel(), _p(PiR), 0 if PiP is None else PiP.data_ptr(), _p(Rs), pinv, _p(g2q),
+                                   ws.numel(), _p(PiR), _pd(PiP), _p(Rs), pinv, _p(g2q),
                                    *c.mont(), dev, st), "lf_ks_moddown_ws")
 
     @staticmethod
@@ -166,7 +188,7 @@ class HipBackend:
         base = key.data_ptr() + first_part * part_stride * 8
         psi_dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
         ipsi_dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
-        check(lib.lf_ks_core(_p(state), nparts, rows, logN, _p(desc), _p(E), Ed.data_ptr(), base, part_stride, comp_stride,
+        check(lib.lf_ks_core(_p(state), nparts, rows, logN, _p(desc), _p(E), _pd(Ed), base, part_stride, comp_stride,
                              row_off, _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
                              c.qptr(), *c.mont(), dev, st), "lf_ks_core")
 
@@ -182,10 +204,10 @@ class HipBackend:
         psi_dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
         ipsi_dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
         check(lib.lf_ks_core_batch(_p(states), states.stride(0), states.size(0), nparts, rows, logN, _p(desc), _p(E),
-                                   Ed.data_ptr(), base, part_stride, comp_stride, row_off, _p(tmp), _p(s), _p(psi), psi_dp,
+                                   _pd(Ed), base, part_stride, comp_stride, row_off, _p(tmp), _p(s), _p(psi), psi_dp,
                                    _p(ipsi), ipsi_dp, _p(Ninv), c.qptr(), *c.mont(), dev, st), "lf_ks_core_batch")
 
     def ks_moddown(self, s, out, addend, ell, K, PiR, Rs, c: Consts, PiP=None):
         dev, st = _ds(out)
         check(lib.lf_ks_moddown(_p(s), _p(out), _p(addend), ell, K, out.size(-1), _p(PiR),
-                                0 if PiP is None else PiP.data_ptr(), _p(Rs), *c.mont(), dev, st), "lf_ks_moddown")
+                                _pd(PiP), _p(Rs), *c.mont(), dev, st), "lf_ks_moddown")

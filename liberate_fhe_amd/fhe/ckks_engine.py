@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from hashlib import sha256
 
 import numpy as np
@@ -89,7 +90,7 @@ class ckks_engine(EvaluatorOps):
         self._workspace = {}
         self._lane = 0          # pipeline lane whose workspaces / stream the batched ops currently use
         self._lane_streams = {}
-        self._warm = set()      # (key id, level, op) pairs whose lazily built state exists (see _run_groups)
+        self._check_kernel_limits()
 
         ds, nd, ls = data_struct, np.ndarray, list
         self.mult_dispatch_dict = {
@@ -348,7 +349,7 @@ class ckks_engine(EvaluatorOps):
                     shard.copy_(self.backend.ops.mont_add([shard], [Psk[i][lo:hi]], _2q)[0])
                 ksk[gid] = pk._replace(data=(b_views, a_views), origin=f"key switch key part index {gid}")
         out = self._new(ksk, types.origins["ksk"], include_special=True, ntt_state=True, montgomery_state=True)
-        self._key_packs[id(out.data)] = (out.data, packs)
+        self._remember_pack(out, packs, own=True)
         return out
 
     def create_evk(self, sk: data_struct) -> data_struct:
@@ -378,9 +379,7 @@ class ckks_engine(EvaluatorOps):
             raise errors.NotMatchType(origin=sk.origin, to=types.origins["sk"])
         sk_rot = self._permuted_secret(sk, encdec.galois_exponent(self.ctx.N, delta))
         rotk = self.create_key_switching_key(sk_rot, sk, a=a)
-        out = rotk._replace(origin=types.origins["rotk"] + f"{delta}")
-        self._key_packs[id(out.data)] = self._key_packs[id(rotk.data)]
-        return out
+        return rotk._replace(origin=types.origins["rotk"] + f"{delta}")   # same tensors: same packed key
 
     def create_galois_key(self, sk: data_struct) -> data_struct:
         if sk.origin != types.origins["sk"]:
@@ -395,22 +394,64 @@ class ckks_engine(EvaluatorOps):
             raise errors.NotMatchDataStructState(origin=sk.origin)
         sk_conj = self._permuted_secret(sk, encdec.conjugation_exponent(self.ctx.N))
         k = self.create_key_switching_key(sk_conj, sk)
-        out = k._replace(origin=types.origins["conjk"])
-        self._key_packs[id(out.data)] = self._key_packs[id(k.data)]
-        return out
+        return k._replace(origin=types.origins["conjk"])
+
+    # ---- packed-key cache --------------------------------------------------------------------------------------
+    # Identity of a key = its first tensor (part 0, component b, first local device): data_structs and lists cannot
+    # be weakly referenced, tensors can.  An entry dies with that tensor (weakref.finalize), so a key the caller
+    # drops releases its pack (gold: 429 MB per key) and a recycled id() can never alias a dead entry.
+    @staticmethod
+    def _key_anchor(ksk):
+        return ksk.data[0].data[0][0]
+
+    @staticmethod
+    def _key_versions(ksk):
+        return tuple(t._version for part in ksk.data for comp in part.data for t in comp)
+
+    def _remember_pack(self, ksk, packs, own):
+        anchor = self._key_anchor(ksk)
+        key = id(anchor)
+        # `own`: the key's tensors ARE views of the pack (in-place edits land in it); a foreign key's pack is a copy,
+        # rebuilt when any of its tensors has been modified in place since (torch's version counters)
+        self._key_packs[key] = {"ref": weakref.ref(anchor), "packs": packs, "own": own,
+                                "versions": None if own else self._key_versions(ksk)}
+        weakref.finalize(anchor, self._key_packs.pop, key, None)
+        return packs
 
     def _key_pack(self, ksk):
-        """Packed per-device key tensors of a key-switch key; foreign (unpacked) keys are packed once."""
-        hit = self._key_packs.get(id(ksk.data))
-        if hit is not None and hit[0] is ksk.data:
-            return hit[1]
+        """Packed per-device key tensors of a key-switch key; foreign (unpacked) keys are packed once, on the
+        CURRENT stream — callers that use the pack from another stream order themselves after this call
+        (see _run_groups: it is made before the side lane is forked)."""
+        hit = self._key_packs.get(id(self._key_anchor(ksk)))
+        if hit is not None and hit["ref"]() is self._key_anchor(ksk) and (hit["own"] or hit["versions"] == self._key_versions(ksk)):
+            return hit["packs"]
         loc = self._loc(0, special=True)
         packs = []
         for i, d in enumerate(loc):
             parts = [torch.stack([part.data[0][i], part.data[1][i]]) for part in ksk.data]
             packs.append(torch.stack(parts).contiguous())
-        self._key_packs[id(ksk.data)] = (ksk.data, packs)
-        return packs
+        return self._remember_pack(ksk, packs, own=False)
+
+    def release_key(self, ksk):
+        """Drop the packed copy of a foreign key-switch key now (it is also dropped when the key's tensors die).
+        Keys made by this engine are views of their pack and hold no second copy."""
+        self._key_packs.pop(id(self._key_anchor(ksk)), None)
+
+    def _check_kernel_limits(self):
+        """The fused kernels reserve registers for at most lf_limits() digit limbs / special primes / rows; a
+        parameter set beyond them must fail HERE, not as a generic launch status deep inside a key switch."""
+        lim = getattr(self.backend, "limits", None)
+        if lim is None:
+            return
+        K = self.ntt.num_special_primes
+        widest = max((len(part) for per_dev in self.ntt.p.p[0] for part in per_dev), default=0)
+        rows = max((len(d) for d in self.ntt.p.destination_arrays_with_special[0]), default=0)
+        if K > lim["special_primes"] or widest > lim["digit_limbs"]:
+            raise errors.KernelLimitExceeded(
+                f"num_special_primes = {K} (digits of up to {widest} limbs) exceeds what the key-switch kernels are "
+                f"built for (at most {lim['special_primes']} special primes, {lim['digit_limbs']} limbs per digit)")
+        if rows > lim["rows"]:
+            raise errors.KernelLimitExceeded(f"{rows} limb rows on one device exceed the kernels' limit of {lim['rows']}")
 
     # =============================================================================================
     # encrypt / decrypt (eng.py:417-595, 1472-1688)
@@ -970,19 +1011,32 @@ class ckks_engine(EvaluatorOps):
                     jobs.append(lambda sel=sel: self._automorphism_batch([cts[i] for i in sel], exponent, rotk, level))
                 slots.append(sel)
                 pos += n
-            for sel, res in zip(slots, self._run_groups(jobs, self._loc(level)[0], (id(rotk), level, "rot"))):
+            for sel, res in zip(slots, self._run_groups(jobs, self._loc(level)[0], lambda: self._prepare_ks(rotk, level))):
                 for i, r in zip(sel, res):
                     out[i] = r
         return out
 
-    def _run_groups(self, jobs, dev_id, warm_key=None):
+    def _prepare_ks(self, key, level):
+        """Build, on the CURRENT stream, every lazily built piece of shared state a key switch at `level` under
+        `key` reads: the packed key, the per-level descriptor tables, the fp64 twins of the twiddle tables."""
+        self._key_pack(key)
+        self._ks_tables(level)
+        warm = getattr(self.backend, "warm_twiddles", None)
+        if warm is not None:
+            for d in self._loc(level):
+                for special in (False, True):
+                    c = self._consts(d, level, special)
+                    warm(self._tw(d, level, special), c)
+                    warm(self._tw(d, level, special, True), c)
+
+    def _run_groups(self, jobs, dev_id, prepare=None):
         """Run independent group jobs (callables returning lists of data_structs) alternately on two streams of
         the device: a group's memory-bound phases (the key stream of the inner product) overlap the other group's
         instruction-bound ones, and launch tails fill.  Each lane has its own workspaces.  Returns the results in
         order; the caller's stream waits for the side lane before returning.
         Lazily built shared state (key pack, per-level tables, fp64 twiddle twins) is produced by launches on the
-        stream of whichever job touches it first: the first time a (key, level) pair comes here, the first job runs
-        on the caller's stream BEFORE the side lane is forked, so the side lane never reads it half-built."""
+        stream of whichever call touches it first: `prepare()` builds all of it on the caller's stream BEFORE the
+        side lane is forked (idempotent: dictionary hits afterwards), so the side lane never reads it half-built."""
         device = self.ntt.devices[dev_id]
         if len(jobs) < 2 or not str(device).startswith("cuda") or os.environ.get("LF_ENGINE_LANES", "2") == "1":
             return [job() for job in jobs]
@@ -992,10 +1046,8 @@ class ckks_engine(EvaluatorOps):
             side = self._lane_streams[dev_id] = torch.cuda.Stream(device=device)
         results = []
         first = 0
-        if warm_key not in self._warm:
-            results.append(jobs[0]())
-            self._warm.add(warm_key)
-            first = 1
+        if prepare is not None:
+            prepare()
         fork = torch.cuda.Event()
         fork.record(main)
         side.wait_event(fork)
@@ -1098,7 +1150,7 @@ class ckks_engine(EvaluatorOps):
                     jobs.append(lambda sel=sel: self._cc_mult_group([pairs[i] for i in sel], evk, level))
                 slots.append(sel)
                 pos += n
-            for sel, res in zip(slots, self._run_groups(jobs, self._loc(level)[0], (id(evk), level, "mult"))):
+            for sel, res in zip(slots, self._run_groups(jobs, self._loc(level)[0], lambda: self._prepare_ks(evk, level))):
                 for i, r in zip(sel, res):
                     out[i] = r
         return out

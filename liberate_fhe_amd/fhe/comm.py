@@ -22,13 +22,17 @@ class DistComm:
         self.local_device = local_device if local_device is not None else (
             f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cpu")
 
+    def _global(self, group_rank):
+        """torch.distributed addresses peers by GLOBAL rank; the engine speaks in ranks of its group."""
+        return group_rank if self.group is None else dist.get_global_rank(self.group, group_rank)
+
     def broadcast(self, tensor, src, shape, device):
-        """`tensor` is the payload on rank `src` and ignored (may be None) elsewhere."""
+        """`tensor` is the payload on (group) rank `src` and ignored (may be None) elsewhere."""
         if self.rank != src:
             tensor = torch.empty(shape, dtype=torch.int64, device=device)
         else:
             tensor = tensor.contiguous()
-        dist.broadcast(tensor, src=src, group=self.group)
+        dist.broadcast(tensor, src=self._global(src), group=self.group)
         return tensor
 
     def all_gather(self, tensor):
@@ -38,7 +42,7 @@ class DistComm:
 
     def broadcast_int(self, value: int, src: int = 0) -> int:
         t = torch.tensor([value], dtype=torch.int64, device=self.local_device)
-        dist.broadcast(t, src=src, group=self.group)
+        dist.broadcast(t, src=self._global(src), group=self.group)
         return int(t.item())
 
     def barrier(self):

@@ -26,14 +26,45 @@ from .presets import errors, types
 _REFERENCE_DS_MODULE = "liberate.fhe.data_struct"
 
 
+def _safe_storage_from_bytes(blob):
+    """What torch.storage._load_from_bytes does, minus the arbitrary-code path: the nested stream is read by
+    torch's restricted (weights_only) unpickler."""
+    return torch.load(io.BytesIO(blob), weights_only=True)
+
+
+# Every global a container file can legitimately name.  Files are exchanged between parties (client keys,
+# server results), so an untrusted .pkl is the NORMAL input: anything outside this list is refused instead of
+# being imported and called, which is what pickle.load would do (the reference's load() has that hole, eng.py:2024-2029).
+_SAFE_GLOBALS = {
+    ("torch._utils", "_rebuild_tensor_v2"): lambda: torch._utils._rebuild_tensor_v2,
+    ("torch.storage", "_load_from_bytes"): lambda: _safe_storage_from_bytes,
+    ("collections", "OrderedDict"): lambda: __import__("collections").OrderedDict,
+    ("numpy", "dtype"): lambda: np.dtype,
+    ("numpy", "ndarray"): lambda: np.ndarray,
+    ("numpy._core.multiarray", "scalar"): lambda: __import__("numpy")._core.multiarray.scalar,
+    ("numpy.core.multiarray", "_reconstruct"): lambda: __import__("numpy")._core.multiarray._reconstruct,
+    ("numpy._core.multiarray", "_reconstruct"): lambda: __import__("numpy")._core.multiarray._reconstruct,
+}
+_SAFE_GLOBALS[("numpy.core.multiarray", "scalar")] = _SAFE_GLOBALS[("numpy._core.multiarray", "scalar")]   # numpy 1.x files
+for _name in ("LongStorage", "DoubleStorage", "FloatStorage", "IntStorage", "ShortStorage", "CharStorage", "ByteStorage",
+              "BoolStorage", "HalfStorage", "ComplexDoubleStorage", "ComplexFloatStorage", "UntypedStorage"):
+    if hasattr(torch, _name):
+        _SAFE_GLOBALS[("torch", _name)] = (lambda n=_name: getattr(torch, n))
+
+
 class _PortableUnpickler(pickle.Unpickler):
     """Reads containers pickled by this package or by the reference (whose class lives in
-    liberate.fhe.data_struct): both are field-for-field the same NamedTuple."""
+    liberate.fhe.data_struct): both are field-for-field the same NamedTuple.  Only the globals such a file needs
+    (the container class, torch tensor / storage reconstructors, numpy array / scalar reconstructors) resolve;
+    any other raises pickle.UnpicklingError."""
 
     def find_class(self, module, name):
         if name == "data_struct" and module in (_REFERENCE_DS_MODULE, data_struct.__module__):
             return data_struct
-        return super().find_class(module, name)
+        hit = _SAFE_GLOBALS.get((module, name))
+        if hit is None:
+            raise pickle.UnpicklingError(f"refusing to load global {module}.{name} from a ciphertext / key file")
+        return hit()
 
 
 def _portable_dumps(obj) -> bytes:
@@ -196,8 +227,10 @@ class EvaluatorOps:
             filename = self.auto_generate_filename()
         if on_host is None:
             on_host = self.device(text) == "cpu" and not getattr(self.backend, "host_tensors", False)
-        host = text if on_host else self.cpu(text)
-        Path(filename).write_bytes(_portable_dumps(host))
+        host = text if on_host else self.cpu(text)   # collective on a multi-rank engine: every rank takes part
+        comm = getattr(self, "comm", None)
+        if comm is None or comm.world_size == 1 or comm.rank == 0:   # .. and exactly one of them writes the file
+            Path(filename).write_bytes(_portable_dumps(host))
 
     def load(self, filename, move_to_gpu=True):
         with Path(filename).open("rb") as f:

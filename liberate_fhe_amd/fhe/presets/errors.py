@@ -38,6 +38,13 @@ class TestException(_EngineError):
         super().__init__("test error")
 
 
+class KernelLimitExceeded(_EngineError):
+    """Not in the reference: a parameter set the fused HIP kernels are not built for (include/ckks_hip.h: lf_limits)."""
+
+    def __init__(self, what: str):
+        super().__init__(what)
+
+
 class NotFoundMessageSpecialPrimes(_EngineError):
     def __init__(self, message_bit, N):
         super().__init__(f"Can't find message_bit = {message_bit:3<d} and N = {N:6<d}".strip())

@@ -1,1 +1,1 @@
-from . import helpers, synth
+from . import synth

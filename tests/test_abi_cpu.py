@@ -20,7 +20,7 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(so, n), f"{n} declared in include/ckks_hip.h but not exported"
     assert sorted(_native.EXPORTED) == names, "python binding table out of sync with the header"
-    assert _native.lib.lf_abi_version() == 5     # pure host call, no HIP runtime use
+    assert _native.lib.lf_abi_version() == 6     # pure host call, no HIP runtime use
 
 
 def test_shim_exposes_the_fifteen_reference_functions():
@@ -50,3 +50,46 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(base, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src.replace("checker", ""), f
+
+
+def test_library_reads_no_environment_variables():
+    """A drop-in library's results must not depend on ambient env vars: no getenv anywhere in the C sources."""
+    csrc = os.path.join(ROOT, "liberate_fhe_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+
+
+def test_limits_are_exported_and_checked_by_the_engine():
+    """lf_limits reports the capacities compiled into the fused kernels; the engine refuses a parameter set
+    beyond them at construction (10 special primes: digits of 10 limbs > 8) instead of failing inside a launch."""
+    import pytest
+    from liberate_fhe_amd import _native
+    from liberate_fhe_amd.fhe.backend import HipBackend
+    from liberate_fhe_amd.fhe.presets import errors
+    assert [_native.lib.lf_limits(i) for i in range(6)] == [8, 8, 250, 8, 24, -1]
+    assert HipBackend.limits["special_primes"] == 8
+
+    from liberate_fhe_amd.fhe import ckks_engine
+    from tests.oracle_backend import OracleBackend
+    ob = OracleBackend()
+    ob.limits = HipBackend.limits
+    with pytest.raises(errors.KernelLimitExceeded):
+        ckks_engine(devices=["cpu"], backend=ob, logN=14, num_special_primes=10, num_scales=10, is_secured=False)
+
+
+def test_unpickler_refuses_foreign_globals(tmp_path):
+    """load() resolves only the container class and the tensor / array reconstructors."""
+    import io
+    import pickle
+    import pytest
+    from liberate_fhe_amd.fhe.evaluator import _PortableUnpickler
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    with pytest.raises(pickle.UnpicklingError):
+        _PortableUnpickler(io.BytesIO(pickle.dumps(Evil()))).load()
+    golden = os.path.join(ROOT, "tests", "golden", "reference_saved_ct.pkl")
+    ct = _PortableUnpickler(open(golden, "rb")).load()   # a file the reference wrote still loads
+    assert ct.origin == "cipher text"

@@ -72,21 +72,3 @@ def test_scale_prime_pools_equal_shipped_table():
         except LookupError:
             got = None
         assert got == (None if isinstance(want, str) else want), (sb, N)
-
-
-@pytest.mark.reference
-@pytest.mark.skipif(not rd.reference_available(), reason="/root/reference not present")
-def test_generated_cache_files_equal_shipped_files(tmp_path):
-    import os
-    import pickle
-    from liberate_fhe_amd.fhe.cache import cache
-    cache.generate_cache(str(tmp_path))
-    shipped = "/root/reference/src/liberate/fhe/cache/resources"
-    names = sorted(os.listdir(str(tmp_path)))
-    assert names == ["logN_N_M.pkl", "message_special_primes.pkl", "scale_primes.pkl"]
-    for name in names:
-        mine = pickle.load(open(os.path.join(str(tmp_path), name), "rb"))
-        ref = pickle.load(open(os.path.join(shipped, name), "rb"))
-        assert mine == ref, name
-    cache.clean_cache(str(tmp_path))
-    assert os.listdir(str(tmp_path)) == []

@@ -44,7 +44,7 @@ if n_last:
         # bench.py's roofline leg: 3 warm-up + n_last timed launches of the tiled pass alone, then 1 + n_last
         # launches of the column pass (a different kernel): the tiled-pass kernel's last n_last dispatches are the timed ones
         lines += ["", f"# ntt_fwd_pass_mixed, roofline leg only (last {n_last} dispatches: the kernel alone on the GPU, "
-                      f"LF_NTT_ONLY_PASS=2): avg {sum(tail) / len(tail):.2f} us, min {min(tail):.2f}, max {max(tail):.2f}",
+                      f"lf_ntt_pass which=2): avg {sum(tail) / len(tail):.2f} us, min {min(tail):.2f}, max {max(tail):.2f}",
                   f"# bench.py reported avg_launch_ms = {bench['roofline']['avg_launch_ms'] * 1e3:.2f} us from HIP events (un-profiled run)"]
 open(os.path.join(out_dir, f"{tag}_bench_kernel_stats.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
