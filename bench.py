@@ -19,7 +19,11 @@ The JSON line also carries
                  kernel launched alone (lf_ntt_pass, the measurement entry) with the grid it has inside the full step;
   cpu_baseline : the C oracle (strict reference-kernel semantics) on this box's host cores, same workload,
                  bounded sample;
-  extra        : cc_mult(+relinearize) ops/s for silver and gold on this rank, rotate ops/s, limb-NTT/s.
+  roofline_engine_ops : cc_mult_evk / rotate_single per preset against the same HBM peak with SURVEY.md §8(d)'s
+                 algorithmic bytes (N = 1 only);
+  extra        : cc_mult(+relinearize) ops/s for silver and gold on this rank, rotate ops/s, limb-NTT/s.  At N > 1:
+                 gold cc_mult as replicas and LIMB-SHARDED over the ranks (RCCL; BASELINE configs[3]) and the
+                 64-ciphertext gold rotate batch (configs[4]), all timed by default under a watchdog.
 """
 from __future__ import annotations
 
@@ -38,6 +42,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0
+HBM_ACHIEVABLE_GBS = 6300.0   # MI355X_MICROARCH.md: what a streaming kernel reaches of the 8 TB/s spec figure
 L_LIMBS = 30
 LOGN = 16
 
@@ -74,15 +79,68 @@ def cpu_baseline(ctx, rows_idx, batch, budget_s=12.0):
             break
     dt = (time.time() - t0) / reps
     threads = min(os.cpu_count() or 1, n)
-    return {"value": batch / dt, "unit": "poly-NTT(L=30,logN=16)/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} x forward NTT of {batch} polys x {len(rows_idx)} limbs, N=65536, C oracle + OpenMP over limb rows"}
+    out = {"value": batch / dt, "unit": "poly-NTT(L=30,logN=16)/s", "cores": threads, "kind": "port",
+           "sample": f"{reps} x forward NTT of {batch} polys x {len(rows_idx)} limbs, N=65536, C oracle + OpenMP over limb rows"}
+    # the same kernel on ONE core: one polynomial's 30 limbs, OpenMP pinned to a single thread
+    try:
+        import ctypes
+        gomp = ctypes.CDLL("libgomp.so.1")
+        before = gomp.omp_get_max_threads()
+        gomp.omp_set_num_threads(1)
+        n1 = len(rows_idx)
+        x1 = np.ascontiguousarray(x[:n1])
+        orc.ntt(x1, psi[:n1], n1, ctx.logN, q2[:n1], ql[:n1], qh[:n1], kl[:n1], kh[:n1])
+        t0, reps1 = time.time(), 0
+        while True:
+            orc.ntt(x1, psi[:n1], n1, ctx.logN, q2[:n1], ql[:n1], qh[:n1], kl[:n1], kh[:n1])
+            reps1 += 1
+            if time.time() - t0 > 4.0 or reps1 >= 20:
+                break
+        gomp.omp_set_num_threads(before)
+        out["single_thread"] = {"value": reps1 / (time.time() - t0), "unit": "poly-NTT(L=30,logN=16)/s", "cores": 1,
+                                "sample": f"{reps1} x forward NTT of 1 poly x {n1} limbs, one OpenMP thread"}
+    except Exception as e:   # a baseline, never a reason to lose the line
+        out["single_thread"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
+def algorithmic_rows(eng, op):
+    """rows of N*8 bytes an op has to move at level 0 -> 1 (cc_mult) or level 0 (rotate).
+    cc_mult : read 4(l+1) input rows + 2 dnum (l+K) key rows, write 2 l rows, l = rows after the rescale;
+    rotate  : read 2 l' + 2 dnum (l'+K) key rows, write 2 l' rows, l' = rows at level 0."""
+    K = eng.ntt.num_special_primes
+    if op == "cc_mult":
+        ell = len(eng.ntt.p.destination_arrays[1][0])
+        dnum = len(eng._ks_tables(1)["order"])
+        return 4 * (ell + 1) + 2 * dnum * (ell + K) + 2 * ell
+    ell = len(eng.ntt.p.destination_arrays[0][0])
+    dnum = len(eng._ks_tables(0)["order"])
+    return 2 * ell + 2 * dnum * (ell + K) + 2 * ell
+
+
+def op_roofline(eng, op, ops_per_s, profile):
+    rows = algorithmic_rows(eng, op)
+    nbytes = rows * eng.ctx.N * 8
+    achieved = nbytes * ops_per_s / 1e9
+    out = {"bound": "hbm", "algorithmic_rows": rows, "algorithmic_bytes": nbytes, "ops_per_s": ops_per_s,
+           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "frac_of_achievable_6300": achieved / HBM_ACHIEVABLE_GBS}
+    if profile:
+        out["from_profile"] = profile    # dominant kernel + per-kernel time, rocprofv3 summary under profiles/
+    return out
 
 
 def engine_rates(dev, quick):
-    """cc_mult(+relinearize) and rotate_single ops/s on this rank for silver and gold (1 GPU each)."""
+    """cc_mult(+relinearize) and rotate_single ops/s on this rank for silver and gold (1 GPU each), each with its
+    HBM roofline block (algorithmic bytes of SURVEY.md §8(d))."""
     from liberate_fhe_amd.fhe import ckks_engine, presets
     from liberate_fhe_amd.utils import synth
     out = {}
+    roof = {}
+    prof = {}
+    ppath = os.path.join(ROOT, "profiles", "r02_engine_ops_summary.json")
+    if os.path.exists(ppath):
+        prof = json.load(open(ppath))
     for name in ("silver", "gold"):
         eng = ckks_engine(**{**presets.params[name], "devices": [dev]})
         a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
@@ -95,8 +153,10 @@ def engine_rates(dev, quick):
         n = 5 if quick else 20
         ms = event_time_ms(lambda: eng.cc_mult(a, b, evk), n)
         out[f"cc_mult_evk_{name}_ops_per_s"] = 1e3 / ms
+        roof[f"cc_mult_evk_{name}"] = op_roofline(eng, "cc_mult", 1e3 / ms, prof.get(f"{name}_cc_mult"))
         ms = event_time_ms(lambda: eng.rotate_single(a, rotk), n)
         out[f"rotate_single_{name}_ops_per_s"] = 1e3 / ms
+        roof[f"rotate_single_{name}"] = op_roofline(eng, "rotate", 1e3 / ms, prof.get(f"{name}_rotate"))
         # configs[4]: a batch of ciphertexts rotated by the same step (one key): groups of 4 per key-switch launch set
         nb = 16
         cts = [synth.ciphertext(eng, 100 + i, 0) for i in range(nb)]
@@ -109,66 +169,122 @@ def engine_rates(dev, quick):
         torch.cuda.synchronize()
         ms = event_time_ms(lambda: eng.cc_mult_batch(pairs, evk), max(2, n // 4))
         out[f"cc_mult_evk_{name}_batch{nb}_ops_per_s"] = nb * 1e3 / ms
+        roof[f"cc_mult_evk_{name}_batch{nb}"] = op_roofline(eng, "cc_mult", nb * 1e3 / ms, None)
+        if name == "gold":
+            # BASELINE configs[4] at its stated size: 64 level-0 ciphertexts (seeds 100..163) under one rotation key
+            cts64 = cts + [synth.ciphertext(eng, 100 + i, 0) for i in range(nb, 64)]
+            eng.rotate_single_batch(cts64, rotk)
+            torch.cuda.synchronize()
+            ms = event_time_ms(lambda: eng.rotate_single_batch(cts64, rotk), 2)
+            out["rotate_single_gold_batch64_rotations_per_s"] = 64 * 1e3 / ms
+            roof["rotate_single_gold_batch64"] = op_roofline(eng, "rotate", 64 * 1e3 / ms, None)
+            del cts64
         del cts, pairs
         del eng, a, b, evk, rotk
         torch.cuda.empty_cache()
-    return out
+    return out, roof
 
 
-def multi_gpu_rates(dev, world, rank, sharded):
-    """N > 1: gold cc_mult(+relinearize) (a) limb-sharded over all ranks — one ciphertext at a time, rescale row by
-    RCCL broadcast, key-switch digits by RCCL all-gather — and (b) as independent replicas (one full engine per
-    GPU, zero communication; the whole-job rate is the sum).  Returns a dict for `extra`; never raises."""
+def cpu_engine_baseline(budget_s=25.0):
+    """cc_mult(+relinearize) at silver on the host cores: this package's orchestration over the CHECKER backend
+    (tests/oracle_backend.py: the reference's composition of ntt_cuda calls, each call the C oracle with OpenMP
+    over limb rows, torch elementwise ops in between — what the reference engine would do if its extension were
+    a CPU library).  Bounded sample: as many ops as fit the budget, at least one."""
+    from liberate_fhe_amd.fhe import ckks_engine, presets
+    from liberate_fhe_amd.utils import synth
+    from tests.oracle_backend import OracleBackend
+    params = {k: v for k, v in presets.params["silver"].items() if k != "devices"}
+    eng = ckks_engine(devices=["cpu"], backend=OracleBackend(), **params)
+    a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
+    evk = synth.key_switch_key(eng, 5)
+    eng.cc_mult(a, b, evk)       # warm: tables, thread pool
+    t0, reps = time.time(), 0
+    while True:
+        eng.cc_mult(a, b, evk)
+        reps += 1
+        if time.time() - t0 > budget_s or reps >= 10:
+            break
+    dt = (time.time() - t0) / reps
+    return {"value": 1.0 / dt, "unit": "cc_mult_evk(silver)/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "sample": f"{reps} x cc_mult+relinearize, silver (logN 15, level 0 -> 1), checker backend (C oracle + OpenMP, "
+                      f"reference-shaped orchestration), after one warm-up op"}
+
+
+def _max_over_ranks(ms, dev):
     import torch.distributed as dist
-    out = {}
+    t = torch.tensor([ms], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def multi_gpu_rates(dev, world, rank, out, sharded=True):
+    """N > 1.  Fills `out` (a dict that main() prints even if a leg below never returns, see the watchdog):
+      replicas      gold cc_mult(+relinearize) on N independent engines, zero communication: N x single rate;
+      config 5      64 gold ciphertexts rotated under one key, 64 / N per rank (batch replicas, full key per GPU);
+      config 4      gold cc_mult LIMB-SHARDED over the N ranks by rns_partition: rescale row by RCCL broadcast,
+                    key-switch digits by per-digit RCCL all-gathers overlapped with the extension of the previous
+                    digit group (fhe/comm.py); plus limb-sharded rotate_single.
+    Every leg is fenced by barriers on the default group and catches its own exceptions; the sharded legs run on
+    their OWN process group with a short timeout, so a rank that fails inside them cannot hang the line."""
+    import datetime
+    import torch.distributed as dist
+    from liberate_fhe_amd.fhe import ckks_engine, presets
+    from liberate_fhe_amd.utils import synth
+    params = {k: v for k, v in presets.params["gold"].items() if k != "devices"}
     try:
-        from liberate_fhe_amd.fhe import ckks_engine, presets
-        from liberate_fhe_amd.fhe.comm import DistComm
-        from liberate_fhe_amd.utils import synth
-        params = {k: v for k, v in presets.params["gold"].items() if k != "devices"}
-        # (b) replicas
         eng = ckks_engine(devices=[dev], **params)
         a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
         evk = synth.key_switch_key(eng, 5)
+        rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
         for _ in range(2):
             eng.cc_mult(a, b, evk)
         torch.cuda.synchronize()
         dist.barrier()
-        ms = event_time_ms(lambda: eng.cc_mult(a, b, evk), 10)
-        t = torch.tensor([ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        out["cc_mult_evk_gold_replicas_ops_per_s"] = world * 1e3 / float(t.item())
-        # the same replicas multiplying batches of 16 pairs under their key (cc_mult_batch)
+        ms = _max_over_ranks(event_time_ms(lambda: eng.cc_mult(a, b, evk), 10), dev)
+        out["cc_mult_evk_gold_replicas_ops_per_s"] = world * 1e3 / ms
         nb = 16
         cts = [synth.ciphertext(eng, 100 + i, 0) for i in range(nb)]
         pairs = [(cts[i], cts[(i + 1) % nb]) for i in range(nb)]
         eng.cc_mult_batch(pairs, evk)
         torch.cuda.synchronize()
         dist.barrier()
-        ms = event_time_ms(lambda: eng.cc_mult_batch(pairs, evk), 3)
-        t = torch.tensor([ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        out[f"cc_mult_evk_gold_replicas_batch{nb}_ops_per_s"] = world * nb * 1e3 / float(t.item())
-        del eng, a, b, evk, cts, pairs
+        ms = _max_over_ranks(event_time_ms(lambda: eng.cc_mult_batch(pairs, evk), 3), dev)
+        out[f"cc_mult_evk_gold_replicas_batch{nb}_ops_per_s"] = world * nb * 1e3 / ms
+        del pairs
+        # config 5, batch-replica mode: ciphertexts 100..163, rank r takes every world-th one
+        mine = [synth.ciphertext(eng, 100 + i, 0) for i in range(rank, 64, world)]
+        eng.rotate_single_batch(mine, rotk)
+        torch.cuda.synchronize()
+        dist.barrier()
+        ms = _max_over_ranks(event_time_ms(lambda: eng.rotate_single_batch(mine, rotk), 3), dev)
+        out["rotate_single_gold_batch64_replicas_rotations_per_s"] = 64 * 1e3 / ms
+        del eng, a, b, evk, rotk, cts, mine
         torch.cuda.empty_cache()
-        if not sharded:
-            return out
-        # (a) limb-sharded (opt-in: a failure on one rank inside the engine's collectives would hang the others,
-        # and this box cannot rehearse a multi-GPU run — see DESIGN.md §7)
-        eng = ckks_engine(devices=[dev], comm=DistComm(local_device=dev), **params)
+    except Exception as e:
+        out["multi_gpu_replicas_error"] = f"{type(e).__name__}: {e}"[:300]
+    if not sharded:
+        return
+    try:
+        from liberate_fhe_amd.fhe.comm import DistComm
+        grp = dist.new_group(ranks=list(range(world)), timeout=datetime.timedelta(seconds=120))
+        eng = ckks_engine(devices=[dev], comm=DistComm(group=grp, local_device=dev), **params)
         a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
         evk = synth.key_switch_key(eng, 5)
+        rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
         for _ in range(2):
             eng.cc_mult(a, b, evk)
         torch.cuda.synchronize()
-        dist.barrier()
-        ms = event_time_ms(lambda: eng.cc_mult(a, b, evk), 10)
-        t = torch.tensor([ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        out["cc_mult_evk_gold_limb_sharded_ops_per_s"] = 1e3 / float(t.item())
-    except Exception as e:   # the headline line must survive a failure of this optional leg
-        out["multi_gpu_cc_mult_error"] = f"{type(e).__name__}: {e}"[:300]
-    return out
+        dist.barrier(group=grp)
+        ms = _max_over_ranks(event_time_ms(lambda: eng.cc_mult(a, b, evk), 10), dev)
+        out["cc_mult_evk_gold_limb_sharded_ops_per_s"] = 1e3 / ms
+        eng.rotate_single(a, rotk)
+        torch.cuda.synchronize()
+        dist.barrier(group=grp)
+        ms = _max_over_ranks(event_time_ms(lambda: eng.rotate_single(a, rotk), 10), dev)
+        out["rotate_single_gold_limb_sharded_ops_per_s"] = 1e3 / ms
+        out["limb_sharded_rows_per_rank_level0"] = [len(d) for d in eng.ntt.p.destination_arrays_with_special[0]]
+    except Exception as e:   # the headline line must survive a failure of this leg
+        out["multi_gpu_limb_sharded_error"] = f"{type(e).__name__}: {e}"[:300]
 
 
 def main():
@@ -178,8 +294,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128, help="polynomials per step per GPU")
     ap.add_argument("--no-extra", action="store_true", help="skip the cc_mult / rotate / CPU legs")
-    ap.add_argument("--sharded", action="store_true",
-                    help="N > 1: also time the limb-sharded gold cc_mult (RCCL broadcast + all-gather)")
+    ap.add_argument("--no-sharded", action="store_true",
+                    help="N > 1: skip the limb-sharded gold cc_mult / rotate legs (RCCL broadcast + all-gather), timed by default")
+    ap.add_argument("--leg-timeout", type=float, default=420.0,
+                    help="N > 1: seconds after which the multi-GPU engine legs are abandoned and the line is printed without them")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -190,8 +308,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
+        import datetime
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")   # a failed collective raises instead of blocking
+        dist.init_process_group("nccl", device_id=torch.device(dev), timeout=datetime.timedelta(seconds=900))
 
     import __graft_entry__ as g
     if rank == 0:
@@ -303,21 +423,44 @@ def main():
                          "wave_instr_per_launch": valu, "achieved_G_per_s": valu / (k_ms * 1e-3) / 1e9,
                          "peak_fma_f64_G_per_s": 455.6, "frac": valu / (k_ms * 1e-3) / 455.6e9}},
     }
-    extra = {"limb_ntt_per_s": value * L_LIMBS, "device_ms_per_step": dev_ms}
+    extra = {"limb_ntt_per_s": value * L_LIMBS, "device_ms_per_step": dev_ms,
+             "whole_step_frac_of_achievable_6300": 16 * N * L_LIMBS * B / (dev_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS}
+    result["extra"] = extra
     if rank == 0 and world == 1 and not args.no_extra:
-        extra.update(engine_rates(dev, quick=False))
+        rates, roof = engine_rates(dev, quick=False)
+        extra.update(rates)
+        result["roofline_engine_ops"] = roof     # cc_mult_evk / rotate_single: the metric's second half, per preset
         result["cpu_baseline"] = cpu_baseline(ctx, rows_idx, batch=min(B, 16))   # bounded sample of the same workload
+        try:
+            result["cpu_baseline"]["cc_mult_evk_silver"] = cpu_engine_baseline()
+        except Exception as e:
+            result["cpu_baseline"]["cc_mult_evk_silver"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     else:
         result["cpu_baseline"] = None   # reported by the N=1 run only
     if world > 1 and not args.no_extra:
-        more = multi_gpu_rates(dev, world, rank, args.sharded)
-        extra.update(more)
-    result["extra"] = extra
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        # The engine legs run under a watchdog: if they are not back after --leg-timeout seconds (a rank stuck in
+        # a collective), rank 0 prints the line with what has been measured so far and every rank leaves with
+        # os._exit — nothing is re-exec'ed, the process just ends.
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(args.leg_timeout):
+                extra["multi_gpu_legs_abandoned_after_s"] = args.leg_timeout
+                if rank == 0:
+                    print(json.dumps(result), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        multi_gpu_rates(dev, world, rank, extra, sharded=not args.no_sharded)
+        done.set()
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if world > 1:
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

@@ -208,6 +208,21 @@ int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int np
                      const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
                      const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 
+/* The two halves of lf_ks_core as separate calls (single ciphertext), so that a limb-sharded engine can start on the
+ * digits that have already arrived while the others are still travelling over xGMI (ckks_engine.py:778-829 stages
+ * every digit through the host before any extension starts):
+ *   lf_ks_fwd   extension + forward NTT of `nparts` digits, descriptors desc[0 .. nparts); the caller offsets desc
+ *               and tmp to the first digit of the group (desc + 3 * first, tmp + first * rows * N);
+ *   lf_ks_tail  after the last group: inner product of ALL nparts digits in tmp with the key + inverse NTT.
+ * lf_ks_fwd over all digits followed by lf_ks_tail == lf_ks_core. */
+int lf_ks_fwd(const int64_t *state, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E, const double *Ed,
+              int64_t *tmp, const int64_t *psi_br, const double *psi_dp, const int64_t *q_host, const int64_t *ql,
+              const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+int lf_ks_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
+               const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
+               const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+               void *stream);
+
 /* Batched forms: `count` (<= 8) independent operand sets in ONE launch — the two components of a ciphertext, the
  * four polynomials cc_mult rescales.  The arrays of pointers are HOST arrays of device pointers; constants are
  * shared by all sets.  addend may be NULL, or hold NULL entries. */

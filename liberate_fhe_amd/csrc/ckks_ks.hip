@@ -275,27 +275,17 @@ void classify_rows(int rows, const int64_t *q_host, RowList &dp, RowList &in) {
     }
 }
 
-}  // namespace
-
-extern "C" {
-
-int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int nparts, int rows, int logN, const int64_t *desc,
-                     const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
-                     int64_t row_off, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
-                     const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
-                     const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
-    if (nparts < 1 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
-        !q_host || !psi_dp || !ipsi_dp || !Ed || (nct != 1 && nct != 2 && nct != 4))
-        return LF_ERR_ARG;
-    if (int e = lf_set_device(device)) return e;
-    hipStream_t st = (hipStream_t)stream;
+// K2 + P2 of `nparts` digits (descriptors desc[0 .. nparts), extended digits into tmp[nct][nparts][rows][N])
+int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, int rows, int logN, const int64_t *desc,
+               const int64_t *E, const double *Ed, int64_t *tmp, const int64_t *psi_br, const double *psi_dp,
+               const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
+               hipStream_t st) {
     const int tl = NTT_TILE_LOG_MAX, S1 = logN - tl;
     const KsGeom kg{logN, tl, S1, rows, nparts, (i64)1 << logN, nct, (i64)state_stride};
     RowList dp, in;
     classify_rows(rows, q_host, dp, in);
     const unsigned tiles = 1u << (logN - tl);
     const unsigned polys = (unsigned)nparts * (unsigned)nct;   // extended digits of all ciphertexts: one stack
-
     const bool mixed = dp.n && in.n && mixed_enabled();   // both arithmetic classes in one launch per step
     // K2: extend + strided pass
     if (mixed) {
@@ -329,6 +319,18 @@ int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int np
                                (const i64 *)psi_br, psi_dp, (const i64 *)nullptr, (const i64 *)ql, (const i64 *)qh,
                                (const i64 *)kl, (const i64 *)kh);
     }
+    return (int)hipGetLastError();
+}
+
+// K3 + K4: inner product of the nparts extended digits with the key, inverse transform to canonical coefficients
+int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
+            int64_t row_off, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp,
+            const int64_t *Ninv, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+            const int64_t *kh, hipStream_t st) {
+    const int tl = NTT_TILE_LOG_MAX, S1 = logN - tl;
+    RowList dp, in;
+    classify_rows(rows, q_host, dp, in);
+    const bool mixed = dp.n && in.n && mixed_enabled();
     // K3: inner product with the key, summed over the digits
     {
         const i64 N = (i64)1 << logN;
@@ -381,6 +383,54 @@ int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int np
                                (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     }
     return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int nparts, int rows, int logN, const int64_t *desc,
+                     const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
+                     int64_t row_off, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
+                     const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
+                     const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (nparts < 1 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
+        !q_host || !psi_dp || !ipsi_dp || !Ed || (nct != 1 && nct != 2 && nct != 4))
+        return LF_ERR_ARG;
+    if (int e = lf_set_device(device)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = ks_forward(state, state_stride, nct, nparts, rows, logN, desc, E, Ed, tmp, psi_br, psi_dp, q_host, ql, qh, kl, kh, st))
+        return e;
+    return ks_tail(nct, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh,
+                   kl, kh, st);
+}
+
+/* The two halves of lf_ks_core as separate calls, so that a limb-sharded engine can start on the digits that have
+ * arrived while the others are still travelling ("gather part p+1 while extending part p"):
+ *   lf_ks_fwd   extension + forward NTT of `nparts` digits, descriptors desc[0 .. nparts) (the caller offsets desc and
+ *               tmp to the first digit of the group: tmp_group = tmp + first * rows * N);
+ *   lf_ks_tail  once every group is done: inner product of ALL nparts digits with the key + inverse NTT. */
+int lf_ks_fwd(const int64_t *state, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E, const double *Ed,
+              int64_t *tmp, const int64_t *psi_br, const double *psi_dp, const int64_t *q_host, const int64_t *ql,
+              const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (nparts < 0 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
+        !q_host || !psi_dp || !Ed)
+        return LF_ERR_ARG;
+    if (nparts == 0) return 0;
+    if (int e = lf_set_device(device)) return e;
+    return ks_forward(state, 0, 1, nparts, rows, logN, desc, E, Ed, tmp, psi_br, psi_dp, q_host, ql, qh, kl, kh, (hipStream_t)stream);
+}
+
+int lf_ks_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
+               const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
+               const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+               void *stream) {
+    if (nparts < 1 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
+        !q_host || !ipsi_dp)
+        return LF_ERR_ARG;
+    if (int e = lf_set_device(device)) return e;
+    return ks_tail(1, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh, kl,
+                   kh, (hipStream_t)stream);
 }
 
 int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,

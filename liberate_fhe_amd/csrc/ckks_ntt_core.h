@@ -11,6 +11,11 @@
 #define SMALL_PRIME_LIMIT (1ull << 41)
 
 #define PAD(L) ((L) + ((L) >> 3))
+// PAD(p + (e << LOGDL)) for LOGDL >= 3 and a p whose bits LOGDL .. LOGDL + K - 1 are clear: the element stride of the
+// padded layout is a compile-time constant, so the 2^K accesses of a register step share ONE address register and
+// differ in the instruction's immediate offset (the compiler does not derive this from the shift / or form:
+// it spent three VALU instructions per LDS access on the address)
+#define PAD_STRIDE(LOGDL) ((1 << (LOGDL)) + ((1 << (LOGDL)) >> 3))
 #define NTT_FLAG_WORD NTT_LDS_WORDS          // two flag words live behind the tile in the same LDS array
 
 namespace {
@@ -135,8 +140,17 @@ struct RowDp {
 // r < 0 ? r + m : r in three fp64 instructions: floor(r * 2^-64) is -1 for r < 0 and 0 otherwise (|r| < 2^53).
 // (Masking m with the sign bit costs four: shift, two 32-bit ANDs, add; measured 1 % slower on the tiled pass.)
 __device__ __forceinline__ double dp_addmask(double r, double m) {
+#ifdef LF_NO_CLAMP_FIX
     const double neg = __builtin_floor(r * 5.421010862427522e-20);
     return __builtin_fma(-neg, m, r);
+#else
+    // r is an INTEGER-valued double: r < 0 means r <= -1, so clamp(-r) to [0, 1] (the VOP3 output modifier) IS the
+    // indicator [r < 0] — one instruction instead of the multiply + floor pair (-0.0 never occurs: a zero sum of
+    // two opposite doubles is +0.0 under round-to-nearest)
+    // (fmin(fmax(x, 0), 1) is the form the compiler folds into the clamp bit: v_max_f64 neg, -r, -r clamp)
+    const double neg = __builtin_fmin(__builtin_fmax(-r, 0.0), 1.0);
+    return __builtin_fma(neg, m, r);
+#endif
 }
 
 // (a * w) mod q, canonical, for a < 2^52, w < q: exact via the FMA low part.
@@ -321,8 +335,9 @@ __device__ __forceinline__ void fwd_step(typename A::T *sm, int T, int log_dl_rt
     for (int w = threadIdx.x; w < items; w += NTT_THREADS) {
         const int p = ((w >> log_dl) << (log_dl + K)) | (w & ((1 << log_dl) - 1));
         typename A::T x[1 << K];
+        const int pb = PAD(p);
 #pragma unroll
-        for (int e = 0; e < (1 << K); ++e) x[e] = sm[PAD(p + (e << log_dl))];
+        for (int e = 0; e < (1 << K); ++e) x[e] = LOGDL >= 3 ? sm[pb + e * PAD_STRIDE(LOGDL >= 3 ? LOGDL : 3)] : sm[PAD(p + (e << log_dl))];
         // stage u uses 2^u twiddles, entries (i0 << u) .. (i0 << u) + 2^u - 1 of the bit-reversed table
         const int i0 = (1 << s) + ((base + p) >> (E - s));
 #pragma unroll
@@ -339,7 +354,10 @@ __device__ __forceinline__ void fwd_step(typename A::T *sm, int T, int log_dl_rt
         }
         A::fwd_end(c, x);
 #pragma unroll
-        for (int e = 0; e < (1 << K); ++e) sm[PAD(p + (e << log_dl))] = x[e];
+        for (int e = 0; e < (1 << K); ++e) {
+            if (LOGDL >= 3) sm[pb + e * PAD_STRIDE(LOGDL >= 3 ? LOGDL : 3)] = x[e];
+            else sm[PAD(p + (e << log_dl))] = x[e];
+        }
     }
 }
 
@@ -378,11 +396,14 @@ __device__ __forceinline__ void fwd_step8(typename A::T *sm, const StepTw<A, LOG
     const int w = lf_tid();
     const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
     typename A::T x[8];
+    typename A::T *sp = sm + PAD(p);   // LOGDL = 0: p = 8 w, the 8 words are consecutive (PAD(8 w + e) = 9 w + e)
+    constexpr int st = LOGDL >= 3 ? PAD_STRIDE(LOGDL >= 3 ? LOGDL : 3) : 1;
+    static_assert(LOGDL >= 3 || LOGDL == 0, "padded stride of a radix-8 step");
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = sm[PAD(p + (e << LOGDL))];
+    for (int e = 0; e < 8; ++e) x[e] = sp[e * st];
     fwd_regs8<A, LOGDL>(x, tw, c);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sm[PAD(p + (e << LOGDL))] = x[e];
+    for (int e = 0; e < 8; ++e) sp[e * st] = x[e];
 }
 
 // Inverse radix-2^K step over local distances dl, 2dl, .. at stages s, s+1, ..
@@ -395,8 +416,9 @@ __device__ __forceinline__ void inv_step(typename A::T *sm, int T, int log_dl_rt
     for (int w = threadIdx.x; w < items; w += NTT_THREADS) {
         const int p = ((w >> log_dl) << (log_dl + K)) | (w & ((1 << log_dl) - 1));
         typename A::T x[1 << K];
+        const int pb = PAD(p);
 #pragma unroll
-        for (int e = 0; e < (1 << K); ++e) x[e] = sm[PAD(p + (e << log_dl))];
+        for (int e = 0; e < (1 << K); ++e) x[e] = LOGDL >= 3 ? sm[pb + e * PAD_STRIDE(LOGDL >= 3 ? LOGDL : 3)] : sm[PAD(p + (e << log_dl))];
         // stage u uses 2^(K-1-u) twiddles, entries (il << (K-1-u)) .. of the bit-reversed table
         const int il = (1 << (logN - s - K)) + ((base + p) >> (s + K - adj));
 #pragma unroll
@@ -413,7 +435,10 @@ __device__ __forceinline__ void inv_step(typename A::T *sm, int T, int log_dl_rt
         }
         A::inv_end(c, x);
 #pragma unroll
-        for (int e = 0; e < (1 << K); ++e) sm[PAD(p + (e << log_dl))] = x[e];
+        for (int e = 0; e < (1 << K); ++e) {
+            if (LOGDL >= 3) sm[pb + e * PAD_STRIDE(LOGDL >= 3 ? LOGDL : 3)] = x[e];
+            else sm[PAD(p + (e << log_dl))] = x[e];
+        }
     }
 }
 
@@ -451,11 +476,14 @@ __device__ __forceinline__ void inv_step8(typename A::T *sm, const StepTwInv<A, 
     const int w = lf_tid();
     const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
     typename A::T x[8];
+    typename A::T *sp = sm + PAD(p);
+    constexpr int st = LOGDL >= 3 ? PAD_STRIDE(LOGDL >= 3 ? LOGDL : 3) : 1;
+    static_assert(LOGDL >= 3 || LOGDL == 0, "padded stride of a radix-8 step");
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = sm[PAD(p + (e << LOGDL))];
+    for (int e = 0; e < 8; ++e) x[e] = sp[e * st];
     inv_regs8<A, LOGDL>(x, tw, c);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sm[PAD(p + (e << LOGDL))] = x[e];
+    for (int e = 0; e < 8; ++e) sp[e * st] = x[e];
 }
 
 template <class A, bool FAST>
@@ -486,6 +514,10 @@ __device__ __forceinline__ void run_fwd_stages(typename A::T *sm, const PassGeom
     if (FAST && g.tl == 12 && left >= 3) {   // strided pass of a 4096-word tile: first step at distance 2^11
         fwd_step<3, A, 9>(sm, T, 9, s, E, base, c); lds_barrier();
         s += 3; left -= 3; log_d -= 3;
+        if (left == 1) {   // logN 16: the fourth strided stage, distance 2^8 known at compile time
+            fwd_step<1, A, 8>(sm, T, 8, s, E, base, c); lds_barrier();
+            return;
+        }
     }
     while (left > 0) {
         if (FAST && left >= 3) {
@@ -610,8 +642,11 @@ __device__ __forceinline__ bool fwd_tile12_core(typename A::T *smt, i64 *sm, typ
     StepTw<A, 0> t0;
     t9.load(c, s, E, base);
     fwd_regs8<A, 9>(x, t9, c);
+    {
+        typename A::T *sp = smt + PAD(w);   // PAD(w + 512 e) = PAD(w) + 576 e
 #pragma unroll
-    for (int e = 0; e < 8; ++e) smt[PAD(w + (e << 9))] = x[e];
+        for (int e = 0; e < 8; ++e) sp[e * PAD_STRIDE(9)] = x[e];
+    }
     t6.load(c, s + 3, E, base);
     lds_barrier();
     if (sm[NTT_FLAG_WORD] != 0) {
@@ -637,13 +672,13 @@ __device__ __forceinline__ void store_tile12_regs(i64 *sm, const i64 (&o)[8], i6
     for (int e = 0; e < 8; ++e) sm[9 * w + e] = o[e];
     wave_lds_sync();
     const int L0 = ((w >> 6) << 9) + ((w & 63) << 1);
+    const i64 *sp = sm + PAD(L0);   // L0 even: PAD(L0 + 128 i + 1) = PAD(L0) + 144 i + 1
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int L = L0 + (i << 7);
         longlong2 v;
-        v.x = sm[PAD(L)];
-        v.y = sm[PAD(L + 1)];
-        *reinterpret_cast<longlong2 *>(dst + L) = v;
+        v.x = sp[i * PAD_STRIDE(7)];
+        v.y = sp[i * PAD_STRIDE(7) + 1];
+        *reinterpret_cast<longlong2 *>(dst + L0 + (i << 7)) = v;
     }
 }
 
@@ -734,8 +769,11 @@ __device__ __forceinline__ bool inv_tile12_core(typename A::T *smt, i64 *sm, typ
     inv_step8<A, 6>(smt, t6, cc);
     t9.load(c, s + 9, 0, logN, base);
     lds_barrier();
+    {
+        const typename A::T *sp = smt + PAD(w);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = smt[PAD(w + (e << 9))];
+        for (int e = 0; e < 8; ++e) x[e] = sp[e * PAD_STRIDE(9)];
+    }
     cc.inv_reduce = 1;
     inv_regs8<A, 9>(x, t9, cc);
     return true;
@@ -773,9 +811,9 @@ __device__ __forceinline__ bool inv_tile12(i64 *sm, const i64 *src_row, i64 *dst
                 v.y = v.y < 0 ? v.y + q2 : v.y;
             }
             odd |= ((u64)v.x >= (u64)q2) | ((u64)v.y >= (u64)q2);
-            const int L = L0 + (i << 7);
-            sm[PAD(L)] = v.x;
-            sm[PAD(L + 1)] = v.y;
+            i64 *sp = sm + PAD(L0);   // L0 even: PAD(L0 + 128 i + 1) = PAD(L0) + 144 i + 1
+            sp[i * PAD_STRIDE(7)] = v.x;
+            sp[i * PAD_STRIDE(7) + 1] = v.y;
         }
     }
     wave_flag_set(sm, odd);

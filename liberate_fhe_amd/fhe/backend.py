@@ -192,6 +192,23 @@ class HipBackend:
                              row_off, _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
                              c.qptr(), *c.mont(), dev, st), "lf_ks_core")
 
+    def ks_fwd(self, state, first, count, rows, logN, desc, E, Ed, tmp, psi, c: Consts):
+        """Extension + forward NTT of digits first .. first + count - 1 into tmp[first:first + count] (lf_ks_fwd)."""
+        dev, st = _ds(tmp)
+        psi_dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
+        N = tmp.size(-1)
+        check(lib.lf_ks_fwd(_p(state), count, rows, logN, _p(desc) + first * 3 * 8, _p(E), _pd(Ed),
+                            _p(tmp) + first * rows * N * 8, _p(psi), psi_dp, c.qptr(), *c.mont(), dev, st), "lf_ks_fwd")
+
+    def ks_tail(self, nparts, rows, logN, key, first_part, row_off, tmp, s, ipsi, Ninv, c: Consts):
+        """Inner product of all extended digits with the key + inverse NTT (lf_ks_tail)."""
+        dev, st = _ds(s)
+        part_stride, comp_stride = key.stride(0), key.stride(1)
+        base = key.data_ptr() + first_part * part_stride * 8
+        ipsi_dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
+        check(lib.lf_ks_tail(nparts, rows, logN, base, part_stride, comp_stride, row_off, _p(tmp), _p(s), _p(ipsi), ipsi_dp,
+                             _p(Ninv), c.qptr(), *c.mont(), dev, st), "lf_ks_tail")
+
     ks_batch_sizes = (4, 2)   # ciphertexts per lf_ks_core_batch call (largest first)
 
     def ks_core_batch(self, states, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv,

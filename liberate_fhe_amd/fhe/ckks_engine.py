@@ -613,13 +613,10 @@ class ckks_engine(EvaluatorOps):
     # exchange steps
     # =============================================================================================
     def _share_rows(self, rows_by_owner, owner, targets, shape):
-        """Row block held by `owner` -> {device: tensor} on every local target device.
-        Reference: GPU -> pinned host -> GPU copies (eng.py:999-1011); here RCCL broadcast, or a
-        device-to-device copy when one process drives all devices."""
-        if self.comm is not None and self.comm.world_size > 1:
-            buf = rows_by_owner if owner in self.local_ids else None
-            buf = self.comm.broadcast(buf, src=owner, shape=shape, device=self.ntt.devices[self.local_ids[0]])
-            return {d: buf for d in targets if d in self.local_ids}
+        """Row block held by `owner` -> {device: tensor} on every target device of THIS process (one process driving
+        several devices: device-to-device copies where the reference stages through pinned host memory,
+        eng.py:999-1011).  With one process per GPU the rows travel by an in-place RCCL broadcast instead
+        (_rescale_operands)."""
         out = {}
         for d in targets:
             dev = self.ntt.devices[d]
@@ -648,14 +645,17 @@ class ckks_engine(EvaluatorOps):
         # the dropped limb's row of every polynomial, on every local target device
         rows0 = []                                   # rows0[k][comp] = {device: [N] tensor}
         multi = self.comm is not None and self.comm.world_size > 1
-        for ct in cts:
+        for k, ct in enumerate(cts):
             if multi:
-                stacked = None
-                if owner in loc_before:
+                # both components' rows in one message, in place on a buffer kept per (level, operand slot)
+                me = self.local_ids[0]
+                buf = self._ws(("rescale_rows", k), (2, N), me)
+                if owner == me:
                     i = loc_before.index(owner)
-                    stacked = torch.stack([ct.data[0][i][0], ct.data[1][i][0]])
-                shared = self._share_rows(stacked, owner, targets, (2, N))
-                rows0.append([{d: t[comp] for d, t in shared.items()} for comp in range(2)])
+                    buf[0].copy_(ct.data[0][i][0])
+                    buf[1].copy_(ct.data[1][i][0])
+                self.comm.broadcast_into(buf, owner)
+                rows0.append([{d: buf[comp] for d in targets if d in self.local_ids} for comp in range(2)])
             else:
                 i = loc_before.index(owner)
                 rows0.append([self._share_rows(ct.data[comp][i][0], owner, targets, (N,)) for comp in range(2)])
@@ -827,41 +827,52 @@ class ckks_engine(EvaluatorOps):
             tabs[("pip", d)] = torch.tensor(
                 [[float(pow(specials[P_ind], -1, ctx.q[r])) if i < nrows - P_ind - 1 else 0.0 for i, r in enumerate(dest)]
                  for P_ind in range(K)], dtype=torch.float64, device=self.ntt.devices[d])
-        # (4) gather map for the digit all-gather (multi-device): row of the stacked per-device states
-        if n_alive > 1:
-            max_rows = max(self._rows(d, level, False) for d in range(n_alive))
-            idx = []
-            for d, rows, _ in order:
-                idx += [d * max_rows + r for r in rows]
-            tabs["gather"] = (max_rows, idx)
+        # (4) exchange schedule (multi-device): runs of consecutive digits with the same owner travel as one
+        # message — (owner, first digit, digits, first row in storage order, rows, first row in the owner's state)
+        groups = []
+        for s_, (d, rows, _) in enumerate(order):
+            if groups and groups[-1][0] == d and groups[-1][5] + groups[-1][4] == rows[0]:
+                g = groups[-1]
+                groups[-1] = (g[0], g[1], g[2] + 1, g[3], g[4] + len(rows), g[5])
+            else:
+                groups.append((d, s_, 1, row_start[s_], len(rows), rows[0]))
+        tabs["groups"] = groups
         self._tables[key] = tabs
         return tabs
 
-    def _gather_digits(self, states, level, tabs):
-        """Every alive device receives every digit (eng.py:778-810: the reference stages through pinned
-        host memory; here one RCCL all-gather, or peer copies inside one process).  Returns
-        {local device: [total_rows, N] digits in storage order}."""
+    def _exchange_digits(self, states, level, tabs):
+        """Every alive device receives every digit (eng.py:778-810: the reference stages all of them through pinned
+        host memory first).  Returns {local device: (digits buffer [total_rows, N] in storage order,
+        [(ready, first digit, digits), ...])}: the digits of a group may be read once `ready.wait()` has been
+        called (ready None: already ordered on the current stream).  Buffers are allocated once per level; the
+        groups are issued in the order the key switch consumes them."""
         n_alive = self.len_devices[level]
         loc = self._loc(level)
+        nparts = len(tabs["order"])
         if n_alive == 1:
-            return {loc[0]: states[loc[0]]} if loc else {}
-        max_rows, idx = tabs["gather"]
+            return {loc[0]: (states[loc[0]], [(None, 0, nparts)])} if loc else {}
         N = self.ctx.N
+        groups = tabs["groups"]
         if self.comm is not None and self.comm.world_size > 1:
-            dev = self.ntt.devices[self.local_ids[0]]
-            mine = torch.zeros((max_rows, N), dtype=torch.int64, device=dev)
-            if loc:
-                mine[:states[loc[0]].size(0)] = states[loc[0]]
-            stacked = torch.cat(self.comm.all_gather(mine)[:n_alive])
-            index = torch.tensor(idx, dtype=torch.int64, device=dev)
-            return {d: stacked.index_select(0, index) for d in loc}
+            me = self.local_ids[0]
+            # a rank without ordinary rows at this level still takes part in the collectives (scratch buffer)
+            buf = self._ws("ks_digits_all", (tabs["total_rows"], N), me)
+            ready = []
+            for owner, first, count, row0, nrows, src_row in groups:
+                dst = buf[row0:row0 + nrows]
+                if owner == me:
+                    dst.copy_(states[me][src_row:src_row + nrows])
+                ready.append((self.comm.broadcast_into(dst, owner, async_op=True), first, count))
+            if not loc:   # nothing to switch here: this rank only had to take part
+                for handle, _, _ in ready:
+                    handle.wait()
+            return {d: (buf, ready) for d in loc}
         out = {}
         for t in loc:
-            dev = self.ntt.devices[t]
-            pieces = []
-            for d, rows, _ in tabs["order"]:
-                pieces.append(states[d][rows[0]:rows[-1] + 1].to(dev))
-            out[t] = torch.cat(pieces)
+            buf = self._ws("ks_digits_all", (tabs["total_rows"], N), t)
+            for owner, first, count, row0, nrows, src_row in groups:
+                buf[row0:row0 + nrows].copy_(states[owner][src_row:src_row + nrows], non_blocking=True)
+            out[t] = (buf, [(None, 0, nparts)])
         return out
 
     def create_switcher(self, a: list[torch.Tensor], ksk: data_struct, level, exit_ntt=False, addends=None,
@@ -891,8 +902,8 @@ class ckks_engine(EvaluatorOps):
             gal = None if galois is None else (galois[0], self._vec("_2q", d, level, False) if galois[1] else None)
             self.backend.ks_digits(src, st, nparts, desc, tab, self._consts(d, level, False), galois=gal)
             states[d] = st
-        # 2. digit gather
-        digits = self._gather_digits(states, level, tabs)
+        # 2. digit exchange: asynchronous, one message per run of digits with the same owner
+        digits = self._exchange_digits(states, level, tabs)
 
         nparts = len(tabs["order"])
         c0, c1 = [], []
@@ -904,14 +915,29 @@ class ckks_engine(EvaluatorOps):
             s = self._ws("ks_sum", (2, rows, N), d)
             key, tw, itw = packs[loc0.index(d)], self._tw(d, level, True), self._tw(d, level, True, True)
             ninv = self._vec("Ninv", d, level, True)
-            if logN >= self.backend.fused_ks_min_logN:
+            dig, ready = digits[d]
+            fused = logN >= self.backend.fused_ks_min_logN
+            if fused and len(ready) > 1 and hasattr(self.backend, "ks_fwd"):
+                # 3. per exchange group, as it arrives: extend + forward NTT of its digits (the next groups are
+                # still on the wire); 4. once all are in: key inner product over all digits + inverse NTT
+                for handle, first, count in ready:
+                    if handle is not None:
+                        handle.wait()
+                    self.backend.ks_fwd(dig, first, count, rows, logN, desc, E, Ed, ext, tw, cs)
+                self.backend.ks_tail(nparts, rows, logN, key, tabs["first_part"], self.ntt.starts[level][d], ext, s, itw,
+                                     ninv, cs)
+                ready = []
+            for handle, _, _ in ready:
+                if handle is not None:
+                    handle.wait()
+            if fused and ready:
                 # 3+4. fused core: extend + NTT + key inner product + inverse NTT, the extended digits never
                 # leave the chip in coefficient form
-                self.backend.ks_core(digits[d], nparts, rows, logN, desc, E, Ed, key, tabs["first_part"],
+                self.backend.ks_core(dig, nparts, rows, logN, desc, E, Ed, key, tabs["first_part"],
                                      self.ntt.starts[level][d], ext, s, tw, itw, ninv, cs)
-            else:
+            elif not fused:
                 # 3. extend every digit to this device's rows, forward NTT
-                self.backend.ks_extend(digits[d], ext, nparts, rows, desc, E, cs)
+                self.backend.ks_extend(dig, ext, nparts, rows, desc, E, cs)
                 self.backend.ntt(ext, nparts, rows, logN, tw, None, cs, relaxed=True)
                 # 4. inner product with the key (streams the key once), inverse NTT
                 self.backend.ks_inner(ext, key, tabs["first_part"], self.ntt.starts[level][d], s[0], s[1], nparts, rows, cs)

@@ -1,10 +1,21 @@
 """Collectives used by the limb-sharded engine: one process per GPU, torch.distributed underneath.
 
 On MI355X the backend is "nccl" (= RCCL) and the payloads travel over xGMI; the CPU test-suite runs the
-same code over "gloo".  The path has exactly two exchange steps: a broadcast of the
-rescaled-away limb row (2 x N words) and an all-gather of the key-switch digits (<= ceil(limbs/world)
-rows per rank).  The reference stages both through pinned host memory
-(src/liberate/fhe/ckks_engine.py:778-810, 999-1011).
+same code over "gloo".  The path has exactly two exchange steps, both IN PLACE on buffers the
+engine allocates once per level (`broadcast_into`):
+
+  * rescale: the dropped limb's two rows (2 x N words) from their owner to every rank;
+  * key switch: every Garner digit from its owner to every rank, ONE collective per run of digits with the same
+    owner, each straight into its rows of the storage-order digit buffer — shards of unequal height travel
+    unpadded, nothing is concatenated or re-indexed afterwards.  The collectives are issued asynchronously, in
+    consumption order, before any extension starts; the engine waits on a group's handle only when it launches
+    that group's extension + NTT (lf_ks_fwd), so group g + 1 is on the wire while the kernels of group g run.
+    With RCCL the wait is a stream dependency (the communicator's stream -> the compute stream), not a host
+    block.  xGMI is point to point: a digit of 4 limbs at gold is 2 MiB = ~15 us on one 153 GB/s link, and the
+    owners of consecutive groups are different GPUs, so consecutive broadcasts leave over different links.
+
+The reference stages both exchanges through pinned host memory (src/liberate/fhe/ckks_engine.py:778-810,
+999-1011) and starts extending only when every digit has landed on every GPU.
 """
 from __future__ import annotations
 
@@ -34,6 +45,13 @@ class DistComm:
             tensor = tensor.contiguous()
         dist.broadcast(tensor, src=self._global(src), group=self.group)
         return tensor
+
+    def broadcast_into(self, buf, src, async_op=False):
+        """In-place broadcast of the preallocated, contiguous `buf` (payload on group rank `src`, destination
+        elsewhere).  async_op: returns the work handle; `.wait()` orders the caller's current stream after it."""
+        if not buf.is_contiguous():
+            raise ValueError("broadcast_into needs a contiguous buffer (a row range of a [rows, N] tensor is)")
+        return dist.broadcast(buf, src=self._global(src), group=self.group, async_op=async_op)
 
     def all_gather(self, tensor):
         out = [torch.empty_like(tensor) for _ in range(self.world_size)]

@@ -76,8 +76,8 @@ def key_switch_key(engine, seed: int, origin: str = "key switch key", ds_type=No
                              level=0, hash=engine.hash, version=engine.version))
     out = ds_type(data=parts, include_special=True, ntt_state=True, montgomery_state=True, origin=origin,
                   level=0, hash=engine.hash, version=engine.version)
-    if hasattr(engine, "_key_packs"):
-        engine._key_packs[id(out.data)] = (out.data, packs)
+    if hasattr(engine, "_remember_pack"):
+        engine._remember_pack(out, packs, own=True)   # the parts are views of the packs
     return out
 
 

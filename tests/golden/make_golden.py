@@ -30,6 +30,10 @@ CONFIGS = {
     "bronze": dict(logN=14, num_special_primes=1),
     "silver": dict(logN=15, num_special_primes=2),
     "gold": dict(logN=16, num_special_primes=4),
+    "platinum": dict(logN=17, num_special_primes=6),
+    # other word widths of the scale primes: 30-bit (fp64 class, far below 2^41) and 45-bit (integer class: >= 2^41)
+    "sb30": dict(logN=13, scale_bits=30, num_scales=6, num_special_primes=2, is_secured=False),
+    "sb45": dict(logN=13, scale_bits=45, num_scales=6, num_special_primes=2, is_secured=False),
 }
 
 
@@ -60,7 +64,7 @@ def run(name, params, n_dev=1):
     rec["ops"]["rotate_single(a,rotk)"] = digest(eng.rotate_single(a, rotk))
     rec["ops"]["rotate_single(cc_mult,rotk)"] = digest(eng.rotate_single(prod, rotk))
     rec["ops"]["cc_add(a,b)"] = digest(eng.cc_add(a, b))
-    if name != "gold":
+    if name not in ("gold", "platinum"):
         rec["ops"]["cc_mult(prod,prod,evk)"] = digest(eng.cc_mult(prod, prod, evk))
     print(f"{name} x{n_dev}: {time.time() - t0:.1f} s", flush=True)
     return rec
@@ -102,6 +106,111 @@ def run_evaluator(params, n_dev):
     return rec
 
 
+# ---- key generation, encrypt / decrypt, encode / decode -------------------------
+# Randomness is injected: both engines draw from tests.helpers.SeededCsprng (numpy PCG64) re-seeded at the same
+# points, so every integer tensor below is reproducible bit for bit on the GPU box without the reference.
+KEYGEN_SEED = 777
+PT_SEED = 4242
+
+
+def reseed(eng, seed):
+    from tests.helpers import SeededCsprng
+    eng.rng = SeededCsprng(eng.ctx.N, [len(di) for di in eng.ntt.p.d], max(eng.ntt.num_special_primes, 2),
+                           devices=list(eng.ntt.devices), seed=seed)
+
+
+def digest_any(x):
+    """Digest of a ciphertext / public key (tuple of tensor lists), a secret key (tensor list) or a key-switch key
+    (list of parts, each a (b, a) pair)."""
+    if hasattr(x, "data"):
+        x = x.data
+    if isinstance(x, torch.Tensor):
+        return hashlib.sha256(np.ascontiguousarray(x.cpu().numpy()).tobytes()).hexdigest()
+    if hasattr(x, "_fields"):
+        return digest_any(x.data)
+    return [digest_any(y) for y in x]
+
+
+def integer_plaintext(N, seed=PT_SEED):
+    """A small-integer "encoded message" (what encode would hand to encrypt), from splitmix64."""
+    return (synth.splitmix64(seed, N) % np.uint64(1 << 30)).astype(np.int64) - (1 << 29)
+
+
+def keygen_sequence(eng):
+    """The operations the fixture records, in order; used by make_golden (reference engine) and by the tests
+    (this package's engine) — the random draws line up because the call order is the same."""
+    out = {}
+    reseed(eng, KEYGEN_SEED)
+    sk = eng.create_secret_key()
+    out["create_secret_key"] = digest_any(sk)
+    pk = eng.create_public_key(sk)
+    out["create_public_key(sk)"] = digest_any(pk)
+    evk = eng.create_evk(sk)
+    out["create_evk(sk)"] = digest_any(evk)
+    rotk = eng.create_rotation_key(sk, 5)
+    out["create_rotation_key(sk,5)"] = digest_any(rotk)
+    conjk = eng.create_conjugation_key(sk)
+    out["create_conjugation_key(sk)"] = digest_any(conjk)
+    crs = eng.generate_rotation_crs(rotk)
+    ksk = eng.create_key_switching_key(sk, sk, a=crs)
+    out["create_key_switching_key(sk,sk,a=crs(rotk))"] = digest_any(ksk)
+    pt = [torch.from_numpy(integer_plaintext(eng.ctx.N)).to(eng.ntt.devices[d])
+          for d in (getattr(eng, "local_ids", None) or range(eng.ntt.num_devices))]
+    ct = eng.encrypt(pt, pk)
+    out["encrypt(pt,pk)"] = digest_any(ct)
+    ct3 = eng.encrypt(pt, pk, level=2)
+    out["encrypt(pt,pk,level=2)"] = digest_any(ct3)
+    dec = eng.decrypt(ct, sk)
+    out["decrypt(ct,sk)"] = digest_any(dec)
+    out["decrypt(ct,sk).head"] = [int(v) for v in dec[0].flatten()[:8].cpu()]
+    prod = eng.cc_mult(ct, ct, evk)
+    out["decrypt(cc_mult(ct,ct,evk),sk)"] = digest_any(eng.decrypt(prod, sk))
+    out["decrypt(rotate_single(ct,rotk),sk)"] = digest_any(eng.decrypt(eng.rotate_single(ct, rotk), sk))
+    out["decrypt(conjugate(ct,conjk),sk)"] = digest_any(eng.decrypt(eng.conjugate(ct, conjk), sk))
+    trip = eng.cc_mult(ct, ct, evk, relin=False)
+    out["decrypt(triplet,sk)"] = digest_any(eng.decrypt(trip, sk))
+    return out
+
+
+def run_keygen(params, n_dev):
+    eng = rd.reference_engine(n_dev, **params)
+    return {"params": params, "n_devices": n_dev, "seed": KEYGEN_SEED, "pt_seed": PT_SEED, "ops": keygen_sequence(eng)}
+
+
+def message(N, seed):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return g.uniform(-1, 1, N // 2) + 1j * g.uniform(-1, 1, N // 2)
+
+
+def run_encdec(params, keep):
+    """encode (with injected stochastic rounding), decode and the decrypt -> decode tail on a fixed message.
+    `keep` = how many leading entries of each vector the fixture stores (all of them for the small ring)."""
+    eng = rd.reference_engine(1, **params)
+    N = eng.ctx.N
+    m = message(N, 31337)
+    rec = {"params": params, "message_seed": 31337, "rng_seed": 99, "keep": keep}
+    for level in (0, 2):
+        reseed(eng, 99)
+        pt = eng.encode(m, level=level)[0]
+        back = eng.decode([pt], level=level)
+        rec[f"encode(level={level})"] = [int(v) for v in pt[:keep]]
+        rec[f"decode(encode,level={level})"] = [[float(v.real), float(v.imag)] for v in back[:keep]]
+    # decode of an exact integer plaintext: the only fp64 step is the FFT
+    ints = integer_plaintext(N)
+    dec = eng.decode([torch.from_numpy(ints)], level=0)
+    rec["decode(integer_plaintext)"] = [[float(v.real), float(v.imag)] for v in dec[:keep]]
+    # encorypt -> decrode with the bias guard (DC term split off and re-added through CRT, eng.py:1472-1681)
+    reseed(eng, KEYGEN_SEED)
+    sk = eng.create_secret_key()
+    pk = eng.create_public_key(sk)
+    reseed(eng, 5150)
+    ct = eng.encorypt(m + 3.0, pk)
+    out = eng.decrode(ct, sk)
+    rec["decrode(encorypt(m+3))"] = [[float(v.real), float(v.imag)] for v in out[:keep]]
+    rec["decrode_max_err"] = float(np.abs(out - (m + 3.0)).max())
+    return rec
+
+
 def write_pickle_fixture(params):
     """A ciphertext file written by the REFERENCE's save() (host form, eng.py:2001-2015): data, not code."""
     import pickle
@@ -139,6 +248,13 @@ if __name__ == "__main__":
     which = sys.argv[1:] or list(CONFIGS)
     path = os.path.join(HERE, "engine_digests.json")
     out = json.load(open(path)) if os.path.exists(path) else {}
+    if "keygen" in which:
+        which.remove("keygen")
+        kpath = os.path.join(HERE, "keygen_encdec.json")
+        k = {"keygen_small": run_keygen(CONFIGS["small"], 1), "keygen_small_x2": run_keygen(CONFIGS["small"], 2),
+             "keygen_bronze": run_keygen(CONFIGS["bronze"], 1),
+             "encdec_small": run_encdec(CONFIGS["small"], 1024), "encdec_silver": run_encdec(CONFIGS["silver"], 128)}
+        json.dump(k, open(kpath, "w"), indent=1)
     for name in which:
         out[name] = run(name, CONFIGS[name])
         if name == "small":

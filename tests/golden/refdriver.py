@@ -25,6 +25,8 @@ import torch
 
 REFERENCE_SRC = "/root/reference/src"
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
 
 
 def reference_available() -> bool:
@@ -39,48 +41,7 @@ def _make_ntt_cuda_standin():
     return make_ops("liberate.ntt.ntt_cuda")
 
 
-class SeededCsprng:
-    """Deterministic replacement for the reference's Csprng (csprng.py:18-323): same method names,
-    shapes and value ranges; randomness from numpy's PCG64 so fixtures are reproducible."""
-
-    def __init__(self, N, C, repeats, devices=None, seed=12345):
-        self.N, self.C, self.num_repeating_channels = N, list(C), repeats
-        self.devices = devices or ["cpu"]
-        self.num_devices = len(self.devices)
-        self.g = np.random.Generator(np.random.PCG64(seed))
-
-    def _t(self, x):
-        return torch.from_numpy(np.ascontiguousarray(x).astype(np.int64))
-
-    def randint(self, amax=3, shift=0, repeats=1):
-        # amax scalar -> [repeats, N] shared by every device; amax per-device list of per-row moduli
-        # -> [C_dev + repeats, N] with the trailing `repeats` rows identical on every device.
-        if not isinstance(amax, (list, tuple)):
-            x = self.g.integers(0, amax, size=(max(repeats, 1), self.N)) + shift
-            return [self._t(x).clone() for _ in range(self.num_devices)]
-        out = []
-        rep_rows = None
-        for dev, q in enumerate(amax):
-            q = list(q)
-            n_rep = repeats
-            body = q[: len(q) - n_rep] if n_rep else q
-            rows = [self.g.integers(0, qi, size=self.N) + shift for qi in body]
-            if n_rep:
-                if rep_rows is None:
-                    rep_rows = [self.g.integers(0, qi, size=self.N) + shift for qi in q[len(q) - n_rep:]]
-                rows += rep_rows
-            out.append(self._t(np.stack(rows)))
-        return out
-
-    def discrete_gaussian(self, non_repeats=0, repeats=1, sigma=3.2):
-        x = np.rint(self.g.normal(0.0, 3.2, size=(max(repeats, 1), self.N)))
-        return [self._t(x).clone() for _ in range(self.num_devices)]
-
-    def randround(self, coef):
-        c = coef.numpy() if isinstance(coef, torch.Tensor) else np.asarray(coef)
-        fl = np.floor(c)
-        r = fl + (self.g.random(c.shape) < (c - fl))
-        return torch.from_numpy(r.astype(np.int64))
+from tests.helpers import SeededCsprng  # noqa: E402  (portable: the GPU-box tests use the same class)
 
 
 _state = {}

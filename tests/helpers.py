@@ -81,3 +81,52 @@ def pick_primes(logN, n40=2, n60=1):
 
 def sha(arr) -> str:
     return hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()
+
+
+class SeededCsprng:
+    """Deterministic stand-in for the engines' Csprng (reference csprng.py:18-323): same method names, shapes and
+    value ranges; randomness from numpy's PCG64, so the reference engine in the build container and this package's
+    engine on the GPU box draw IDENTICAL tensors from one seed (the reference's own Csprng cannot be seeded).
+    `devices`: where the drawn tensors are placed (one entry per logical device)."""
+
+    def __init__(self, N, C, repeats, devices=None, seed=12345, local_ids=None, **_):
+        import torch
+        self.torch = torch
+        self.N, self.C, self.num_repeating_channels = N, list(C), repeats
+        self.devices = devices or ["cpu"]
+        self.num_devices = len(self.devices)
+        self.g = np.random.Generator(np.random.PCG64(seed))
+
+    def _t(self, x, dev=0):
+        return self.torch.from_numpy(np.ascontiguousarray(x).astype(np.int64)).to(self.devices[dev])
+
+    def randint(self, amax=3, shift=0, repeats=1):
+        # amax scalar -> [repeats, N] shared by every device; amax per-device list of per-row moduli
+        # -> [C_dev + repeats, N] with the trailing `repeats` rows identical on every device.
+        if not isinstance(amax, (list, tuple)):
+            x = self.g.integers(0, amax, size=(max(repeats, 1), self.N)) + shift
+            return [self._t(x, d) for d in range(self.num_devices)]
+        out = []
+        rep_rows = None
+        for dev, q in enumerate(amax):
+            q = list(q)
+            n_rep = repeats
+            body = q[: len(q) - n_rep] if n_rep else q
+            rows = [self.g.integers(0, qi, size=self.N) + shift for qi in body]
+            if n_rep:
+                if rep_rows is None:
+                    rep_rows = [self.g.integers(0, qi, size=self.N) + shift for qi in q[len(q) - n_rep:]]
+                rows += rep_rows
+            out.append(self._t(np.stack(rows), dev))
+        return out
+
+    def discrete_gaussian(self, non_repeats=0, repeats=1, sigma=3.2):
+        x = np.rint(self.g.normal(0.0, 3.2, size=(max(repeats, 1), self.N)))
+        return [self._t(x, d) for d in range(self.num_devices)]
+
+    def randround(self, coef):
+        dev = coef.device if isinstance(coef, self.torch.Tensor) else "cpu"
+        c = coef.cpu().numpy() if isinstance(coef, self.torch.Tensor) else np.asarray(coef)
+        fl = np.floor(c)
+        r = fl + (self.g.random(c.shape) < (c - fl))
+        return self.torch.from_numpy(r.astype(np.int64)).to(dev)

@@ -310,6 +310,17 @@ class OracleBackend:
         self.ks_inner(tmp, key, first_part, row_off, s[0], s[1], nparts, rows, c)
         self.intt(s, 2, rows, logN, ipsi, Ninv, 2, c)
 
+    def ks_fwd(self, state, first, count, rows, logN, desc, E, Ed, tmp, psi, c):
+        """Digits first .. first + count - 1 only: extend + NTT into tmp[first:first + count]."""
+        D = desc.reshape(-1, 3)[first:first + count].contiguous()
+        sub = tmp[first:first + count]
+        self.ks_extend(state, sub, count, rows, D, E, c)
+        self.ntt(sub, count, rows, logN, psi, None, c)
+
+    def ks_tail(self, nparts, rows, logN, key, first_part, row_off, tmp, s, ipsi, Ninv, c):
+        self.ks_inner(tmp, key, first_part, row_off, s[0], s[1], nparts, rows, c)
+        self.intt(s, 2, rows, logN, ipsi, Ninv, 2, c)
+
     ks_batch_sizes = (4, 2)
 
     def ks_digits_batch(self, srcs, states, nparts, desc, tab, c, galois=None):

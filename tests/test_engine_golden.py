@@ -47,7 +47,7 @@ def check_config(engine, rec):
         assert digest(engine.cc_mult(prod, prod, evk)) == ops["cc_mult(prod,prod,evk)"]
 
 
-@pytest.mark.parametrize("name", ["small", "small_x2", "bronze", "silver"])
+@pytest.mark.parametrize("name", ["small", "small_x2", "bronze", "silver", "sb30", "sb45"])
 def test_checker_engine_reproduces_reference_digests(name):
     from liberate_fhe_amd.fhe import ckks_engine
     from tests.oracle_backend import OracleBackend
@@ -57,12 +57,32 @@ def test_checker_engine_reproduces_reference_digests(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["small", "small_x2", "bronze", "silver", "gold"])
+@pytest.mark.parametrize("name", ["small", "small_x2", "bronze", "silver", "gold", "platinum", "sb30", "sb45"])
 def test_hip_engine_reproduces_reference_digests(name):
+    """All four presets (platinum: logN 17, 6 special primes, a five-stage strided pass — the LDS-tiled fallback
+    of the column kernels) and the other scale-prime widths: sb30 = 30-bit scale primes (fp64 class), sb45 =
+    45-bit scale primes (>= 2^41: the integer class for every limb)."""
     from liberate_fhe_amd.fhe import ckks_engine
     rec = GOLD[name]
     eng = ckks_engine(devices=["cuda:0"] * rec["n_devices"], **rec["params"])
     check_config(eng, rec)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small", "silver"])
+def test_hip_public_relinearize_of_an_exact_triplet(name):
+    """cc_mult(relin=False) hands out the reference's exact NTT / Montgomery / lazy triplet (not the internal
+    plain-domain one); relinearize() of it must land on the same ciphertext as the fused cc_mult — the reference
+    engine's digest."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    rec = GOLD[name]
+    eng = ckks_engine(devices=["cuda:0"], **rec["params"])
+    s = rec["seeds"]
+    a, b = synth.ciphertext(eng, s["ct_a"], 0), synth.ciphertext(eng, s["ct_b"], 0)
+    evk = synth.key_switch_key(eng, s["evk"])
+    trip = eng.cc_mult(a, b, evk, relin=False)
+    assert trip.origin == "cipher text triplet" and trip.ntt_state and trip.montgomery_state
+    assert digest(eng.relinearize(trip, evk)) == rec["ops"]["cc_mult(a,b,evk)"]
 
 
 @pytest.mark.gpu

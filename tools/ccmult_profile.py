@@ -1,4 +1,8 @@
-"""Kernel-level timing of one engine op (development aid): python tools/ccmult_profile.py gold cc_mult"""
+"""Kernel-level timing of one engine op (development aid): python tools/ccmult_profile.py gold cc_mult [--mark]
+
+--mark: bracket the timed loop with two tiny marker kernels (torch fill of a 1-element tensor with 12345 / 54321 is
+not distinguishable in a trace, so the markers are lf_reduce_2q launches on a [1, 2] tensor — `ew_kernel<...>` with
+grid 1), so that tools/summarize_engine_ops.py can separate steady-state dispatches from set-up."""
 import sys, os, warnings
 sys.path.insert(0, os.environ.get("LF_PKG_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # LF_PKG_ROOT: A/B another checkout
 warnings.filterwarnings("ignore")
@@ -7,6 +11,7 @@ from liberate_fhe_amd.fhe import ckks_engine, presets
 from liberate_fhe_amd.utils import synth
 name = sys.argv[1] if len(sys.argv) > 1 else "gold"
 op = sys.argv[2] if len(sys.argv) > 2 else "cc_mult"
+mark = "--mark" in sys.argv
 eng = ckks_engine(**{**presets.params[name], "devices": ["cuda:0"]})
 a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
 evk = synth.key_switch_key(eng, 5)
@@ -14,9 +19,22 @@ rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
 fn = (lambda: eng.cc_mult(a, b, evk)) if op == "cc_mult" else (lambda: eng.rotate_single(a, rotk))
 for _ in range(3): fn()
 torch.cuda.synchronize()
+
+
+def marker():
+    from liberate_fhe_amd._native import lib
+    t = torch.zeros((1, 2), dtype=torch.int64, device="cuda:0")
+    q2 = torch.full((1,), 10, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    lib.lf_make_signed(t.data_ptr(), 1, 2, q2.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+
+
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 n = 10
+if mark: marker()
 e0.record()
 for _ in range(n): fn()
 e1.record(); torch.cuda.synchronize()
+if mark: marker()
 print(f"{name} {op}: {e0.elapsed_time(e1)/n*1e3:.1f} us/op  {n/e0.elapsed_time(e1)*1e3:.1f} ops/s")

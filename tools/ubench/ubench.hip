@@ -11,11 +11,12 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
+#define CLB : "vcc", "s10", "s11"
 #define REP8_32(INS) \
-  asm volatile(INS : "+v"(r0) : "v"(b), "v"(c)); asm volatile(INS : "+v"(r1) : "v"(b), "v"(c)); \
-  asm volatile(INS : "+v"(r2) : "v"(b), "v"(c)); asm volatile(INS : "+v"(r3) : "v"(b), "v"(c)); \
-  asm volatile(INS : "+v"(r4) : "v"(b), "v"(c)); asm volatile(INS : "+v"(r5) : "v"(b), "v"(c)); \
-  asm volatile(INS : "+v"(r6) : "v"(b), "v"(c)); asm volatile(INS : "+v"(r7) : "v"(b), "v"(c));
+  asm volatile(INS : "+v"(r0) : "v"(b), "v"(c) CLB); asm volatile(INS : "+v"(r1) : "v"(b), "v"(c) CLB); \
+  asm volatile(INS : "+v"(r2) : "v"(b), "v"(c) CLB); asm volatile(INS : "+v"(r3) : "v"(b), "v"(c) CLB); \
+  asm volatile(INS : "+v"(r4) : "v"(b), "v"(c) CLB); asm volatile(INS : "+v"(r5) : "v"(b), "v"(c) CLB); \
+  asm volatile(INS : "+v"(r6) : "v"(b), "v"(c) CLB); asm volatile(INS : "+v"(r7) : "v"(b), "v"(c) CLB);
 
 #define KERNEL32(NAME, INS) \
 __global__ void __launch_bounds__(256) NAME(uint32_t* out, int iters) { \
@@ -71,6 +72,23 @@ KERNEL64D(k_fma_f64,     "v_fma_f64 %0, %0, %1, %2")
 KERNEL64D(k_mul_f64,     "v_mul_f64 %0, %0, %1")
 KERNEL64D(k_add_f64,     "v_add_f64 %0, %0, %1")
 KERNEL64D(k_rndne_f64,   "v_rndne_f64 %0, %0")
+KERNEL64D(k_floor_f64,   "v_floor_f64 %0, %0")
+KERNEL64D(k_trunc_f64,   "v_trunc_f64 %0, %0")
+KERNEL64D(k_ldexp_f64,   "v_ldexp_f64 %0, %0, 1")
+KERNEL64D(k_addclamp_f64,"v_add_f64 %0, -%0, %1 clamp")
+KERNEL64D(k_max_f64,     "v_max_f64 %0, %0, %1")
+KERNEL32(k_cndmask_s,    "v_cndmask_b32_e64 %0, %0, %1, s[10:11]")
+KERNEL32(k_cmp_cnd,      "v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc")
+KERNEL32(k_cmp_u32,      "v_cmp_lt_u32 vcc, %0, %1")
+KERNEL32(k_cmp_s,        "v_cmp_lt_u32_e64 s[10:11], %0, %1")
+KERNEL32(k_min_u32,      "v_min_u32 %0, %0, %1")
+KERNEL32(k_ashr,         "v_ashrrev_i32 %0, 31, %0")
+KERNEL32(k_addco,        "v_add_co_u32 %0, vcc, %0, %1\n\tv_addc_co_u32 %0, vcc, %0, %2, vcc")
+KERNEL32(k_and_or,       "v_and_or_b32 %0, %0, %1, %2")
+KERNEL32(k_xor,          "v_xor_b32 %0, %0, %1")
+KERNEL32(k_bfi,          "v_bfi_b32 %0, %1, %2, %0")
+KERNEL32(k_cvt_f64_u32,  "v_cvt_f32_u32 %0, %0")
+KERNEL64U(k_cmp_u64,     "v_cmp_lt_u64 vcc, %0, %1")
 KERNEL64U(k_lshl_add_u64,"v_lshl_add_u64 %0, %0, 1, %1")
 KERNEL64U(k_lshlrev_b64, "v_lshlrev_b64 %0, 1, %0")
 KERNEL64U(k_lshrrev_b64, "v_lshrrev_b64 %0, 1, %0")
@@ -139,6 +157,13 @@ int main() {
     {"v_mul_hi_u32_u24", k_mul_hi_u24, 16}, {"v_lshl_or_b32", k_lshl_or, 16}, {"v_cndmask_b32", k_cndmask, 16},
     {"v_mad_u64_u32", k_mad_u64_u32, 16}, {"v_mad_i64_i32", k_mad_i64_i32, 16},
     {"v_fma_f64", k_fma_f64, 16}, {"v_mul_f64", k_mul_f64, 16}, {"v_add_f64", k_add_f64, 16}, {"v_rndne_f64", k_rndne_f64, 16},
+    {"v_floor_f64", k_floor_f64, 16}, {"v_trunc_f64", k_trunc_f64, 16}, {"v_ldexp_f64", k_ldexp_f64, 16},
+    {"v_add_f64 clamp", k_addclamp_f64, 16}, {"v_max_f64", k_max_f64, 16},
+    {"v_cndmask_b32 (sgpr mask)", k_cndmask_s, 16}, {"v_cmp_lt_u32+v_cndmask (pair)", k_cmp_cnd, 16},
+    {"v_cmp_lt_u32 vcc", k_cmp_u32, 16}, {"v_cmp_lt_u32 sgpr", k_cmp_s, 16}, {"v_min_u32", k_min_u32, 16},
+    {"v_ashrrev_i32", k_ashr, 16}, {"v_add_co+v_addc (pair)", k_addco, 16}, {"v_and_or_b32", k_and_or, 16},
+    {"v_xor_b32", k_xor, 16}, {"v_bfi_b32", k_bfi, 16}, {"v_cvt_f32_u32", k_cvt_f64_u32, 16},
+    {"v_cmp_lt_u64", k_cmp_u64, 16},
     {"v_lshl_add_u64", k_lshl_add_u64, 16}, {"v_lshlrev_b64", k_lshlrev_b64, 16}, {"v_lshrrev_b64", k_lshrrev_b64, 16},
     {"mm62 (int closed form)", k_mm62, 4}, {"mulmod_dp (fp64, q<2^41)", k_mm_dp, 4},
   };
