@@ -18,7 +18,7 @@ for preset in ("silver", "gold"):
         if not os.path.exists(db):
             continue
         con = sqlite3.connect(db)
-        rows = con.execute("select name, start, end, grid_size_x from kernels order by start").fetchall()
+        rows = con.execute("select name, start, end, grid_x from kernels order by start").fetchall()
         marks = [i for i, r in enumerate(rows) if "ew_kernel" in r[0] and r[3] <= 256]
         if len(marks) < 2:
             lines.append(f"## {preset} {op}: markers not found ({len(marks)})")
