@@ -305,13 +305,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # development aid (never set by the driver): LF_BENCH_REHEARSE=1 runs the N > 1 code path on a ONE-GPU box —
+    # every rank on cuda:0, collectives over gloo (RCCL refuses two ranks on one device).  Numbers are meaningless.
+    rehearse = world > 1 and os.environ.get("LF_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")   # a failed collective raises instead of blocking
-        dist.init_process_group("nccl", device_id=torch.device(dev), timeout=datetime.timedelta(seconds=900))
+        if rehearse:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev), timeout=datetime.timedelta(seconds=900))
 
     import __graft_entry__ as g
     if rank == 0:
@@ -426,6 +434,8 @@ def main():
     extra = {"limb_ntt_per_s": value * L_LIMBS, "device_ms_per_step": dev_ms,
              "whole_step_frac_of_achievable_6300": 16 * N * L_LIMBS * B / (dev_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS}
     result["extra"] = extra
+    if rehearse:
+        extra["REHEARSAL"] = "all ranks on cuda:0 over gloo: not a measurement"
     if rank == 0 and world == 1 and not args.no_extra:
         rates, roof = engine_rates(dev, quick=False)
         extra.update(rates)

@@ -72,8 +72,8 @@ SideStream *side_stream(int device) {
     return &s;
 }
 
-// polynomials per launch group: the whole batch (splitting a batch so that its two passes meet in the Infinity
-// Cache was measured on MI355X and only adds launch tails)
+// polynomials per launch group of the inverse transform: the whole batch (splitting a batch so that its two passes
+// meet in the Infinity Cache was measured on MI355X and only adds launch tails)
 int chunk_polys(int batch, int, int, bool) { return batch; }
 
 template <bool DP>
@@ -217,17 +217,36 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
     classify(rows, q_host, psi_dp, dp, in);
     hipStream_t st = (hipStream_t)stream;
     const bool mixed = rsrc || (dp.n && in.n && mixed_enabled());   // both classes in one launch per pass
-    SideStream *side = (dp.n && in.n && !mixed) ? side_stream(device) : nullptr;
-    hipStream_t st_int = side ? side->stream : st;
+    // Two-pass transforms of a large batch run as LF_NTT_PIPE chunks alternating between the caller's stream and a
+    // side stream: the column pass of one chunk (HBM-bound, few VALU cycles) shares the chip with the tiled pass of
+    // its neighbour (VALU-issue-bound, HBM half idle) instead of the two running back to back.  Both passes of a
+    // chunk stay on one stream, so the dependency needs no event; fork / join events fence the side stream.
+#ifndef LF_NTT_PIPE
+#define LF_NTT_PIPE 1
+#endif
+#ifndef LF_NTT_PIPE_MIN_POLYS
+#define LF_NTT_PIPE_MIN_POLYS 16   // polynomials per chunk below which launch tails eat the overlap
+#endif
+    int nchunks = 1;
+    if (LF_NTT_PIPE > 1 && S1 > 0 && !rsrc && !only_pass && batch >= 2 * LF_NTT_PIPE_MIN_POLYS) {
+        nchunks = LF_NTT_PIPE;
+        while (nchunks > 1 && batch / nchunks < LF_NTT_PIPE_MIN_POLYS) --nchunks;
+    }
+    SideStream *side = nchunks > 1 ? side_stream(device) : nullptr;
     if (side) {
         (void)hipEventRecord(side->fork, st);
         (void)hipStreamWaitEvent(side->stream, side->fork, 0);
+    } else {
+        nchunks = 1;
     }
+    hipStream_t st_main = st;
     // only_pass = 1 | 2 (lf_ntt_pass, measurement only): launch only the column pass / only the tiled pass
-    const int chunk = rsrc ? batch : chunk_polys(batch, rows, logN, S1 > 0);   // the rescale source indexes whole-batch polynomials
-    for (int b0 = 0; b0 < batch; b0 += chunk) {
+    const int chunk = (batch + nchunks - 1) / nchunks;
+    for (int b0 = 0, ci = 0; b0 < batch; b0 += chunk, ++ci) {
         const int nb = batch - b0 < chunk ? batch - b0 : chunk;
         i64 *base = (i64 *)a + ((i64)b0 * rows << logN);
+        st = (side && (ci & 1)) ? side->stream : st_main;
+        hipStream_t st_int = st;
         const unsigned per_row = (unsigned)nb << (logN - tl);
         for (int pass = (S1 > 0 ? 0 : 1); pass < 2; ++pass) {
             if (only_pass && pass + 1 != only_pass) continue;   // measurement only: time one pass kernel by itself
@@ -267,7 +286,7 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
     }
     if (side) {
         (void)hipEventRecord(side->join, side->stream);
-        (void)hipStreamWaitEvent(st, side->join, 0);
+        (void)hipStreamWaitEvent(st_main, side->join, 0);
     }
     return (int)hipGetLastError();
 }

@@ -645,19 +645,22 @@ class ckks_engine(EvaluatorOps):
         # the dropped limb's row of every polynomial, on every local target device
         rows0 = []                                   # rows0[k][comp] = {device: [N] tensor}
         multi = self.comm is not None and self.comm.world_size > 1
-        for k, ct in enumerate(cts):
-            if multi:
-                # both components' rows in one message, in place on a buffer kept per (level, operand slot)
-                me = self.local_ids[0]
-                buf = self._ws(("rescale_rows", k), (2, N), me)
-                if owner == me:
-                    i = loc_before.index(owner)
-                    buf[0].copy_(ct.data[0][i][0])
-                    buf[1].copy_(ct.data[1][i][0])
-                self.comm.broadcast_into(buf, owner)
-                rows0.append([{d: buf[comp] for d in targets if d in self.local_ids} for comp in range(2)])
-            else:
+        if multi:
+            # the dropped limb's rows of ALL operands (cc_mult: both ciphertexts, both components) in ONE message, in
+            # place on a buffer kept per operand count
+            me = self.local_ids[0]
+            buf = self._ws("rescale_rows", (2 * len(cts), N), me)
+            if owner == me:
                 i = loc_before.index(owner)
+                for k, ct in enumerate(cts):
+                    buf[2 * k].copy_(ct.data[0][i][0])
+                    buf[2 * k + 1].copy_(ct.data[1][i][0])
+            self.comm.broadcast_into(buf, owner)
+            for k in range(len(cts)):
+                rows0.append([{d: buf[2 * k + comp] for d in targets if d in self.local_ids} for comp in range(2)])
+        else:
+            i = loc_before.index(owner)
+            for ct in cts:
                 rows0.append([self._share_rows(ct.data[comp][i][0], owner, targets, (N,)) for comp in range(2)])
         per_dev = {}
         for d in self._loc(nxt):
