@@ -92,14 +92,17 @@ int lf_mont_sub(const int64_t *a, const int64_t *b, int64_t *c, int rows, int64_
  * row runs the integer class.
  * flags: LF_NTT_RELAXED = the caller only needs the result modulo q (outputs are then canonical
  * residues instead of the reference's lazy representatives) — for fused internal use, never for the
- * drop-in ops. */
+ * drop-in ops.  A relaxed FORWARD transform accepts the reference's signed-lazy words (|a| < 2q); a relaxed
+ * INVERSE transform takes non-negative words below 2^52 (what lf_tensor / lf_ks_inner / the fused core write). */
 #define LF_NTT_RELAXED 1
 /* with LF_NTT_RELAXED: fp64-class limbs stay in the PLAIN domain — lf_ntt applies Rs to integer-class limbs
  * only, lf_intt (tail >= 2) multiplies fp64-class limbs by N^-1 instead of N^-1 R^-1.  Used by the fused
  * cc_mult, whose tensor product then needs one plain modular product per term (lf_tensor, plain = 1). */
 #define LF_NTT_PLAIN 2
 
-/* plain twiddles as doubles from the Montgomery-form compact table: out = reduce_q(redc(mont)). */
+/* plain twiddles as doubles from the Montgomery-form compact table: out = reduce_q(redc(mont)).  Entry 0 of every
+ * row (psi^0 = 1, which no butterfly stage reads) receives 1 / q_row instead: the fp64-class kernels take the
+ * reciprocal from there.  Tables handed to lf_ntt / lf_intt / lf_ks_* as psi_dp / ipsi_dp must come from here. */
 int lf_twiddle_dp(const int64_t *mont, double *out, int rows, int64_t N, const int64_t *ql, const int64_t *qh,
                   const int64_t *kl, const int64_t *kh, int device, void *stream);
 

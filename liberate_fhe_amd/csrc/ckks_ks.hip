@@ -73,9 +73,9 @@ __device__ __forceinline__ void ks_ext_body(i64 *sm, int b, const i64 *__restric
 
     Ctx c;
     c.m = load_mod(ql, qh, kl, kh, crow);
-    c.d = make_dp(c.m);
     c.tw_mont = psi_br + ((i64)crow << kg.logN);
     c.tw_dp = DP ? psi_dp + ((i64)crow << kg.logN) : nullptr;
+    c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
     c.relaxed = 1;
     c.inv_reduce = 0;
     // desc[p] = {row_start, alpha | wide << 8, e_off}; wide = the digit's words exceed 53 bits (a digit made of

@@ -367,8 +367,7 @@ template <class A, int LOGDL>
 struct StepTw {
     typename A::W w0[1], w1[2], w2[4];
     int i0;
-    __device__ __forceinline__ void load(const Ctx &c, int s, int E, int base) {
-        const int w = lf_tid();
+    __device__ __forceinline__ void load(const Ctx &c, int s, int E, int base, int w) {
         const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
         i0 = (1 << s) + ((base + p) >> (E - s));
         A::tw_group(c, i0, 1, w0);
@@ -392,8 +391,7 @@ __device__ __forceinline__ void fwd_regs8(typename A::T (&x)[8], const StepTw<A,
 }
 
 template <class A, int LOGDL>
-__device__ __forceinline__ void fwd_step8(typename A::T *sm, const StepTw<A, LOGDL> &tw, const Ctx &c) {
-    const int w = lf_tid();
+__device__ __forceinline__ void fwd_step8(typename A::T *sm, const StepTw<A, LOGDL> &tw, const Ctx &c, int w) {
     const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
     typename A::T x[8];
     typename A::T *sp = sm + PAD(p);   // LOGDL = 0: p = 8 w, the 8 words are consecutive (PAD(8 w + e) = 9 w + e)
@@ -447,8 +445,7 @@ template <class A, int LOGDL>
 struct StepTwInv {
     typename A::W w0[4], w1[2], w2[1];
     int il;
-    __device__ __forceinline__ void load(const Ctx &c, int s, int adj, int logN, int base) {
-        const int w = lf_tid();
+    __device__ __forceinline__ void load(const Ctx &c, int s, int adj, int logN, int base, int w) {
         const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
         il = (1 << (logN - s - 3)) + ((base + p) >> (s + 3 - adj));
         A::tw_group(c, il << 2, 4, w0);
@@ -472,8 +469,7 @@ __device__ __forceinline__ void inv_regs8(typename A::T (&x)[8], const StepTwInv
 }
 
 template <class A, int LOGDL>
-__device__ __forceinline__ void inv_step8(typename A::T *sm, const StepTwInv<A, LOGDL> &tw, const Ctx &c) {
-    const int w = lf_tid();
+__device__ __forceinline__ void inv_step8(typename A::T *sm, const StepTwInv<A, LOGDL> &tw, const Ctx &c, int w) {
     const int p = ((w >> LOGDL) << (LOGDL + 3)) | (w & ((1 << LOGDL) - 1));
     typename A::T x[8];
     typename A::T *sp = sm + PAD(p);
@@ -497,17 +493,17 @@ __device__ __forceinline__ void run_fwd_stages(typename A::T *sm, const PassGeom
         StepTw<A, 6> t6;
         StepTw<A, 3> t3;
         StepTw<A, 0> t0;
-        t9.load(c, s, E, base);
-        fwd_step8<A, 9>(sm, t9, c);
-        t6.load(c, s + 3, E, base);
+        t9.load(c, s, E, base, lf_tid());
+        fwd_step8<A, 9>(sm, t9, c, lf_tid());
+        t6.load(c, s + 3, E, base, lf_tid());
         lds_barrier();
-        fwd_step8<A, 6>(sm, t6, c);
-        t3.load(c, s + 6, E, base);
+        fwd_step8<A, 6>(sm, t6, c, lf_tid());
+        t3.load(c, s + 6, E, base, lf_tid());
         lds_barrier();
-        fwd_step8<A, 3>(sm, t3, c);
-        t0.load(c, s + 9, E, base);
+        fwd_step8<A, 3>(sm, t3, c, lf_tid());
+        t0.load(c, s + 9, E, base, lf_tid());
         lds_barrier();
-        fwd_step8<A, 0>(sm, t0, c);
+        fwd_step8<A, 0>(sm, t0, c, lf_tid());
         lds_barrier();
         return;
     }
@@ -553,17 +549,17 @@ __device__ __forceinline__ void run_inv_stages(typename A::T *sm, const PassGeom
         StepTwInv<A, 3> t3;
         StepTwInv<A, 6> t6;
         StepTwInv<A, 9> t9;
-        t0.load(c, s, adj, g.logN, base);
-        arm(3); inv_step8<A, 0>(sm, t0, cc); left -= 3;
-        t3.load(c, s + 3, adj, g.logN, base);
+        t0.load(c, s, adj, g.logN, base, lf_tid());
+        arm(3); inv_step8<A, 0>(sm, t0, cc, lf_tid()); left -= 3;
+        t3.load(c, s + 3, adj, g.logN, base, lf_tid());
         lds_barrier();
-        arm(3); inv_step8<A, 3>(sm, t3, cc); left -= 3;
-        t6.load(c, s + 6, adj, g.logN, base);
+        arm(3); inv_step8<A, 3>(sm, t3, cc, lf_tid()); left -= 3;
+        t6.load(c, s + 6, adj, g.logN, base, lf_tid());
         lds_barrier();
-        arm(3); inv_step8<A, 6>(sm, t6, cc); left -= 3;
-        t9.load(c, s + 9, adj, g.logN, base);
+        arm(3); inv_step8<A, 6>(sm, t6, cc, lf_tid()); left -= 3;
+        t9.load(c, s + 9, adj, g.logN, base, lf_tid());
         lds_barrier();
-        arm(3); inv_step8<A, 9>(sm, t9, cc);
+        arm(3); inv_step8<A, 9>(sm, t9, cc, lf_tid());
         lds_barrier();
         return;
     }
@@ -583,6 +579,18 @@ __device__ __forceinline__ void run_inv_stages(typename A::T *sm, const PassGeom
         }
         lds_barrier();
     }
+}
+
+// The same constants with 1 / q taken from slot 0 of the limb's fp64 twiddle table: no stage ever reads entry 0
+// (forward indices start at 2^s >= 1, inverse ones at N >> (s + 1) >= 1), so lf_twiddle_dp stores the correctly
+// rounded reciprocal there and the pass kernels skip the 13-instruction fp64 division per wave.
+__device__ __forceinline__ RowDp make_dp_tab(const RowMod &m, const double *__restrict__ tw_dp) {
+    RowDp d;
+    d.q = (double)m.q;
+    d.q2 = 2.0 * d.q;
+    d.qinv = tw_dp[0];
+    d.q2inv = 0.5 * d.qinv;
+    return d;
 }
 
 __device__ __forceinline__ RowDp make_dp(const RowMod &m) {
@@ -631,43 +639,48 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// steps of the forward tile; x[e] = word (w + 512 e) on entry, word (8 w + e) on exit
-template <class A>
+// steps of the forward tile; x[e] = word (w + 512 e) on entry, word (8 w + e) on exit.
+// KEEP: the thread index stays in ONE register for the whole tile (relaxed kernels: no out-of-line call that would
+// spill it); otherwise it is rebuilt from the wave index and v_mbcnt at every use (see lf_tid).
+// CHECK: the tile may hold a word outside [0, 2q) (flag word written by wave_flag_set): relaxed fp64 tiles never do.
+#define LF_TID(KEEP, w0) ((KEEP) ? (w0) : lf_tid())
+template <class A, bool KEEP, bool CHECK>
 __device__ __forceinline__ bool fwd_tile12_core(typename A::T *smt, i64 *sm, typename A::T (&x)[8], int s, int E, int base,
-                                                const Ctx &c) {
-    const int w = lf_tid();
+                                                const Ctx &c, int w0) {
     StepTw<A, 9> t9;
     StepTw<A, 6> t6;
     StepTw<A, 3> t3;
     StepTw<A, 0> t0;
-    t9.load(c, s, E, base);
+    t9.load(c, s, E, base, LF_TID(KEEP, w0));
     fwd_regs8<A, 9>(x, t9, c);
     {
-        typename A::T *sp = smt + PAD(w);   // PAD(w + 512 e) = PAD(w) + 576 e
+        typename A::T *sp = smt + PAD(LF_TID(KEEP, w0));   // PAD(w + 512 e) = PAD(w) + 576 e
 #pragma unroll
         for (int e = 0; e < 8; ++e) sp[e * PAD_STRIDE(9)] = x[e];
     }
-    t6.load(c, s + 3, E, base);
+    t6.load(c, s + 3, E, base, LF_TID(KEEP, w0));
     lds_barrier();
-    if (sm[NTT_FLAG_WORD] != 0) {
+    if (CHECK && sm[NTT_FLAG_WORD] != 0) {
         lds_barrier();   // every wave has read the flag before the generic path resets it
         return false;
     }
-    fwd_step8<A, 6>(smt, t6, c);
-    t3.load(c, s + 6, E, base);
+    fwd_step8<A, 6>(smt, t6, c, LF_TID(KEEP, w0));
+    t3.load(c, s + 6, E, base, LF_TID(KEEP, w0));
     lds_barrier();
-    fwd_step8<A, 3>(smt, t3, c);
-    t0.load(c, s + 9, E, base);
+    fwd_step8<A, 3>(smt, t3, c, LF_TID(KEEP, w0));
+    t0.load(c, s + 9, E, base, LF_TID(KEEP, w0));
     lds_barrier();
+    {
+        const int w = LF_TID(KEEP, w0);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = smt[9 * w + e];
+        for (int e = 0; e < 8; ++e) x[e] = smt[9 * w + e];
+    }
     fwd_regs8<A, 0>(x, t0, c);
     return true;
 }
 
 // 8 consecutive result words per thread -> global, 16 B per lane and 1 KiB contiguous per wave instruction
-__device__ __forceinline__ void store_tile12_regs(i64 *sm, const i64 (&o)[8], i64 *dst) {
-    const int w = lf_tid();
+__device__ __forceinline__ void store_tile12_regs(i64 *sm, const i64 (&o)[8], i64 *dst, int w) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) sm[9 * w + e] = o[e];
     wave_lds_sync();
@@ -682,12 +695,15 @@ __device__ __forceinline__ void store_tile12_regs(i64 *sm, const i64 (&o)[8], i6
     }
 }
 
-template <bool DP>
+template <bool DP, bool RLX>
 __device__ __forceinline__ bool fwd_tile12(i64 *sm, i64 *__restrict__ row, int tile, const PassGeom &g, const Ctx &c,
                                            bool enter, i64 rs) {
     const int w = lf_tid();
     const int base = tile << 12;
     const i64 q2 = c.m.q2;
+    // relaxed transforms: the fp64 class converts signed words directly (dp_from_signed: the balanced arithmetic is
+    // sign-agnostic), the integer class folds them into [0, 2q) first
+    const bool fold = RLX && !DP;
     i64 raw[8];
     {
         const i64 *src = row + base + w;
@@ -697,8 +713,8 @@ __device__ __forceinline__ bool fwd_tile12(i64 *sm, i64 *__restrict__ row, int t
     int odd = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        if (g.relaxed) raw[e] = raw[e] < 0 ? raw[e] + q2 : raw[e];   // residues only: fold the signed-lazy words
-        odd |= ((u64)raw[e] >= (u64)q2);
+        if (fold) raw[e] = raw[e] < 0 ? raw[e] + q2 : raw[e];   // residues only: fold the signed-lazy words
+        if (!(RLX && DP)) odd |= ((u64)raw[e] >= (u64)q2);      // relaxed fp64 tiles accept any non-negative representative
     }
     i64 o[8];
     if (DP) {
@@ -707,19 +723,19 @@ __device__ __forceinline__ bool fwd_tile12(i64 *sm, i64 *__restrict__ row, int t
         const double r1 = enter ? (double)((1ull << 62) % c.m.q) : 0.0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            double v = dp_from_word(raw[e]);
+            double v = RLX ? dp_from_signed(raw[e]) : dp_from_word(raw[e]);
             if (enter) {   // Montgomery entry, emulated exactly: REDC62(a * R^2)
                 v = dp_mulmod(v, r1, c.d);
-                if (!g.relaxed && dp_below_fix_limit(v)) v = dp_lazy_fix(v, (u64)raw[e], (u64)rs, c.d.q);
+                if (!RLX && dp_below_fix_limit(v)) v = dp_lazy_fix(v, (u64)raw[e], (u64)rs, c.d.q);
             }
             x[e] = v;
         }
-        wave_flag_set(sm, g.relaxed ? 0 : odd);   // relaxed tiles accept any non-negative representative
-        const bool ok = g.relaxed ? fwd_tile12_core<ArithDpR>(smd, sm, x, g.s0, g.logN, base, c)
-                                  : fwd_tile12_core<ArithDp>(smd, sm, x, g.s0, g.logN, base, c);
+        if (!RLX) wave_flag_set(sm, odd);
+        const bool ok = RLX ? fwd_tile12_core<ArithDpR, true, false>(smd, sm, x, g.s0, g.logN, base, c, w)
+                            : fwd_tile12_core<ArithDp, false, true>(smd, sm, x, g.s0, g.logN, base, c, w);
         if (!ok) return false;
         // the pass accumulated without subtractions: back to the lazy word in [0, 2q) (relaxed: canonical residue)
-        const double md = g.relaxed ? c.d.q : c.d.q2, mi = g.relaxed ? c.d.qinv : c.d.q2inv;
+        const double md = RLX ? c.d.q : c.d.q2, mi = RLX ? c.d.qinv : c.d.q2inv;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = dp_to_word(dp_reduce(x[e], md, mi));
     } else {
@@ -731,46 +747,48 @@ __device__ __forceinline__ bool fwd_tile12(i64 *sm, i64 *__restrict__ row, int t
             }
         }
         wave_flag_set(sm, odd);
-        if (!fwd_tile12_core<ArithInt<false>>(sm, sm, raw, g.s0, g.logN, base, c)) return false;
+        if (!fwd_tile12_core<ArithInt<false>, RLX, true>(sm, sm, raw, g.s0, g.logN, base, c, w)) return false;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = raw[e];
     }
-    store_tile12_regs(sm, o, row + base);
+    store_tile12_regs(sm, o, row + base, LF_TID(RLX, w));
     return true;
 }
 
-// steps of the inverse tile; x[e] = word (8 w + e) on entry, word (w + 512 e) on exit
-template <class A>
+// steps of the inverse tile; x[e] = word (8 w + e) on entry, word (w + 512 e) on exit (KEEP / CHECK: see the forward core)
+template <class A, bool KEEP, bool CHECK>
 __device__ __forceinline__ bool inv_tile12_core(typename A::T *smt, i64 *sm, typename A::T (&x)[8], int s, int logN, int base,
-                                                const Ctx &c) {
-    const int w = lf_tid();
+                                                const Ctx &c, int w0) {
     Ctx cc = c;
     StepTwInv<A, 0> t0;
     StepTwInv<A, 3> t3;
     StepTwInv<A, 6> t6;
     StepTwInv<A, 9> t9;
     // fp64 class: words double per stage; reduced mod 2q at the end of every second step (run_inv_stages)
-    t0.load(c, s, 0, logN, base);
+    t0.load(c, s, 0, logN, base, LF_TID(KEEP, w0));
     cc.inv_reduce = 0;
     inv_regs8<A, 0>(x, t0, cc);
+    {
+        const int w = LF_TID(KEEP, w0);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) smt[9 * w + e] = x[e];
-    t3.load(c, s + 3, 0, logN, base);
+        for (int e = 0; e < 8; ++e) smt[9 * w + e] = x[e];
+    }
+    t3.load(c, s + 3, 0, logN, base, LF_TID(KEEP, w0));
     lds_barrier();
-    if (sm[NTT_FLAG_WORD] != 0) {
+    if (CHECK && sm[NTT_FLAG_WORD] != 0) {
         lds_barrier();
         return false;
     }
     cc.inv_reduce = 1;
-    inv_step8<A, 3>(smt, t3, cc);
-    t6.load(c, s + 6, 0, logN, base);
+    inv_step8<A, 3>(smt, t3, cc, LF_TID(KEEP, w0));
+    t6.load(c, s + 6, 0, logN, base, LF_TID(KEEP, w0));
     lds_barrier();
     cc.inv_reduce = 0;
-    inv_step8<A, 6>(smt, t6, cc);
-    t9.load(c, s + 9, 0, logN, base);
+    inv_step8<A, 6>(smt, t6, cc, LF_TID(KEEP, w0));
+    t9.load(c, s + 9, 0, logN, base, LF_TID(KEEP, w0));
     lds_barrier();
     {
-        const typename A::T *sp = smt + PAD(w);
+        const typename A::T *sp = smt + PAD(LF_TID(KEEP, w0));
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = sp[e * PAD_STRIDE(9)];
     }
@@ -790,13 +808,16 @@ __device__ __forceinline__ i64 inv_tail_int(i64 t, int tail, i64 ninv, const Ctx
     return z;
 }
 
-template <bool DP>
+template <bool DP, bool RLX>
 __device__ __forceinline__ bool inv_tile12(i64 *sm, const i64 *src_row, i64 *dst_row, int tile, const PassGeom &g, const Ctx &c,
                                            const i64 *__restrict__ Ninv, int tail, int crow) {
     const int w = lf_tid();
     const int base = tile << 12;
     const i64 q2 = c.m.q2;
-    // 16-byte loads, 1 KiB contiguous per wave instruction, exchanged through the wave's own LDS span
+    // 16-byte loads, 1 KiB contiguous per wave instruction, exchanged through the wave's own LDS span.
+    // Relaxed transforms take NON-NEGATIVE words (include/ckks_hip.h: every producer inside the library — tensor
+    // product, key inner product — writes canonical or lazy [0, 2q) words): nothing to fold, and the fp64 class
+    // accepts any such representative, so it has no out-of-range tiles either.
     const int L0 = ((w >> 6) << 9) + ((w & 63) << 1);
     int odd = 0;
     {
@@ -805,18 +826,14 @@ __device__ __forceinline__ bool inv_tile12(i64 *sm, const i64 *src_row, i64 *dst
         for (int i = 0; i < 4; ++i) in[i] = *reinterpret_cast<const longlong2 *>(src_row + base + L0 + (i << 7));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            longlong2 v = in[i];
-            if (g.relaxed) {
-                v.x = v.x < 0 ? v.x + q2 : v.x;
-                v.y = v.y < 0 ? v.y + q2 : v.y;
-            }
-            odd |= ((u64)v.x >= (u64)q2) | ((u64)v.y >= (u64)q2);
+            const longlong2 v = in[i];
+            if (!(RLX && DP)) odd |= ((u64)v.x >= (u64)q2) | ((u64)v.y >= (u64)q2);
             i64 *sp = sm + PAD(L0);   // L0 even: PAD(L0 + 128 i + 1) = PAD(L0) + 144 i + 1
             sp[i * PAD_STRIDE(7)] = v.x;
             sp[i * PAD_STRIDE(7) + 1] = v.y;
         }
     }
-    wave_flag_set(sm, odd);
+    if (!(RLX && DP)) wave_flag_set(sm, odd);
     wave_lds_sync();
     i64 raw[8];
 #pragma unroll
@@ -828,8 +845,8 @@ __device__ __forceinline__ bool inv_tile12(i64 *sm, const i64 *src_row, i64 *dst
         double x[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = dp_from_word(raw[e]);
-        const bool ok = g.relaxed ? inv_tile12_core<ArithDpR>(smd, sm, x, g.s0, g.logN, base, c)
-                                  : inv_tile12_core<ArithDp>(smd, sm, x, g.s0, g.logN, base, c);
+        const bool ok = RLX ? inv_tile12_core<ArithDpR, true, false>(smd, sm, x, g.s0, g.logN, base, c, w)
+                            : inv_tile12_core<ArithDp, false, true>(smd, sm, x, g.s0, g.logN, base, c, w);
         if (!ok) return false;
         const int t_eff = tail;   // the caller passes TAIL_NONE unless this is the last pass
         // chain tail: z = REDC(t * Ninv); [redc]; [reduce]; [signed]    (K.cu:527-529, 754-902)
@@ -855,7 +872,7 @@ __device__ __forceinline__ bool inv_tile12(i64 *sm, const i64 *src_row, i64 *dst
             out[e << 9] = (t_eff >= 3) ? (i64)z : dp_to_word(z);
         }
     } else {
-        if (!inv_tile12_core<ArithInt<false>>(sm, sm, raw, g.s0, g.logN, base, c)) return false;
+        if (!inv_tile12_core<ArithInt<false>, RLX, true>(sm, sm, raw, g.s0, g.logN, base, c, w)) return false;
         const int t_eff = tail;   // the caller passes TAIL_NONE unless this is the last pass
         const i64 ninv = (t_eff != TAIL_NONE) ? Ninv[crow] : 0;
 #pragma unroll
@@ -883,9 +900,9 @@ __device__ __forceinline__ void fwd_pass_body(i64 *sm, int b, i64 *__restrict__ 
         const int item = 0;
         Ctx c;
         c.m = load_mod(ql, qh, kl, kh, crow);
-        c.d = make_dp(c.m);
         c.tw_mont = psi_br + ((i64)crow << g.logN);
         c.tw_dp = DP ? psi_dp + ((i64)crow << g.logN) : nullptr;
+        c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
         c.relaxed = g.relaxed;
         c.inv_reduce = 0;
         i64 *row = a + ((i64)(poly * g.rows + crow) << g.logN);
@@ -894,7 +911,7 @@ __device__ __forceinline__ void fwd_pass_body(i64 *sm, int b, i64 *__restrict__ 
 
         // contiguous 4096-word pass: register-fed form; false = the tile holds a word outside [0, 2q)
         if (g.tl == 12 && g.S == 12 && !g.strided && !g.noreg) {
-            if (fwd_tile12<DP>(sm, row, tile, g, c, enter, rs)) return;
+            if (fwd_tile12<DP, RLX>(sm, row, tile, g, c, enter, rs)) return;
         }
 
         if (threadIdx.x == 0) sm[NTT_FLAG_WORD] = 0;   // both block_or flag words
@@ -1044,9 +1061,9 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
 
     Ctx c;
     c.m = load_mod(ql, qh, kl, kh, crow);
-    c.d = make_dp(c.m);
     c.tw_mont = psi_br + ((i64)crow << g.logN);
     c.tw_dp = DP ? psi_dp + ((i64)crow << g.logN) : nullptr;
+    c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
     c.relaxed = g.relaxed;
     c.inv_reduce = 0;
     const i64 rs = enter ? Rs[crow] : 0;
@@ -1071,7 +1088,7 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
     int odd = 0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        if (g.relaxed) w[k] = w[k] < 0 ? w[k] + c.m.q2 : w[k];   // residues only: fold signed-lazy words
+        if (g.relaxed && !DP) w[k] = w[k] < 0 ? w[k] + c.m.q2 : w[k];   // residues only: fold signed-lazy words
         odd |= ((u64)w[k] >= (u64)c.m.q2);
     }
     if (DP && (g.relaxed || !odd)) {
@@ -1079,7 +1096,8 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
         const double r1 = enter ? (double)((1ull << 62) % c.m.q) : 0.0;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            double v = dp_from_word(w[k]);
+            // relaxed: signed words convert directly (the balanced arithmetic is sign-agnostic)
+            double v = g.relaxed ? dp_from_signed(w[k]) : dp_from_word(w[k]);
             if (enter) {   // Montgomery entry, emulated exactly: REDC62(a * R^2)
                 v = dp_mulmod(v, r1, c.d);
                 if (!g.relaxed && dp_below_fix_limit(v)) v = dp_lazy_fix(v, (u64)w[k], (u64)rs, c.d.q);
@@ -1164,9 +1182,9 @@ __device__ __forceinline__ void inv_pass_body(i64 *sm, int b, const i64 *src, i6
         const int item = 0;
         Ctx c;
         c.m = load_mod(ql, qh, kl, kh, crow);
-        c.d = make_dp(c.m);
         c.tw_mont = ipsi_br + ((i64)crow << g.logN);
         c.tw_dp = DP ? ipsi_dp + ((i64)crow << g.logN) : nullptr;
+        c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
         c.relaxed = g.relaxed;
         c.inv_reduce = 0;
         i64 *row = dst + ((i64)(poly * g.rows + crow) << g.logN);
@@ -1175,7 +1193,7 @@ __device__ __forceinline__ void inv_pass_body(i64 *sm, int b, const i64 *src, i6
 
         // contiguous 4096-word pass: register-fed form; false = the tile holds a word outside [0, 2q)
         if (g.tl == 12 && g.S == 12 && !g.strided && !g.noreg) {
-            if (inv_tile12<DP>(sm, src + ((i64)(poly * g.rows + crow) << g.logN), row, tile, g, c, Ninv, tail, crow)) return;
+            if (inv_tile12<DP, RLX>(sm, src + ((i64)(poly * g.rows + crow) << g.logN), row, tile, g, c, Ninv, tail, crow)) return;
         }
 
         if (threadIdx.x == 0) sm[NTT_FLAG_WORD] = 0;   // both block_or flag words
@@ -1310,9 +1328,9 @@ __device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const 
     const int poly = r % g.batch, crow = rl.id[r / g.batch];
     Ctx c;
     c.m = load_mod(ql, qh, kl, kh, crow);
-    c.d = make_dp(c.m);
     c.tw_mont = ipsi_br + ((i64)crow << g.logN);
     c.tw_dp = DP ? ipsi_dp + ((i64)crow << g.logN) : nullptr;
+    c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
     c.relaxed = g.relaxed;
     c.inv_reduce = 0;
     const i64 ninv_mont = (tail != TAIL_NONE) ? Ninv[crow] : 0;
@@ -1324,7 +1342,7 @@ __device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const 
     int odd = 0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        if (g.relaxed) w[k] = w[k] < 0 ? w[k] + c.m.q2 : w[k];
+        // (relaxed: the words come from this library's relaxed tiled pass — canonical / lazy [0, 2q), never negative)
         odd |= ((u64)w[k] >= (u64)c.m.q2);
     }
     if (DP && !odd) {
@@ -1472,7 +1490,7 @@ __global__ void __launch_bounds__(256) twiddle_dp_kernel(const i64 *__restrict__
     const RowMod m = load_mod(ql, qh, kl, kh, r);
     i64 v = redc62(mont[(i64)r * N + j], m.q, m.k);
     v = v < (i64)m.q ? v : v - (i64)m.q;
-    out[(i64)r * N + j] = (double)v;
+    out[(i64)r * N + j] = j == 0 ? 1.0 / (double)m.q : (double)v;   // slot 0 (= psi^0, never used): 1 / q, see make_dp_tab
 }
 
 }  // namespace
