@@ -397,16 +397,18 @@ def main():
     cols_ms = event_time_ms(lambda: one_pass(1), n_roof)
     alg_bytes_per_launch = 8 * N * L_LIMBS * B                      # 16*N per limb per transform, two launches
     achieved = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
-    traffic = valu = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    traffic = valu = valu_busy = cols_traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_r02.json")
     if os.path.exists(tpath):
-        tj = json.load(open(tpath))   # PMC bytes per launch at the profiled batch; a launch's traffic is linear in the batch
+        tj = json.load(open(tpath))   # PMC figures per launch at the profiled batch; a launch's traffic is linear in the batch
+        scale = B / float(tj.get("batch_per_gpu", 128))
         traffic = tj.get("ntt_fwd_pass_mixed_bytes_per_launch")
-        if traffic is not None:
-            traffic = traffic * B / float(tj.get("batch_per_gpu", 16))
+        traffic = None if traffic is None else traffic * scale
+        cols_traffic = tj.get("ntt_fwd_cols_mixed_bytes_per_launch")
+        cols_traffic = None if cols_traffic is None else cols_traffic * scale
         valu = tj.get("ntt_fwd_pass_mixed_valu_wave_instr_per_launch")
-        if valu is not None:
-            valu = valu * B / float(tj.get("batch_per_gpu", 16))
+        valu = None if valu is None else valu * scale
+        valu_busy = tj.get("ntt_fwd_pass_mixed_valu_busy_frac")
 
     result = {
         "metric": "NTTs/sec (forward negacyclic poly-NTT, logN=16, L=30 limbs, bit-exact vs reference semantics)",
@@ -424,12 +426,14 @@ def main():
                      "column_pass_algorithmic_GBps": alg_bytes_per_launch / (cols_ms * 1e-3) / 1e9,
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                      "whole_step_algorithmic_GBps": 16 * N * L_LIMBS * B / (dev_ms * 1e-3) / 1e9,
-                     # what actually bounds the kernel: VALU issue.  Wave-instructions per launch from the PMC pass
-                     # in profiles/ (scaled to the batch) over the live launch time, against the measured rate of
-                     # back-to-back v_fma_f64 on this part (profiles/r01_ubench.txt)
-                     "valu_issue": None if valu is None else {
-                         "wave_instr_per_launch": valu, "achieved_G_per_s": valu / (k_ms * 1e-3) / 1e9,
-                         "peak_fma_f64_G_per_s": 455.6, "frac": valu / (k_ms * 1e-3) / 455.6e9}},
+                     "column_pass_traffic": cols_traffic,
+                     # what actually bounds the kernel: VALU issue.  PMC pass of profiles/r02_bench_pmc.txt: wave-level
+                     # VALU instructions per launch (scaled to the batch) and the fraction of cycles the SIMDs' VALU is
+                     # busy (SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs over SQ_BUSY_CU_CYCLES / 256 CUs) — a utilisation,
+                     # measured, not a ratio against a synthetic peak
+                     "valu": None if valu is None else {
+                         "wave_instr_per_launch": valu, "wave_instr_G_per_s": valu / (k_ms * 1e-3) / 1e9,
+                         "busy_frac_pmc": valu_busy, "source": "profiles/traffic_r02.json"}},
     }
     extra = {"limb_ntt_per_s": value * L_LIMBS, "device_ms_per_step": dev_ms,
              "whole_step_frac_of_achievable_6300": 16 * N * L_LIMBS * B / (dev_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS}

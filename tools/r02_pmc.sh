@@ -1,0 +1,23 @@
+#!/bin/bash
+# PMC passes (separate runs, as the guide prescribes) over the bench step and over gold / silver cc_mult + rotate
+set -u
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out; mkdir -p $OUT; REPO=$PWD
+run() {  # tag, counters..., then "--", then program args
+  local TAG=$1; shift; local CNT=(); while [ "$1" != "--" ]; do CNT+=("$1"); shift; done; shift
+  cd /tmp && rocprofv3 --pmc "${CNT[@]}" --kernel-trace -d $OUT/pmc2_$TAG -o p -- python3 "$@" > $OUT/pmc2_$TAG.log 2>&1; cd $REPO
+}
+B="$REPO/bench.py --no-extra --steps 5 --warmup 2"
+run bench_fetch FETCH_SIZE -- $B
+run bench_write WRITE_SIZE -- $B
+run bench_valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY -- $B
+for P in gold silver; do
+  C="$REPO/tools/ccmult_profile.py $P cc_mult --mark"
+  run ${P}_fetch FETCH_SIZE -- $C
+  run ${P}_write WRITE_SIZE -- $C
+  run ${P}_valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY -- $C
+done
+# kernel stats of the bench command itself (the file the roofline numbers are checked against)
+cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_r02 -o stats -- python3 $REPO/bench.py --no-extra > $OUT/prof_r02.log 2>&1; cd $REPO
+python3 bench.py > $OUT/bench_r02.json 2> $OUT/bench_r02.err; tail -c 400 $OUT/bench_r02.json
+ls $OUT | grep pmc2 | head -20

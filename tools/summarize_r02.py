@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""gpurun_out/ of tools/r02_pmc.sh -> the tracked summaries under profiles/ (tag r02):
+
+  r02_bench_kernel_stats.txt   rocprofv3 --kernel-trace --stats of `python3 bench.py --no-extra`
+  r02_bench_pmc.txt            FETCH_SIZE / WRITE_SIZE / SQ passes over the same command (separate runs)
+  traffic_r02.json             what bench.py folds into its roofline block (bytes and VALU figures per launch)
+  r02_engine_ops_pmc.txt       the same counters per kernel of gold / silver cc_mult (+relinearize)
+
+Units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts a 16 B/lane coalesced read at
+half its bytes (MI355X_MICROARCH.md, HBM section) -> doubled.  SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count in units of
+4 cycles summed over the chip's 1024 SIMDs; SQ_BUSY_CU_CYCLES in cycles summed over the 256 CUs."""
+import collections, json, os, sqlite3, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, out = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+TAG = "r02"
+
+
+def q(db, sql):
+    con = sqlite3.connect(db)
+    try:
+        return con.execute(sql).fetchall()
+    finally:
+        con.close()
+
+
+def short(k):
+    return k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
+def counters(tag):
+    """{(kernel, grid): {counter: avg, 'us': avg, 'n': dispatches}} of one PMC pass"""
+    db = os.path.join(src, f"pmc2_{tag}", "p_results.db")
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for k, n, v, du, gx in q(db, "select kernel_name, counter_name, value, duration, grid_size_x from counters_collection"):
+        agg[(short(k), gx)][n].append(v)
+        agg[(short(k), gx)]["us"].append(du / 1e3)
+    return {k: {**{n: sum(v) / len(v) for n, v in d.items()}, "n": len(d["us"])} for k, d in agg.items()}
+
+
+# ---- bench: kernel stats -------------------------------------------------------------------------------------------
+lines = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-extra   ({TAG})",
+         "# columns: kernel | calls | total_us | avg_us | % of GPU time", ""]
+for name, calls, total, avg, pct in q(os.path.join(src, f"prof_{TAG}", "stats_results.db"),
+                                      "select name,total_calls,total_duration,average,percentage from top_kernels"):
+    lines.append(f"{short(name)[:90]:90s} | {calls:6d} | {total:12.1f} | {avg:10.2f} | {pct:6.2f}")
+try:
+    bench = json.load(open(os.path.join(src, f"bench_{TAG}.json")))
+    r = bench["roofline"]
+    lines += ["", f"# bench.py (un-profiled run of the same box): value {bench['value']:.0f} poly-NTT/s, ms_per_step {bench['ms_per_step']:.4f};",
+              f"# roofline leg (lf_ntt_pass which = 2, {r['launches_timed']} launches): avg_launch_ms {r['avg_launch_ms']:.4f} from HIP events;",
+              f"# the last {r['launches_timed']} ntt_fwd_pass_mixed<false> dispatches of the trace above are that leg."]
+    durs = [d[0] / 1e3 for d in q(os.path.join(src, f"prof_{TAG}", "stats_results.db"),
+                                  "select duration from kernels where name like '%ntt_fwd_pass_mixed<false>%' order by start")]
+    tail = durs[-int(r["launches_timed"]):]
+    lines.append(f"# their average under rocprofv3: {sum(tail) / len(tail):.2f} us (min {min(tail):.2f}, max {max(tail):.2f})")
+except Exception as e:
+    lines.append(f"# bench line not found: {e}")
+open(os.path.join(out, f"{TAG}_bench_kernel_stats.txt"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines[:12]))
+
+# ---- bench: PMC ----------------------------------------------------------------------------------------------------
+f, w, v = counters("bench_fetch"), counters("bench_write"), counters("bench_valu")
+pm = [f"# rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --no-extra --steps 5 --warmup 2   ({TAG}); one run per line group",
+      "# kernel/grid | us | FETCH_SIZE KiB (raw) | read MB (x2, gfx950) | WRITE_SIZE KiB | write MB | moved TB/s | VALU wave-instr | VALU busy | CU busy", ""]
+traffic = {"batch_per_gpu": 128}
+for key in sorted(f):
+    if "ntt_" not in key[0]:
+        continue
+    rd, wr = 2 * f[key]["FETCH_SIZE"] * 1024, w[key]["WRITE_SIZE"] * 1024
+    us = v[key]["us"]
+    clk_cu = v[key]["SQ_BUSY_CU_CYCLES"] / 256 / us / 1e3     # GHz while busy (upper bound: busy CUs only)
+    valu_busy = v[key]["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (v[key]["SQ_BUSY_CU_CYCLES"] / 256)
+    pm.append(f"{key[0]}/g{key[1]} | {us:8.1f} | {f[key]['FETCH_SIZE']:10.1f} | {rd / 1e6:8.1f} | {w[key]['WRITE_SIZE']:10.1f} | {wr / 1e6:8.1f} | "
+              f"{(rd + wr) / us / 1e6:5.2f} | {v[key]['SQ_INSTS_VALU']:.4g} | {valu_busy:5.3f} | cycles/CU {v[key]['SQ_BUSY_CU_CYCLES'] / 256:.4g} (~{clk_cu:.2f} GHz x launch)")
+    name = "ntt_fwd_pass_mixed" if "fwd_pass" in key[0] else "ntt_fwd_cols_mixed"
+    traffic[f"{name}_bytes_per_launch"] = rd + wr
+    traffic[f"{name}_valu_wave_instr_per_launch"] = v[key]["SQ_INSTS_VALU"]
+    traffic[f"{name}_valu_busy_frac"] = valu_busy
+    traffic[f"{name}_salu_per_valu"] = v[key]["SQ_INSTS_SALU"] / v[key]["SQ_INSTS_VALU"]
+traffic["note"] = ("per launch at batch_per_gpu polynomials x 30 limbs; bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes, gfx950 half-count "
+                   "correction on reads); valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs over SQ_BUSY_CU_CYCLES / 256 CUs; source "
+                   "profiles/r02_bench_pmc.txt")
+open(os.path.join(out, f"{TAG}_bench_pmc.txt"), "w").write("\n".join(pm) + "\n")
+json.dump(traffic, open(os.path.join(out, f"traffic_{TAG}.json"), "w"), indent=1)
+print("\n".join(pm))
+
+# ---- engine ops: PMC per kernel ------------------------------------------------------------------------------------
+eo = [f"# rocprofv3 --pmc <counters> --kernel-trace -- python3 tools/ccmult_profile.py <preset> cc_mult --mark   ({TAG}); FETCH / WRITE / SQ in separate runs",
+      "# averages over all dispatches of the run (3 warm-up + 10 timed ops); a kernel listed twice runs on two grids per op",
+      "# kernel/grid | us | read MB (2 x FETCH_SIZE) | write MB | moved TB/s | VALU wave-instr | VALU busy"]
+for preset in ("gold", "silver"):
+    try:
+        f, w, v = counters(f"{preset}_fetch"), counters(f"{preset}_write"), counters(f"{preset}_valu")
+    except Exception as e:
+        eo.append(f"## {preset}: missing ({e})")
+        continue
+    eo += ["", f"## {preset} cc_mult + relinearize"]
+    for key in sorted(v, key=lambda k: -v[k]["us"] * v[k]["n"]):
+        if not (key[0].startswith(("ntt_", "ks_", "tensor"))) or key not in f or key not in w:
+            continue
+        rd, wr, us = 2 * f[key]["FETCH_SIZE"] * 1024, w[key]["WRITE_SIZE"] * 1024, v[key]["us"]
+        busy = v[key]["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (v[key]["SQ_BUSY_CU_CYCLES"] / 256)
+        eo.append(f"{key[0]}/g{key[1]} | {us:7.1f} | {rd / 1e6:7.1f} | {wr / 1e6:7.1f} | {(rd + wr) / us / 1e6:5.2f} | {v[key]['SQ_INSTS_VALU']:.4g} | {busy:5.3f}")
+open(os.path.join(out, f"{TAG}_engine_ops_pmc.txt"), "w").write("\n".join(eo) + "\n")
+print("\n".join(eo))
