@@ -51,6 +51,18 @@ static __device__ __forceinline__ i64 mm62u(u64 a, u64 b, u64 q, u64 k) {
     return (i64)(xh + __umul64hi(s4, q) + (u64)(lo != 0));
 }
 
+// REDC62 of a signed 128-bit value x, |x| < 2^124: (x + ((x*k) mod R) * q) / R — the tail of mm62s without the product.
+// The fused key switch accumulates sum_i y_i * c_i over a digit's limbs in 128 bits and reduces ONCE (only the
+// residue matters there), instead of one REDC and one conditional subtraction per limb.
+static __device__ __forceinline__ i64 redc62_wide(i128 x, u64 q, u64 k) {
+    const u64 lo = (u64)x;
+    const i64 hi = (i64)(x >> 64);
+    const u64 xl = lo & M62;
+    const i64 xh = (i64)(((u64)hi << 2) | (lo >> 62));
+    const u64 s = (xl * k) & M62;
+    return xh + (i64)__umul64hi(s << 2, q) + (i64)(xl != 0);
+}
+
 // mont_redc body (K.cu:587-606): (x + ((x*k) mod R) * q) / R for signed x, |x| < 2^62.
 static __device__ __forceinline__ i64 redc62(i64 x, u64 q, u64 k) {
     const u64 xl = (u64)x & M62;

@@ -127,17 +127,36 @@ __device__ __forceinline__ void ks_ext_body(i64 *sm, int b, const i64 *__restric
         for (int i = 0; i < KS_MAX_ALPHA; ++i) cst[i] = i < alpha ? E[e_off + (i64)i * kg.rows] : 0;
         for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2) {
             const i64 j = tile_gaddr(g, tile, L);
-            i64 a0 = 0, a1 = 0;
+            i64 a0, a1;
+            if (wide && alpha > 1) {
+                // several 60-bit limbs in one digit (no preset has that): term by term, as the reference extends
+                a0 = a1 = 0;
 #pragma unroll
-            for (int i = 0; i < KS_MAX_ALPHA; ++i) {
-                if (i < alpha) {
-                    const longlong2 y = *reinterpret_cast<const longlong2 *>(state + (i64)(row_start + i) * kg.N + j);
-                    const i64 t0 = mm62s(y.x, cst[i], c.m.q, c.m.k), t1 = mm62s(y.y, cst[i], c.m.q, c.m.k);
-                    a0 = i == 0 ? t0 : csub(a0 + t0, c.m.q2);
-                    a1 = i == 0 ? t1 : csub(a1 + t1, c.m.q2);
+                for (int i = 0; i < KS_MAX_ALPHA; ++i) {
+                    if (i < alpha) {
+                        const longlong2 y = *reinterpret_cast<const longlong2 *>(state + (i64)(row_start + i) * kg.N + j);
+                        const i64 t0 = mm62s(y.x, cst[i], c.m.q, c.m.k), t1 = mm62s(y.y, cst[i], c.m.q, c.m.k);
+                        a0 = i == 0 ? t0 : csub(a0 + t0, c.m.q2);
+                        a1 = i == 0 ? t1 : csub(a1 + t1, c.m.q2);
+                    }
                 }
+            } else {
+                // sum_i y_i * (L_{i-1} R^2 mod q) in 128 bits, ONE REDC: |y_i| < 2^44 for digits of 40-bit limbs
+                // (<= 8 terms, constants < 2^60: |sum| < 2^107), or a single term |y| < 2^61 — the result lies in
+                // (-2^59, q + 2^59), inside the (-2q, 2q) the fold below expects
+                i128 x0 = 0, x1 = 0;
+#pragma unroll
+                for (int i = 0; i < KS_MAX_ALPHA; ++i) {
+                    if (i < alpha) {
+                        const longlong2 y = *reinterpret_cast<const longlong2 *>(state + (i64)(row_start + i) * kg.N + j);
+                        x0 += (i128)y.x * (i128)cst[i];
+                        x1 += (i128)y.y * (i128)cst[i];
+                    }
+                }
+                a0 = redc62_wide(x0, c.m.q, c.m.k);
+                a1 = redc62_wide(x1, c.m.q, c.m.k);
             }
-            sm[PAD(L)] = a0 < 0 ? a0 + c.m.q2 : a0;       // residues only: fold the signed-lazy words
+            sm[PAD(L)] = a0 < 0 ? a0 + c.m.q2 : a0;       // residues only: fold into [0, 2q)
             sm[PAD(L + 1)] = a1 < 0 ? a1 + c.m.q2 : a1;
         }
         lds_barrier();
