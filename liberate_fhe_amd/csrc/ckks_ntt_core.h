@@ -6,6 +6,9 @@
 #include <stdlib.h>
 
 #define NTT_THREADS 512
+#ifndef LF_PASS_WAVES
+#define LF_PASS_WAVES 6   // waves per SIMD the mixed pass kernels are compiled for (80 VGPRs = 3 blocks per CU)
+#endif
 #define NTT_LDS_WORDS ((1 << NTT_TILE_LOG_MAX) + (1 << (NTT_TILE_LOG_MAX - 3)))
 #define TAIL_NONE (-1)
 #define SMALL_PRIME_LIMIT (1ull << 41)
@@ -643,6 +646,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 // KEEP: the thread index stays in ONE register for the whole tile (relaxed kernels: no out-of-line call that would
 // spill it); otherwise it is rebuilt from the wave index and v_mbcnt at every use (see lf_tid).
 // CHECK: the tile may hold a word outside [0, 2q) (flag word written by wave_flag_set): relaxed fp64 tiles never do.
+#ifndef LF_EXACT_KEEP
+#define LF_EXACT_KEEP false
+#endif
 #define LF_TID(KEEP, w0) ((KEEP) ? (w0) : lf_tid())
 template <class A, bool KEEP, bool CHECK>
 __device__ __forceinline__ bool fwd_tile12_core(typename A::T *smt, i64 *sm, typename A::T (&x)[8], int s, int E, int base,
@@ -732,7 +738,7 @@ __device__ __forceinline__ bool fwd_tile12(i64 *sm, i64 *__restrict__ row, int t
         }
         if (!RLX) wave_flag_set(sm, odd);
         const bool ok = RLX ? fwd_tile12_core<ArithDpR, true, false>(smd, sm, x, g.s0, g.logN, base, c, w)
-                            : fwd_tile12_core<ArithDp, false, true>(smd, sm, x, g.s0, g.logN, base, c, w);
+                            : fwd_tile12_core<ArithDp, LF_EXACT_KEEP, true>(smd, sm, x, g.s0, g.logN, base, c, w);
         if (!ok) return false;
         // the pass accumulated without subtractions: back to the lazy word in [0, 2q) (relaxed: canonical residue)
         const double md = RLX ? c.d.q : c.d.q2, mi = RLX ? c.d.qinv : c.d.q2inv;
@@ -751,7 +757,7 @@ __device__ __forceinline__ bool fwd_tile12(i64 *sm, i64 *__restrict__ row, int t
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = raw[e];
     }
-    store_tile12_regs(sm, o, row + base, LF_TID(RLX, w));
+    store_tile12_regs(sm, o, row + base, LF_TID(RLX || LF_EXACT_KEEP, w));
     return true;
 }
 
@@ -993,7 +999,7 @@ struct ClassLists {
 };
 
 template <bool RLX>
-__global__ void __launch_bounds__(NTT_THREADS, 6) ntt_fwd_pass_mixed(i64 *__restrict__ a, PassGeom g, ClassLists cl,
+__global__ void __launch_bounds__(NTT_THREADS, LF_PASS_WAVES) ntt_fwd_pass_mixed(i64 *__restrict__ a, PassGeom g, ClassLists cl,
                                                                        const i64 *__restrict__ psi_br,
                                                                        const double *__restrict__ psi_dp,
                                                                        const i64 *__restrict__ Rs, const i64 *__restrict__ ql,
@@ -1280,7 +1286,7 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_inv_pass_io(const
 }
 
 template <bool RLX>
-__global__ void __launch_bounds__(NTT_THREADS, 6) ntt_inv_pass_mixed(const i64 *src, i64 *dst, PassGeom g, ClassLists cl,
+__global__ void __launch_bounds__(NTT_THREADS, LF_PASS_WAVES) ntt_inv_pass_mixed(const i64 *src, i64 *dst, PassGeom g, ClassLists cl,
                                                                        const i64 *__restrict__ ipsi_br,
                                                                        const double *__restrict__ ipsi_dp,
                                                                        const i64 *__restrict__ Ninv, int tail,

@@ -267,3 +267,34 @@ def test_hip_engine_equals_checker_engine_at_deeper_levels(level):
             res += [eng.cc_mult(a, b, evk), eng.cc_mult(b, a, evk), eng.rotate_single(a, rotk), eng.rotate_single(b, rotk)]
         outs.append([digest(x) for x in res])
     assert outs[0] == outs[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,splits", [("silver", [(0, 9)]), ("silver", [(0, 1), (1, 5), (6, 3)]), ("gold", [(0, 4), (4, 6)])])
+def test_ks_fwd_groups_plus_tail_equal_ks_core(name, splits):
+    """lf_ks_fwd over any partition of the digits into consecutive groups, then lf_ks_tail, leaves exactly what the
+    undivided lf_ks_core leaves (the limb-sharded engine feeds the groups as they arrive from the other GPUs)."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    eng = ckks_engine(devices=["cuda:0"], **GOLD[name]["params"])
+    level, d = 0, 0
+    a = synth.ciphertext(eng, 7, level)
+    key = synth.key_switch_key(eng, 8)
+    tabs = eng._ks_tables(level)
+    N, logN = eng.ctx.N, eng.ctx.logN
+    rows, ell = eng._rows(d, level, True), eng._rows(d, level, False)
+    nparts = len(tabs["order"])
+    assert sum(c for _, c in splits) == nparts
+    st = torch.empty((ell, N), dtype=torch.int64, device="cuda:0")
+    n_d, desc_d, tab_d = tabs[("digits", d)]
+    eng.backend.ks_digits(a.data[1][0], st, n_d, desc_d, tab_d, eng._consts(d, level, False))
+    desc, E, Ed = tabs[("extend", d)]
+    cs = eng._consts(d, level, True)
+    kp = eng._key_pack(key)[0]
+    tw, itw, ninv = eng._tw(d, level, True), eng._tw(d, level, True, True), eng._vec("Ninv", d, level, True)
+    ext1, ext2 = (torch.zeros((nparts, rows, N), dtype=torch.int64, device="cuda:0") for _ in range(2))
+    s1, s2 = (torch.zeros((2, rows, N), dtype=torch.int64, device="cuda:0") for _ in range(2))
+    eng.backend.ks_core(st, nparts, rows, logN, desc, E, Ed, kp, tabs["first_part"], eng.ntt.starts[level][d], ext1, s1, tw, itw, ninv, cs)
+    for first, count in splits:
+        eng.backend.ks_fwd(st, first, count, rows, logN, desc, E, Ed, ext2, tw, cs)
+    eng.backend.ks_tail(nparts, rows, logN, kp, tabs["first_part"], eng.ntt.starts[level][d], ext2, s2, itw, ninv, cs)
+    assert torch.equal(ext1, ext2) and torch.equal(s1, s2)

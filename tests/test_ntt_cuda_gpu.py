@@ -314,3 +314,27 @@ def test_galois_gather_equals_scatter(canonical):
     check(lib.lf_ks_digits_galois(a.data_ptr(), got.data_ptr(), rows, desc.data_ptr(), tab.data_ptr(), N, pow(p, -1, 2 * N),
                                   q2.data_ptr() if canonical else 0, *cp, 0, st), "digits_galois")
     assert torch.equal(got, want)
+
+
+def test_ntt_pass_entry_is_the_two_halves_of_lf_ntt():
+    """lf_ntt_pass (the measurement entry bench.py times): which = 1 then which = 2 on one buffer == lf_ntt;
+    single-pass sizes and other selectors are argument errors."""
+    from liberate_fhe_amd._native import lib, check
+    from liberate_fhe_amd.ntt import twiddles
+    logN = 14
+    lim = Limbs(logN, pick_primes(logN, 3, 2))
+    rows, batch = lim.rows, 3
+    psi, q2 = dev(lim.mont_tables()[0]), dev(lim._2q)
+    c = [dev(v) for v in (lim.ql, lim.qh, lim.kl, lim.kh)]
+    cp = [t.data_ptr() for t in c]
+    st = torch.cuda.current_stream().cuda_stream
+    dp = twiddles.dp_pointer(psi, *c, 0, st)
+    q_host = np.array(lim.q, dtype=np.int64)
+    x = dev(np.stack([lim.uniform(40 + b, lazy=True) for b in range(batch)]))
+    want, got = x.clone(), x.clone()
+    check(lib.lf_ntt(want.data_ptr(), batch, rows, logN, psi.data_ptr(), dp, q_host.ctypes.data, 0, 0, q2.data_ptr(), *cp, 0, st), "ntt")
+    for which in (1, 2):
+        check(lib.lf_ntt_pass(got.data_ptr(), batch, rows, logN, psi.data_ptr(), dp, q_host.ctypes.data, 0, 0, which, *cp, 0, st), "pass")
+    assert torch.equal(got, want)
+    assert lib.lf_ntt_pass(got.data_ptr(), batch, rows, logN, psi.data_ptr(), dp, q_host.ctypes.data, 0, 0, 3, *cp, 0, st) == 10001
+    assert lib.lf_ntt_pass(got.data_ptr(), batch, rows, 12, psi.data_ptr(), dp, q_host.ctypes.data, 0, 0, 1, *cp, 0, st) == 10001
