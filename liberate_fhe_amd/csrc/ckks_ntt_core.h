@@ -272,8 +272,16 @@ struct ArithDp {
     // lazy REDC62(S * O) for O = o (any representative < 2^52 of the lazy word mod 2q)
     static __device__ __forceinline__ T mul(const Ctx &c, W w, T o, int idx) {
         T v = dp_mulmod(o, w, c.d);
+#ifdef LF_UNIFORM_GUARD
+        // wave-uniform test first: the scalar branch lets the compiler move the (rare) repair out of the fast path
+        if (!c.relaxed && __builtin_expect(__builtin_amdgcn_ballot_w64(dp_below_fix_limit(v)) != 0, 0)) {
+            if (dp_below_fix_limit(v))
+                v = dp_lazy_fix(v, (u64)c.tw_mont[idx], (u64)dp_reduce(o, c.d.q2, c.d.q2inv), c.d.q);
+        }
+#else
         if (!c.relaxed && dp_below_fix_limit(v))
             v = dp_lazy_fix(v, (u64)c.tw_mont[idx], (u64)dp_reduce(o, c.d.q2, c.d.q2inv), c.d.q);
+#endif
         return v;
     }
     static __device__ __forceinline__ void fwd(const Ctx &c, T &a, T &b, W w, int idx) {
