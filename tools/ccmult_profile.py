@@ -17,7 +17,7 @@ a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
 evk = synth.key_switch_key(eng, 5)
 rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
 fn = (lambda: eng.cc_mult(a, b, evk)) if op == "cc_mult" else (lambda: eng.rotate_single(a, rotk))
-for _ in range(3): fn()
+for _ in range(40): fn()   # steady-state clocks (tools/warm_probe.py)
 torch.cuda.synchronize()
 
 

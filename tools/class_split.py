@@ -21,13 +21,13 @@ for name, lo, hi in (("fp64 class (25 limbs)", tot - 30, tot - 5), ("integer cla
     for which, label in ((2, "tiled pass"), (1, "column pass")):
         f = lambda: check(lib.lf_ntt_pass(x.data_ptr(), B, L, 16, psi.data_ptr(), dp, q_host.ctypes.data, 0, 0, which, ql.data_ptr(), qh.data_ptr(),
                                           kl.data_ptr(), kh.data_ptr(), 0, st), "pass")
-        for _ in range(2): f()
+        for _ in range(25): f()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5): f()
+        for _ in range(20): f()
         e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / 5 * 1e3
+        us = e0.elapsed_time(e1) / 20 * 1e3
         bf = B * L * (N // 2) * (12 if which == 2 else 4) / 64     # wave-level butterflies per launch
         print(f"{name:26s} {label:11s} {us:8.1f} us/launch  {us * 1e3 / (B * L):7.1f} ns per limb  wave-butterflies {bf:.4g}")
     del x
