@@ -24,6 +24,7 @@
 // modular multiplication.  60-bit limbs keep the reference's Montgomery integer arithmetic.
 #include "../../include/ckks_hip.h"
 #include "ckks_ntt_core.h"
+#include "ckks_ntt_tile16.h"
 
 #define KS_WORDS ((1 << NTT_TILE_LOG_MAX) / NTT_THREADS)   // tile words owned by one thread (8)
 
@@ -324,7 +325,10 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
     {
         const PassGeom g{logN, tl, 0, tl, S1, 0, rows, (int)polys, 1, 1, 0};
         const unsigned per_row = polys << (logN - tl);
-        if (mixed) {
+        if (LF_TILE16) {
+            launch_pass16(false, 1, (int)polys, st, (const i64 *)tmp, (i64 *)tmp, g, in, dp, (const i64 *)psi_br, psi_dp,
+                          (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+        } else if (mixed) {
             const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
             hipLaunchKernelGGL((ntt_fwd_pass_mixed<true>), dim3((unsigned)cl.in_blocks + per_row * dp.n), dim3(NTT_THREADS), 0, st,
                                (i64 *)tmp, g, cl, (const i64 *)psi_br, psi_dp, (const i64 *)nullptr, (const i64 *)ql,
@@ -333,7 +337,7 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
             hipLaunchKernelGGL((ntt_fwd_pass<true, true>), dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, (i64 *)tmp, g, dp,
                                (const i64 *)psi_br, psi_dp, (const i64 *)nullptr, (const i64 *)ql, (const i64 *)qh,
                                (const i64 *)kl, (const i64 *)kh);
-        if (in.n && !mixed)
+        if (!LF_TILE16 && in.n && !mixed)
             hipLaunchKernelGGL((ntt_fwd_pass<false, true>), dim3(per_row * in.n), dim3(NTT_THREADS), 0, st, (i64 *)tmp, g, in,
                                (const i64 *)psi_br, psi_dp, (const i64 *)nullptr, (const i64 *)ql, (const i64 *)qh,
                                (const i64 *)kl, (const i64 *)kh);
@@ -371,6 +375,11 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
     for (int pass = 0; pass < 2; ++pass) {
         PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, inv_polys, 1, 0, 0}
                                : PassGeom{logN, tl, 1, S1, tl, tl - S1, rows, inv_polys, 1, 1, 0};
+        if (LF_TILE16 && pass == 0) {
+            launch_pass16(true, 1, inv_polys, st, (const i64 *)s, (i64 *)s, g, in, dp, (const i64 *)ipsi_br, ipsi_dp,
+                          (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+            continue;
+        }
         if (pass == 1 && S1 <= 4 && cols_enabled()) {
             if (mixed) {
                 launch_inv_cols_mixed(S1, inv_polys, st, (i64 *)s, g, in, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,

@@ -32,6 +32,7 @@
 //     switch): negative input words are folded, outputs are canonical residues.
 #include "../../include/ckks_hip.h"
 #include "ckks_ntt_core.h"
+#include "ckks_ntt_tile16.h"
 #include <stdlib.h>
 #include <mutex>
 
@@ -267,6 +268,12 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
                 if (in.n) launch_cols<false>(S1, col_blocks * in.n, st_int, base, g, in, psi_br, psi_dp, rs, ql, qh, kl, kh);
                 continue;
             }
+            if (LF_TILE16 && pass == 1 && S1 > 0 && tl == NTT_TILE_LOG_MAX && rs == nullptr) {
+                // contiguous 12-stage pass: 16 words per thread (ckks_ntt_tile16.h), either class or both
+                launch_pass16(false, relaxed, nb, st, base, base, g, in, dp, (const i64 *)psi_br, psi_dp, (const i64 *)ql,
+                              (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+                continue;
+            }
             if (mixed) {
                 const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
                 LF_LAUNCH_MIXED(ntt_fwd_pass_mixed, relaxed, dim3((unsigned)cl.in_blocks + per_row * dp.n), dim3(NTT_THREADS), 0, st,
@@ -339,6 +346,11 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
                 if (in.n)
                     launch_inv_cols<false>(SB, nb, st_int, base, g, in, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t,
                                            (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+                continue;
+            }
+            if (LF_TILE16 && pass == 0 && SB > 0 && tl == NTT_TILE_LOG_MAX) {
+                launch_pass16(true, relaxed, nb, st, (const i64 *)base, base, g, in, dp, (const i64 *)ipsi_br, ipsi_dp,
+                              (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
                 continue;
             }
             if (mixed) {

@@ -1,0 +1,532 @@
+// ckks_ntt_tile16.h — the contiguous 4096-word pass of a two-pass transform (logN >= 13) with 16 words per thread.
+//
+// 256 threads per tile, three radix-16 register steps: two block-wide LDS exchanges instead of the three of the
+// 8-words-per-thread form (ckks_ntt_core.h: fwd_tile12 / inv_tile12, still used for logN = 12), the per-step index /
+// twiddle-address work amortised over 32 butterflies instead of 12, and the twiddles of the step at distance >= 256
+// depend on the tile only (scalar loads).  LDS holds the tile once (34 KiB): four blocks = 4 waves per SIMD, so the
+// arithmetic is written for instruction-level parallelism inside a wave:
+//   * exact fp64 class: per stage the 8 modular products first (independent dependency chains), ONE wave-uniform
+//     test for the rare lazy-fix case (T0 < 2^22, see ArithDp) whose repair sits out of the fast path, then the 8
+//     add / sub pairs;
+//   * relaxed fp64 class and the integer class have no per-butterfly branch to begin with.
+// Measured on MI355X (tools/proto16_check.py, 25 fp64-class limbs x 128 polynomials, exact): 855 -> 737 us per launch.
+// (The same stage-wise guard in the 8-words-per-thread kernel, 6 waves per SIMD, changes nothing: 1 185 vs 1 200 us.)
+//
+// Word order inside a step: thread w holds words p + (e << LOGDL), e = 0..15, with
+//   LOGDL = 8: p = w                       (distances 2048 .. 256; first forward step / last inverse step: global memory)
+//   LOGDL = 4: p = (w >> 4) << 8 | w & 15  (distances 128 .. 16)
+//   LOGDL = 0: p = 16 w                    (distances 8 .. 1;   last forward step / first inverse step)
+// LDS index of word L is L + (L >> 4) (one pad word per 16): the 16-consecutive-word accesses of the LOGDL = 0 step
+// (thread stride 17 words = 34 banks) and the strided ones are conflict-free for ds_read/write_b64.
+// A tile holding a word outside [0, 2q) (signed-lazy inputs) is detected before anything is stored
+// and redone stage by stage in signed integer arithmetic, exactly as the reference would compute it.
+#pragma once
+#include "ckks_ntt_core.h"
+
+#ifndef LF_TILE16
+#define LF_TILE16 1   // 0: keep the 8-words-per-thread kernels for every size (A/B switch)
+#endif
+#define NTT16_THREADS 256
+#define PAD16(L) ((L) + ((L) >> 4))
+#define NTT16_LDS_WORDS (4096 + 256)
+#define NTT16_FLAG NTT16_LDS_WORDS   // flag word behind the tile: one byte per wave
+
+namespace {
+
+// ---- register steps ----------------------------------------------------------------------------------------------
+// forward: stage u of the step uses the 2^u table entries (i0 << u) .. (cf. fwd_step)
+template <class A>
+__device__ __forceinline__ void fwd_regs16(typename A::T (&x)[16], int i0, const Ctx &c) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int du = 1 << (3 - u);
+        typename A::W wv[8];
+        A::tw_group(c, i0 << u, 1 << u, wv);
+#pragma unroll
+        for (int j = 0; j < (1 << u); ++j) {
+            const int e0 = j << (4 - u);
+#pragma unroll
+            for (int t = 0; t < du; ++t) A::fwd(c, x[e0 + t], x[e0 + t + du], wv[j], (i0 << u) + j);
+        }
+    }
+    A::fwd_end(c, x);
+}
+
+// the twiddles of the first three stages of a step (7 entries), requested ahead of the barrier in front of the step
+struct Tw16Early {
+    double w0[1], w1[2], w2[4];
+    __device__ __forceinline__ void load(const Ctx &c, int i0) {
+        ArithDp::tw_group(c, i0, 1, w0);
+        ArithDp::tw_group(c, i0 << 1, 2, w1);
+        ArithDp::tw_group(c, i0 << 2, 4, w2);
+    }
+};
+
+// exact fp64 class (ArithDp semantics, bit for bit): products of a stage first, one uniform test, then add / sub
+__device__ __forceinline__ void fwd_regs16_exact(double (&x)[16], int i0, const Ctx &c, const Tw16Early *early = nullptr) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int du = 1 << (3 - u);
+        double wv[8];
+        if (early && u < 3) {
+#pragma unroll
+            for (int j = 0; j < (1 << u); ++j) wv[j] = u == 0 ? early->w0[j & 0] : (u == 1 ? early->w1[j & 1] : early->w2[j & 3]);
+        } else {
+            ArithDp::tw_group(c, i0 << u, 1 << u, wv);
+        }
+        double V[8];
+        bool rare = false;
+#pragma unroll
+        for (int j = 0; j < (1 << u); ++j) {
+            const int e0 = j << (4 - u);
+#pragma unroll
+            for (int t = 0; t < du; ++t) {
+                V[j * du + t] = dp_mulmod(x[e0 + t + du], wv[j], c.d);
+                rare |= dp_below_fix_limit(V[j * du + t]);
+            }
+        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
+#pragma unroll
+            for (int j = 0; j < (1 << u); ++j) {
+                const int e0 = j << (4 - u);
+#pragma unroll
+                for (int t = 0; t < du; ++t) {
+                    double &v = V[j * du + t];
+                    if (dp_below_fix_limit(v))
+                        v = dp_lazy_fix(v, (u64)c.tw_mont[(i0 << u) + j], (u64)dp_reduce(x[e0 + t + du], c.d.q2, c.d.q2inv), c.d.q);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < (1 << u); ++j) {
+            const int e0 = j << (4 - u);
+#pragma unroll
+            for (int t = 0; t < du; ++t) {
+                const double U = x[e0 + t], Vv = V[j * du + t];
+                x[e0 + t] = U + Vv;
+                x[e0 + t + du] = U - Vv;
+            }
+        }
+    }
+}
+
+// inverse: stage u of the step uses the 2^(3-u) table entries (il << (3-u)) .. (cf. inv_step); A::inv_end reduces
+template <class A>
+__device__ __forceinline__ void inv_regs16(typename A::T (&x)[16], int il, const Ctx &c) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int du = 1 << u;
+        typename A::W wv[8];
+        A::tw_group(c, il << (3 - u), 1 << (3 - u), wv);
+#pragma unroll
+        for (int h = 0; h < (1 << (3 - u)); ++h) {
+            const int e0 = h << (u + 1);
+#pragma unroll
+            for (int t = 0; t < du; ++t) A::inv(c, x[e0 + t], x[e0 + t + du], wv[h], (il << (3 - u)) + h);
+        }
+    }
+    A::inv_end(c, x);
+}
+
+// exact fp64 class, inverse (ArithDp::inv semantics): O = U - V, b = lazy REDC62(S * O), a = U + V
+__device__ __forceinline__ void inv_regs16_exact(double (&x)[16], int il, const Ctx &c) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int du = 1 << u;
+        double wv[8];
+        ArithDp::tw_group(c, il << (3 - u), 1 << (3 - u), wv);
+        double O[8], V[8];
+        bool rare = false;
+#pragma unroll
+        for (int h = 0; h < (1 << (3 - u)); ++h) {
+            const int e0 = h << (u + 1);
+#pragma unroll
+            for (int t = 0; t < du; ++t) {
+                const int k = h * du + t;
+                O[k] = x[e0 + t] - x[e0 + t + du];
+                V[k] = dp_mulmod(O[k], wv[h], c.d);
+                rare |= dp_below_fix_limit(V[k]);
+            }
+        }
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
+#pragma unroll
+            for (int h = 0; h < (1 << (3 - u)); ++h) {
+#pragma unroll
+                for (int t = 0; t < du; ++t) {
+                    const int k = h * du + t;
+                    if (dp_below_fix_limit(V[k]))
+                        V[k] = dp_lazy_fix(V[k], (u64)c.tw_mont[(il << (3 - u)) + h], (u64)dp_reduce(O[k], c.d.q2, c.d.q2inv), c.d.q);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < (1 << (3 - u)); ++h) {
+            const int e0 = h << (u + 1);
+#pragma unroll
+            for (int t = 0; t < du; ++t) {
+                const int k = h * du + t;
+                x[e0 + t] = x[e0 + t] + x[e0 + t + du];
+                x[e0 + t + du] = V[k];
+            }
+        }
+    }
+    // sums doubled four times from below 2q: back to a representative in [0, 2q) (dp_reduce takes |x| < 64 * 2q)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = dp_reduce(x[e], c.d.q2, c.d.q2inv);
+}
+
+// ---- odd tiles: the reference's signed arithmetic, stage by stage (rare; any thread count) -------------------------
+__device__ __forceinline__ void tile16_slow(i64 *sm, const i64 *src, i64 *dst, int base, int s0, int logN, bool inverse, const Ctx &c) {
+    for (int L = threadIdx.x; L < 4096; L += NTT16_THREADS) sm[PAD16(L)] = src[L];
+    __syncthreads();
+    for (int j = 0; j < 12; ++j) {
+        const int st = s0 + j;
+        const int logd = inverse ? j : 11 - j;
+        for (int i = threadIdx.x; i < 2048; i += NTT16_THREADS) {
+            const int pa = ((i >> logd) << (logd + 1)) | (i & ((1 << logd) - 1)), pb = pa + (1 << logd);
+            i64 a = sm[PAD16(pa)], b = sm[PAD16(pb)];
+            if (!inverse) {
+                const int idx = (1 << st) + ((base + pa) >> (logN - st));
+                ArithInt<true>::fwd(c, a, b, c.tw_mont[idx], idx);
+            } else {
+                const int idx = (1 << (logN - st - 1)) + ((base + pa) >> (st + 1));
+                ArithInt<true>::inv(c, a, b, c.tw_mont[idx], idx);
+            }
+            sm[PAD16(pa)] = a;
+            sm[PAD16(pb)] = b;
+        }
+        __syncthreads();
+    }
+    for (int L = threadIdx.x; L < 4096; L += NTT16_THREADS) dst[L] = sm[PAD16(L)];
+}
+
+// wave v owns byte v of the flag word: every wave writes its byte, so the word needs no reset
+__device__ __forceinline__ void wave_flag_set16(i64 *sm, int pred, int w) {
+    const bool any = __builtin_amdgcn_ballot_w64(pred != 0) != 0;
+    if ((w & 63) == 0) reinterpret_cast<unsigned char *>(sm + NTT16_FLAG)[w >> 6] = any ? 1 : 0;
+}
+__device__ __forceinline__ bool tile_flagged16(const i64 *sm) { return reinterpret_cast<const unsigned *>(sm + NTT16_FLAG)[0] != 0; }
+
+// ---- forward tile: words w + 256 e in, 16 w + e out ------------------------------------------------------------------
+template <bool DP, bool RLX>
+__device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int tile, const PassGeom &g, const Ctx &c) {
+#ifdef LF16_TIDX
+    const int w = threadIdx.x;
+#else
+    const int w = lf_tid();
+#endif
+    const int base = tile << 12, E = g.logN, s = g.s0;
+#ifdef LF16_NOCHECK
+    constexpr bool CHECK = !DP;            // experiment: price of the range check in the exact fp64 class
+#else
+    constexpr bool CHECK = !(RLX && DP);   // relaxed fp64 tiles accept any word the library's own first pass wrote
+#endif
+    i64 raw[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) raw[e] = row[base + w + (e << 8)];
+    if (CHECK) {
+        int odd = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) odd |= ((u64)raw[e] >= (u64)c.m.q2);
+        wave_flag_set16(sm, odd, w);
+    }
+    const int iA = (1 << s) + (base >> (E - s));                 // tile-uniform
+    const int pB = ((w >> 4) << 8) | (w & 15);
+    const int iB = (1 << (s + 4)) + ((base + pB) >> (E - s - 4));
+    const int iC = (1 << (s + 8)) + ((base + 16 * w) >> (E - s - 8));
+    i64 o[16];
+    if (DP) {
+        double *smd = reinterpret_cast<double *>(sm);
+        double x[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[e] = RLX ? dp_from_signed(raw[e]) : dp_from_word(raw[e]);
+        if (RLX) fwd_regs16<ArithDpR>(x, iA, c);
+        else fwd_regs16_exact(x, iA, c);
+        {
+            double *sp = smd + PAD16(w);                          // PAD16(w + 256 e) = PAD16(w) + 272 e
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sp[e * 272] = x[e];
+        }
+#ifndef LF16_NO_PREFETCH
+        Tw16Early twB, twC;
+        if (!RLX) twB.load(c, iB);
+#endif
+        lds_barrier();
+        if (CHECK && tile_flagged16(sm)) {
+            __syncthreads();
+            tile16_slow(sm, row + base, row + base, base, s, E, false, c);
+            return;
+        }
+        {
+            double *sp = smd + PAD16(pB);                         // PAD16(p + 16 e) = PAD16(p) + 17 e
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x[e] = sp[e * 17];
+            if (RLX) fwd_regs16<ArithDpR>(x, iB, c);
+#ifndef LF16_NO_PREFETCH
+            else fwd_regs16_exact(x, iB, c, &twB);
+#else
+            else fwd_regs16_exact(x, iB, c);
+#endif
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sp[e * 17] = x[e];
+        }
+#ifndef LF16_NO_PREFETCH
+        if (!RLX) twC.load(c, iC);
+#endif
+        lds_barrier();
+        {
+            const double *sp = smd + 17 * w;                      // PAD16(16 w + e) = 17 w + e
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x[e] = sp[e];
+        }
+        if (RLX) fwd_regs16<ArithDpR>(x, iC, c);
+#ifndef LF16_NO_PREFETCH
+        else fwd_regs16_exact(x, iC, c, &twC);
+#else
+        else fwd_regs16_exact(x, iC, c);
+#endif
+        // the pass accumulated without subtractions: back to the lazy word in [0, 2q) (relaxed: canonical residue)
+        const double md = RLX ? c.d.q : c.d.q2, mi = RLX ? c.d.qinv : c.d.q2inv;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = dp_to_word(dp_reduce(x[e], md, mi));
+    } else {
+        {
+            i64 *sp = sm + PAD16(w);
+            fwd_regs16<ArithInt<false>>(raw, iA, c);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sp[e * 272] = raw[e];
+        }
+        lds_barrier();
+        if (tile_flagged16(sm)) {
+            __syncthreads();
+            tile16_slow(sm, row + base, row + base, base, s, E, false, c);
+            return;
+        }
+        {
+            i64 *sp = sm + PAD16(pB);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) raw[e] = sp[e * 17];
+            fwd_regs16<ArithInt<false>>(raw, iB, c);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sp[e * 17] = raw[e];
+        }
+        lds_barrier();
+        {
+            const i64 *sp = sm + 17 * w;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) raw[e] = sp[e];
+        }
+        fwd_regs16<ArithInt<false>>(raw, iC, c);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = raw[e];
+    }
+    // 16 consecutive result words per thread -> the wave's own 1024-word LDS span -> 16-byte stores, 1 KiB per instruction
+    {
+        i64 *sp = sm + 17 * w;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sp[e] = o[e];
+    }
+    wave_lds_sync();
+    const int L0 = ((w >> 6) << 10) + ((w & 63) << 1);
+    const i64 *so = sm + PAD16(L0);                              // L0 even: PAD16(L0 + 128 i + 1) = PAD16(L0) + 136 i + 1
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        longlong2 v;
+        v.x = so[i * 136];
+        v.y = so[i * 136 + 1];
+        *reinterpret_cast<longlong2 *>(row + base + L0 + (i << 7)) = v;
+    }
+}
+
+// ---- inverse tile (first pass of a two-pass inverse transform, no chain tail): 16 w + e in, w + 256 e out ------------
+template <bool DP, bool RLX>
+__device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst_row, int tile, const PassGeom &g, const Ctx &c) {
+    const int w = lf_tid();
+    const int base = tile << 12, logN = g.logN, s = g.s0;
+    constexpr bool CHECK = !(RLX && DP);   // relaxed inverse transforms take non-negative words (include/ckks_hip.h)
+    const int L0 = ((w >> 6) << 10) + ((w & 63) << 1);
+    {
+        longlong2 in[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) in[i] = *reinterpret_cast<const longlong2 *>(src_row + base + L0 + (i << 7));
+        int odd = 0;
+        i64 *sp = sm + PAD16(L0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (CHECK) odd |= ((u64)in[i].x >= (u64)c.m.q2) | ((u64)in[i].y >= (u64)c.m.q2);
+            sp[i * 136] = in[i].x;
+            sp[i * 136 + 1] = in[i].y;
+        }
+        if (CHECK) wave_flag_set16(sm, odd, w);
+    }
+    wave_lds_sync();
+    i64 raw[16];
+    {
+        const i64 *sp = sm + 17 * w;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) raw[e] = sp[e];
+    }
+    const int iC = (1 << (logN - s - 4)) + ((base + 16 * w) >> (s + 4));
+    const int pB = ((w >> 4) << 8) | (w & 15);
+    const int iB = (1 << (logN - s - 8)) + ((base + pB) >> (s + 8));
+    const int iA = (1 << (logN - s - 12)) + (base >> (s + 12));   // tile-uniform
+    i64 *out = dst_row + base + w;
+    Ctx cc = c;
+    cc.inv_reduce = 1;                                            // fp64 classes: fold at the end of every radix-16 step
+    if (DP) {
+        double *smd = reinterpret_cast<double *>(sm);
+        double x[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[e] = dp_from_word(raw[e]);
+        if (RLX) inv_regs16<ArithDpR>(x, iC, cc);
+        else inv_regs16_exact(x, iC, cc);
+        {
+            double *sp = smd + 17 * w;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sp[e] = x[e];
+        }
+        lds_barrier();
+        if (CHECK && tile_flagged16(sm)) {
+            __syncthreads();
+            tile16_slow(sm, src_row + base, dst_row + base, base, s, logN, true, c);
+            return;
+        }
+        {
+            double *sp = smd + PAD16(pB);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x[e] = sp[e * 17];
+            if (RLX) inv_regs16<ArithDpR>(x, iB, cc);
+            else inv_regs16_exact(x, iB, cc);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sp[e * 17] = x[e];
+        }
+        lds_barrier();
+        {
+            const double *sp = smd + PAD16(w);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x[e] = sp[e * 272];
+        }
+        if (RLX) inv_regs16<ArithDpR>(x, iA, cc);
+        else inv_regs16_exact(x, iA, cc);
+        // exact: the lazy word in [0, 2q); relaxed: balanced residue -> canonical
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[e << 8] = dp_to_word(RLX ? dp_addmask(x[e], c.d.q) : x[e]);
+    } else {
+        inv_regs16<ArithInt<false>>(raw, iC, cc);
+        {
+            i64 *sp = sm + 17 * w;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sp[e] = raw[e];
+        }
+        lds_barrier();
+        if (tile_flagged16(sm)) {
+            __syncthreads();
+            tile16_slow(sm, src_row + base, dst_row + base, base, s, logN, true, c);
+            return;
+        }
+        {
+            i64 *sp = sm + PAD16(pB);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) raw[e] = sp[e * 17];
+            inv_regs16<ArithInt<false>>(raw, iB, cc);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sp[e * 17] = raw[e];
+        }
+        lds_barrier();
+        {
+            const i64 *sp = sm + PAD16(w);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) raw[e] = sp[e * 272];
+        }
+        inv_regs16<ArithInt<false>>(raw, iA, cc);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[e << 8] = raw[e];
+    }
+}
+
+// ---- kernels: both arithmetic classes in one launch (integer-class blocks first), see ntt_fwd_pass_mixed -----------
+template <bool DP, bool RLX, bool INV>
+__device__ __forceinline__ void pass16_body(i64 *sm, int b, const i64 *src, i64 *dst, const PassGeom &g, const RowList &rl,
+                                            const i64 *__restrict__ tw_br, const double *__restrict__ tw_dp,
+                                            const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                            const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    int poly, crow, tile;
+    block_coords(g, rl, b, poly, crow, tile);
+    Ctx c;
+    c.m = load_mod(ql, qh, kl, kh, crow);
+    c.tw_mont = tw_br + ((i64)crow << g.logN);
+    c.tw_dp = DP ? tw_dp + ((i64)crow << g.logN) : nullptr;
+    c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
+    c.relaxed = RLX ? 1 : 0;
+    c.inv_reduce = 0;
+    const i64 off = (i64)(poly * g.rows + crow) << g.logN;
+    if (INV) inv_tile16<DP, RLX>(sm, src + off, dst + off, tile, g, c);
+    else fwd_tile16<DP, RLX>(sm, dst + off, tile, g, c);
+}
+
+template <bool RLX, bool INV>
+__global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_mixed(const i64 *src, i64 *dst, PassGeom g, ClassLists cl,
+                                                                       const i64 *__restrict__ tw_br,
+                                                                       const double *__restrict__ tw_dp,
+                                                                       const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                       const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT16_LDS_WORDS + 1];
+    const int b = blockIdx.x;
+    if (b < cl.in_blocks) {
+        if (b < cl.in_real) pass16_body<false, RLX, INV>(sm, b, src, dst, g, cl.in, tw_br, tw_dp, ql, qh, kl, kh);
+    } else {
+        pass16_body<true, RLX, INV>(sm, b - cl.in_blocks, src, dst, g, cl.dp, tw_br, tw_dp, ql, qh, kl, kh);
+    }
+}
+
+// one arithmetic class per launch (used when a transform has a single class, or LF16_SPLIT)
+template <bool DP, bool RLX, bool INV>
+__global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16(const i64 *src, i64 *dst, PassGeom g, RowList rl,
+                                                                const i64 *__restrict__ tw_br, const double *__restrict__ tw_dp,
+                                                                const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT16_LDS_WORDS + 1];
+    pass16_body<DP, RLX, INV>(sm, blockIdx.x, src, dst, g, rl, tw_br, tw_dp, ql, qh, kl, kh);
+}
+
+template <bool DP>
+inline void launch_pass16_class(bool inverse, int relaxed, unsigned blocks, hipStream_t st, const i64 *src, i64 *dst,
+                                const PassGeom &g, const RowList &rl, const i64 *tw_br, const double *tw_dp, const i64 *ql,
+                                const i64 *qh, const i64 *kl, const i64 *kh) {
+    const dim3 grid(blocks), block(NTT16_THREADS);
+    if (inverse) {
+        if (relaxed) hipLaunchKernelGGL((ntt_pass16<DP, true, true>), grid, block, 0, st, src, dst, g, rl, tw_br, tw_dp, ql, qh, kl, kh);
+        else hipLaunchKernelGGL((ntt_pass16<DP, false, true>), grid, block, 0, st, src, dst, g, rl, tw_br, tw_dp, ql, qh, kl, kh);
+    } else {
+        if (relaxed) hipLaunchKernelGGL((ntt_pass16<DP, true, false>), grid, block, 0, st, src, dst, g, rl, tw_br, tw_dp, ql, qh, kl, kh);
+        else hipLaunchKernelGGL((ntt_pass16<DP, false, false>), grid, block, 0, st, src, dst, g, rl, tw_br, tw_dp, ql, qh, kl, kh);
+    }
+}
+
+// host: the contiguous 12-stage pass of `polys` polynomials (forward: in place on dst; inverse: src -> dst, no tail)
+inline void launch_pass16(bool inverse, int relaxed, int polys, hipStream_t st, const i64 *src, i64 *dst, const PassGeom &g,
+                          const RowList &in, const RowList &dp, const i64 *tw_br, const double *tw_dp, const i64 *ql,
+                          const i64 *qh, const i64 *kl, const i64 *kh) {
+    const unsigned per_row = (unsigned)polys << (g.logN - 12);
+#ifdef LF16_SPLIT
+    const bool split = true;
+#else
+    const bool split = !(in.n && dp.n);
+#endif
+    if (split) {   // integer class first: its few, long blocks should not be the tail
+        if (in.n) launch_pass16_class<false>(inverse, relaxed, per_row * (unsigned)in.n, st, src, dst, g, in, tw_br, tw_dp, ql, qh, kl, kh);
+        if (dp.n) launch_pass16_class<true>(inverse, relaxed, per_row * (unsigned)dp.n, st, src, dst, g, dp, tw_br, tw_dp, ql, qh, kl, kh);
+        return;
+    }
+    const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
+    const dim3 grid((unsigned)cl.in_blocks + per_row * (unsigned)dp.n), block(NTT16_THREADS);
+    if (inverse) {
+        if (relaxed) hipLaunchKernelGGL((ntt_pass16_mixed<true, true>), grid, block, 0, st, src, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
+        else hipLaunchKernelGGL((ntt_pass16_mixed<false, true>), grid, block, 0, st, src, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
+    } else {
+        if (relaxed) hipLaunchKernelGGL((ntt_pass16_mixed<true, false>), grid, block, 0, st, src, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
+        else hipLaunchKernelGGL((ntt_pass16_mixed<false, false>), grid, block, 0, st, src, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
+    }
+}
+
+}  // namespace
