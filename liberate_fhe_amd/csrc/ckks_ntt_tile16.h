@@ -34,14 +34,34 @@
 namespace {
 
 // ---- register steps ----------------------------------------------------------------------------------------------
+// the twiddles of the three widest-shared stages of a step (7 entries), requested ahead of the barrier in front of it:
+// forward steps use stages 0..2 (1, 2, 4 entries at i0, 2 i0, 4 i0), inverse steps stages 1..3 (4, 2, 1 entries at
+// 4 il, 2 il, il); the remaining 8-entry stage is loaded where it is used
+template <class A>
+struct Tw16Early {
+    typename A::W w1[1], w2[2], w4[4];
+    __device__ __forceinline__ void load(const Ctx &c, int i) {
+        A::tw_group(c, i, 1, w1);
+        A::tw_group(c, i << 1, 2, w2);
+        A::tw_group(c, i << 2, 4, w4);
+    }
+    // group of `cnt` (1, 2 or 4) entries into wv
+    __device__ __forceinline__ void get(int cnt, typename A::W (&wv)[8]) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < cnt) wv[j] = cnt == 1 ? w1[0] : (cnt == 2 ? w2[j & 1] : w4[j]);
+    }
+};
+
 // forward: stage u of the step uses the 2^u table entries (i0 << u) .. (cf. fwd_step)
 template <class A>
-__device__ __forceinline__ void fwd_regs16(typename A::T (&x)[16], int i0, const Ctx &c) {
+__device__ __forceinline__ void fwd_regs16(typename A::T (&x)[16], int i0, const Ctx &c, const Tw16Early<A> *early = nullptr) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int du = 1 << (3 - u);
         typename A::W wv[8];
-        A::tw_group(c, i0 << u, 1 << u, wv);
+        if (early && u < 3) early->get(1 << u, wv);
+        else A::tw_group(c, i0 << u, 1 << u, wv);
 #pragma unroll
         for (int j = 0; j < (1 << u); ++j) {
             const int e0 = j << (4 - u);
@@ -52,28 +72,14 @@ __device__ __forceinline__ void fwd_regs16(typename A::T (&x)[16], int i0, const
     A::fwd_end(c, x);
 }
 
-// the twiddles of the first three stages of a step (7 entries), requested ahead of the barrier in front of the step
-struct Tw16Early {
-    double w0[1], w1[2], w2[4];
-    __device__ __forceinline__ void load(const Ctx &c, int i0) {
-        ArithDp::tw_group(c, i0, 1, w0);
-        ArithDp::tw_group(c, i0 << 1, 2, w1);
-        ArithDp::tw_group(c, i0 << 2, 4, w2);
-    }
-};
-
 // exact fp64 class (ArithDp semantics, bit for bit): products of a stage first, one uniform test, then add / sub
-__device__ __forceinline__ void fwd_regs16_exact(double (&x)[16], int i0, const Ctx &c, const Tw16Early *early = nullptr) {
+__device__ __forceinline__ void fwd_regs16_exact(double (&x)[16], int i0, const Ctx &c, const Tw16Early<ArithDp> *early = nullptr) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int du = 1 << (3 - u);
         double wv[8];
-        if (early && u < 3) {
-#pragma unroll
-            for (int j = 0; j < (1 << u); ++j) wv[j] = u == 0 ? early->w0[j & 0] : (u == 1 ? early->w1[j & 1] : early->w2[j & 3]);
-        } else {
-            ArithDp::tw_group(c, i0 << u, 1 << u, wv);
-        }
+        if (early && u < 3) early->get(1 << u, wv);
+        else ArithDp::tw_group(c, i0 << u, 1 << u, wv);
         double V[8];
         bool rare = false;
 #pragma unroll
@@ -112,12 +118,13 @@ __device__ __forceinline__ void fwd_regs16_exact(double (&x)[16], int i0, const 
 
 // inverse: stage u of the step uses the 2^(3-u) table entries (il << (3-u)) .. (cf. inv_step); A::inv_end reduces
 template <class A>
-__device__ __forceinline__ void inv_regs16(typename A::T (&x)[16], int il, const Ctx &c) {
+__device__ __forceinline__ void inv_regs16(typename A::T (&x)[16], int il, const Ctx &c, const Tw16Early<A> *early = nullptr) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int du = 1 << u;
         typename A::W wv[8];
-        A::tw_group(c, il << (3 - u), 1 << (3 - u), wv);
+        if (early && u > 0) early->get(1 << (3 - u), wv);
+        else A::tw_group(c, il << (3 - u), 1 << (3 - u), wv);
 #pragma unroll
         for (int h = 0; h < (1 << (3 - u)); ++h) {
             const int e0 = h << (u + 1);
@@ -129,12 +136,13 @@ __device__ __forceinline__ void inv_regs16(typename A::T (&x)[16], int il, const
 }
 
 // exact fp64 class, inverse (ArithDp::inv semantics): O = U - V, b = lazy REDC62(S * O), a = U + V
-__device__ __forceinline__ void inv_regs16_exact(double (&x)[16], int il, const Ctx &c) {
+__device__ __forceinline__ void inv_regs16_exact(double (&x)[16], int il, const Ctx &c, const Tw16Early<ArithDp> *early = nullptr) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int du = 1 << u;
         double wv[8];
-        ArithDp::tw_group(c, il << (3 - u), 1 << (3 - u), wv);
+        if (early && u > 0) early->get(1 << (3 - u), wv);
+        else ArithDp::tw_group(c, il << (3 - u), 1 << (3 - u), wv);
         double O[8], V[8];
         bool rare = false;
 #pragma unroll
@@ -207,20 +215,66 @@ __device__ __forceinline__ void wave_flag_set16(i64 *sm, int pred, int w) {
 }
 __device__ __forceinline__ bool tile_flagged16(const i64 *sm) { return reinterpret_cast<const unsigned *>(sm + NTT16_FLAG)[0] != 0; }
 
+template <bool RLX> struct DpArith { typedef ArithDp type; };
+template <> struct DpArith<true> { typedef ArithDpR type; };
+
+// one radix-16 step of arithmetic class A in mode RLX (the exact fp64 class has its own stage-wise routine)
+template <class A, bool EXACT_DP>
+__device__ __forceinline__ void fwd_step16(typename A::T (&x)[16], int i0, const Ctx &c, const Tw16Early<A> *early) {
+    if constexpr (EXACT_DP) fwd_regs16_exact(x, i0, c, early);
+    else fwd_regs16<A>(x, i0, c, early);
+}
+template <class A, bool EXACT_DP>
+__device__ __forceinline__ void inv_step16(typename A::T (&x)[16], int il, const Ctx &c, const Tw16Early<A> *early) {
+    if constexpr (EXACT_DP) inv_regs16_exact(x, il, c, early);
+    else inv_regs16<A>(x, il, c, early);
+}
+
 // ---- forward tile: words w + 256 e in, 16 w + e out ------------------------------------------------------------------
+// A = arithmetic class of the limb; T = its word type in LDS (double / i64).  The twiddles of the next step's first
+// three stages are requested before the barrier that ends the current one.
+template <class A, bool DP, bool RLX>
+__device__ __forceinline__ bool fwd_tile16_steps(typename A::T *smt, const i64 *sm, typename A::T (&x)[16], int w, int base,
+                                                 int E, int s, const Ctx &c, bool check) {
+    constexpr bool EX = DP && !RLX;
+    const int iA = (1 << s) + (base >> (E - s));                 // tile-uniform
+    const int pB = ((w >> 4) << 8) | (w & 15);
+    const int iB = (1 << (s + 4)) + ((base + pB) >> (E - s - 4));
+    const int iC = (1 << (s + 8)) + ((base + 16 * w) >> (E - s - 8));
+    Tw16Early<A> twB, twC;
+    fwd_step16<A, EX>(x, iA, c, nullptr);
+    {
+        typename A::T *sp = smt + PAD16(w);                      // PAD16(w + 256 e) = PAD16(w) + 272 e
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sp[e * 272] = x[e];
+    }
+    twB.load(c, iB);
+    lds_barrier();
+    if (check && tile_flagged16(sm)) return false;
+    {
+        typename A::T *sp = smt + PAD16(pB);                     // PAD16(p + 16 e) = PAD16(p) + 17 e
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[e] = sp[e * 17];
+        fwd_step16<A, EX>(x, iB, c, &twB);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sp[e * 17] = x[e];
+    }
+    twC.load(c, iC);
+    lds_barrier();
+    {
+        const typename A::T *sp = smt + 17 * w;                  // PAD16(16 w + e) = 17 w + e
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[e] = sp[e];
+    }
+    fwd_step16<A, EX>(x, iC, c, &twC);
+    return true;
+}
+
 template <bool DP, bool RLX>
 __device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int tile, const PassGeom &g, const Ctx &c) {
-#ifdef LF16_TIDX
-    const int w = threadIdx.x;
-#else
     const int w = lf_tid();
-#endif
     const int base = tile << 12, E = g.logN, s = g.s0;
-#ifdef LF16_NOCHECK
-    constexpr bool CHECK = !DP;            // experiment: price of the range check in the exact fp64 class
-#else
     constexpr bool CHECK = !(RLX && DP);   // relaxed fp64 tiles accept any word the library's own first pass wrote
-#endif
     i64 raw[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) raw[e] = row[base + w + (e << 8)];
@@ -230,95 +284,27 @@ __device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int t
         for (int e = 0; e < 16; ++e) odd |= ((u64)raw[e] >= (u64)c.m.q2);
         wave_flag_set16(sm, odd, w);
     }
-    const int iA = (1 << s) + (base >> (E - s));                 // tile-uniform
-    const int pB = ((w >> 4) << 8) | (w & 15);
-    const int iB = (1 << (s + 4)) + ((base + pB) >> (E - s - 4));
-    const int iC = (1 << (s + 8)) + ((base + 16 * w) >> (E - s - 8));
     i64 o[16];
+    bool ok;
     if (DP) {
-        double *smd = reinterpret_cast<double *>(sm);
+        typedef typename DpArith<RLX>::type AD;
         double x[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) x[e] = RLX ? dp_from_signed(raw[e]) : dp_from_word(raw[e]);
-        if (RLX) fwd_regs16<ArithDpR>(x, iA, c);
-        else fwd_regs16_exact(x, iA, c);
-        {
-            double *sp = smd + PAD16(w);                          // PAD16(w + 256 e) = PAD16(w) + 272 e
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sp[e * 272] = x[e];
-        }
-#ifndef LF16_NO_PREFETCH
-        Tw16Early twB, twC;
-        if (!RLX) twB.load(c, iB);
-#endif
-        lds_barrier();
-        if (CHECK && tile_flagged16(sm)) {
-            __syncthreads();
-            tile16_slow(sm, row + base, row + base, base, s, E, false, c);
-            return;
-        }
-        {
-            double *sp = smd + PAD16(pB);                         // PAD16(p + 16 e) = PAD16(p) + 17 e
-#pragma unroll
-            for (int e = 0; e < 16; ++e) x[e] = sp[e * 17];
-            if (RLX) fwd_regs16<ArithDpR>(x, iB, c);
-#ifndef LF16_NO_PREFETCH
-            else fwd_regs16_exact(x, iB, c, &twB);
-#else
-            else fwd_regs16_exact(x, iB, c);
-#endif
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sp[e * 17] = x[e];
-        }
-#ifndef LF16_NO_PREFETCH
-        if (!RLX) twC.load(c, iC);
-#endif
-        lds_barrier();
-        {
-            const double *sp = smd + 17 * w;                      // PAD16(16 w + e) = 17 w + e
-#pragma unroll
-            for (int e = 0; e < 16; ++e) x[e] = sp[e];
-        }
-        if (RLX) fwd_regs16<ArithDpR>(x, iC, c);
-#ifndef LF16_NO_PREFETCH
-        else fwd_regs16_exact(x, iC, c, &twC);
-#else
-        else fwd_regs16_exact(x, iC, c);
-#endif
+        ok = fwd_tile16_steps<AD, true, RLX>(reinterpret_cast<double *>(sm), sm, x, w, base, E, s, c, CHECK);
         // the pass accumulated without subtractions: back to the lazy word in [0, 2q) (relaxed: canonical residue)
         const double md = RLX ? c.d.q : c.d.q2, mi = RLX ? c.d.qinv : c.d.q2inv;
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[e] = dp_to_word(dp_reduce(x[e], md, mi));
     } else {
-        {
-            i64 *sp = sm + PAD16(w);
-            fwd_regs16<ArithInt<false>>(raw, iA, c);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sp[e * 272] = raw[e];
-        }
-        lds_barrier();
-        if (tile_flagged16(sm)) {
-            __syncthreads();
-            tile16_slow(sm, row + base, row + base, base, s, E, false, c);
-            return;
-        }
-        {
-            i64 *sp = sm + PAD16(pB);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) raw[e] = sp[e * 17];
-            fwd_regs16<ArithInt<false>>(raw, iB, c);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sp[e * 17] = raw[e];
-        }
-        lds_barrier();
-        {
-            const i64 *sp = sm + 17 * w;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) raw[e] = sp[e];
-        }
-        fwd_regs16<ArithInt<false>>(raw, iC, c);
+        ok = fwd_tile16_steps<ArithInt<false>, false, RLX>(sm, sm, raw, w, base, E, s, c, true);
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[e] = raw[e];
+    }
+    if (!ok) {   // a word outside [0, 2q): nothing has been stored yet
+        __syncthreads();
+        tile16_slow(sm, row + base, row + base, base, s, E, false, c);
+        return;
     }
     // 16 consecutive result words per thread -> the wave's own 1024-word LDS span -> 16-byte stores, 1 KiB per instruction
     {
@@ -339,6 +325,42 @@ __device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int t
 }
 
 // ---- inverse tile (first pass of a two-pass inverse transform, no chain tail): 16 w + e in, w + 256 e out ------------
+template <class A, bool DP, bool RLX>
+__device__ __forceinline__ bool inv_tile16_steps(typename A::T *smt, const i64 *sm, typename A::T (&x)[16], int w, int base,
+                                                 int logN, int s, const Ctx &c, bool check) {
+    constexpr bool EX = DP && !RLX;
+    const int iC = (1 << (logN - s - 4)) + ((base + 16 * w) >> (s + 4));
+    const int pB = ((w >> 4) << 8) | (w & 15);
+    const int iB = (1 << (logN - s - 8)) + ((base + pB) >> (s + 8));
+    const int iA = (1 << (logN - s - 12)) + (base >> (s + 12));   // tile-uniform
+    Tw16Early<A> twB;
+    inv_step16<A, EX>(x, iC, c, nullptr);
+    {
+        typename A::T *sp = smt + 17 * w;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sp[e] = x[e];
+    }
+    twB.load(c, iB);
+    lds_barrier();
+    if (check && tile_flagged16(sm)) return false;
+    {
+        typename A::T *sp = smt + PAD16(pB);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[e] = sp[e * 17];
+        inv_step16<A, EX>(x, iB, c, &twB);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sp[e * 17] = x[e];
+    }
+    lds_barrier();
+    {
+        const typename A::T *sp = smt + PAD16(w);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[e] = sp[e * 272];
+    }
+    inv_step16<A, EX>(x, iA, c, nullptr);                         // tile-uniform twiddles: scalar loads
+    return true;
+}
+
 template <bool DP, bool RLX>
 __device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst_row, int tile, const PassGeom &g, const Ctx &c) {
     const int w = lf_tid();
@@ -366,81 +388,30 @@ __device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst
 #pragma unroll
         for (int e = 0; e < 16; ++e) raw[e] = sp[e];
     }
-    const int iC = (1 << (logN - s - 4)) + ((base + 16 * w) >> (s + 4));
-    const int pB = ((w >> 4) << 8) | (w & 15);
-    const int iB = (1 << (logN - s - 8)) + ((base + pB) >> (s + 8));
-    const int iA = (1 << (logN - s - 12)) + (base >> (s + 12));   // tile-uniform
     i64 *out = dst_row + base + w;
     Ctx cc = c;
     cc.inv_reduce = 1;                                            // fp64 classes: fold at the end of every radix-16 step
+    bool ok;
     if (DP) {
-        double *smd = reinterpret_cast<double *>(sm);
+        typedef typename DpArith<RLX>::type AD;
         double x[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) x[e] = dp_from_word(raw[e]);
-        if (RLX) inv_regs16<ArithDpR>(x, iC, cc);
-        else inv_regs16_exact(x, iC, cc);
-        {
-            double *sp = smd + 17 * w;
+        ok = inv_tile16_steps<AD, true, RLX>(reinterpret_cast<double *>(sm), sm, x, w, base, logN, s, cc, CHECK);
+        if (ok) {   // exact: the lazy word in [0, 2q); relaxed: balanced residue -> canonical
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sp[e] = x[e];
+            for (int e = 0; e < 16; ++e) out[e << 8] = dp_to_word(RLX ? dp_addmask(x[e], c.d.q) : x[e]);
         }
-        lds_barrier();
-        if (CHECK && tile_flagged16(sm)) {
-            __syncthreads();
-            tile16_slow(sm, src_row + base, dst_row + base, base, s, logN, true, c);
-            return;
-        }
-        {
-            double *sp = smd + PAD16(pB);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) x[e] = sp[e * 17];
-            if (RLX) inv_regs16<ArithDpR>(x, iB, cc);
-            else inv_regs16_exact(x, iB, cc);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sp[e * 17] = x[e];
-        }
-        lds_barrier();
-        {
-            const double *sp = smd + PAD16(w);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) x[e] = sp[e * 272];
-        }
-        if (RLX) inv_regs16<ArithDpR>(x, iA, cc);
-        else inv_regs16_exact(x, iA, cc);
-        // exact: the lazy word in [0, 2q); relaxed: balanced residue -> canonical
-#pragma unroll
-        for (int e = 0; e < 16; ++e) out[e << 8] = dp_to_word(RLX ? dp_addmask(x[e], c.d.q) : x[e]);
     } else {
-        inv_regs16<ArithInt<false>>(raw, iC, cc);
-        {
-            i64 *sp = sm + 17 * w;
+        ok = inv_tile16_steps<ArithInt<false>, false, RLX>(sm, sm, raw, w, base, logN, s, cc, true);
+        if (ok) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sp[e] = raw[e];
+            for (int e = 0; e < 16; ++e) out[e << 8] = raw[e];
         }
-        lds_barrier();
-        if (tile_flagged16(sm)) {
-            __syncthreads();
-            tile16_slow(sm, src_row + base, dst_row + base, base, s, logN, true, c);
-            return;
-        }
-        {
-            i64 *sp = sm + PAD16(pB);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) raw[e] = sp[e * 17];
-            inv_regs16<ArithInt<false>>(raw, iB, cc);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sp[e * 17] = raw[e];
-        }
-        lds_barrier();
-        {
-            const i64 *sp = sm + PAD16(w);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) raw[e] = sp[e * 272];
-        }
-        inv_regs16<ArithInt<false>>(raw, iA, cc);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) out[e << 8] = raw[e];
+    }
+    if (!ok) {
+        __syncthreads();
+        tile16_slow(sm, src_row + base, dst_row + base, base, s, logN, true, c);
     }
 }
 
