@@ -81,17 +81,19 @@ __device__ __forceinline__ void fwd_regs16_exact(double (&x)[16], int i0, const 
         if (early && u < 3) early->get(1 << u, wv);
         else ArithDp::tw_group(c, i0 << u, 1 << u, wv);
         double V[8];
-        bool rare = false;
 #pragma unroll
         for (int j = 0; j < (1 << u); ++j) {
             const int e0 = j << (4 - u);
 #pragma unroll
-            for (int t = 0; t < du; ++t) {
-                V[j * du + t] = dp_mulmod(x[e0 + t + du], wv[j], c.d);
-                rare |= dp_below_fix_limit(V[j * du + t]);
-            }
+            for (int t = 0; t < du; ++t) V[j * du + t] = dp_mulmod(x[e0 + t + du], wv[j], c.d);
         }
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
+        // smallest high word of the 8 canonical products (signed: -0.0 counts as below, like dp_below_fix_limit):
+        // four three-way minima and one compare instead of eight compares
+        int hmin = min(min(__double2hiint(V[0]), __double2hiint(V[1])), __double2hiint(V[2]));
+        hmin = min(min(hmin, __double2hiint(V[3])), __double2hiint(V[4]));
+        hmin = min(min(hmin, __double2hiint(V[5])), __double2hiint(V[6]));
+        hmin = min(hmin, __double2hiint(V[7]));
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(hmin < 0x41500000) != 0, 0)) {
 #pragma unroll
             for (int j = 0; j < (1 << u); ++j) {
                 const int e0 = j << (4 - u);
@@ -144,7 +146,6 @@ __device__ __forceinline__ void inv_regs16_exact(double (&x)[16], int il, const 
         if (early && u > 0) early->get(1 << (3 - u), wv);
         else ArithDp::tw_group(c, il << (3 - u), 1 << (3 - u), wv);
         double O[8], V[8];
-        bool rare = false;
 #pragma unroll
         for (int h = 0; h < (1 << (3 - u)); ++h) {
             const int e0 = h << (u + 1);
@@ -153,10 +154,13 @@ __device__ __forceinline__ void inv_regs16_exact(double (&x)[16], int il, const 
                 const int k = h * du + t;
                 O[k] = x[e0 + t] - x[e0 + t + du];
                 V[k] = dp_mulmod(O[k], wv[h], c.d);
-                rare |= dp_below_fix_limit(V[k]);
             }
         }
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
+        int hmin = min(min(__double2hiint(V[0]), __double2hiint(V[1])), __double2hiint(V[2]));
+        hmin = min(min(hmin, __double2hiint(V[3])), __double2hiint(V[4]));
+        hmin = min(min(hmin, __double2hiint(V[5])), __double2hiint(V[6]));
+        hmin = min(hmin, __double2hiint(V[7]));
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(hmin < 0x41500000) != 0, 0)) {
 #pragma unroll
             for (int h = 0; h < (1 << (3 - u)); ++h) {
 #pragma unroll
