@@ -49,9 +49,9 @@ try:
     r = bench["roofline"]
     lines += ["", f"# bench.py (un-profiled run of the same box): value {bench['value']:.0f} poly-NTT/s, ms_per_step {bench['ms_per_step']:.4f};",
               f"# roofline leg (lf_ntt_pass which = 2, {r['launches_timed']} launches): avg_launch_ms {r['avg_launch_ms']:.4f} from HIP events;",
-              f"# the last {r['launches_timed']} ntt_fwd_pass_mixed<false> dispatches of the trace above are that leg."]
+              f"# the last {r['launches_timed']} tiled-pass dispatches (ntt_pass16_mixed<false, false>) of the trace above are that leg."]
     durs = [d[0] / 1e3 for d in q(os.path.join(src, f"prof_{TAG}", "stats_results.db"),
-                                  "select duration from kernels where name like '%ntt_fwd_pass_mixed<false>%' order by start")]
+                                  "select duration from kernels where (name like '%ntt_fwd_pass_mixed<false>%' or name like '%ntt_pass16_mixed<false, false>%') order by start")]
     tail = durs[-int(r["launches_timed"]):]
     lines.append(f"# their average under rocprofv3: {sum(tail) / len(tail):.2f} us (min {min(tail):.2f}, max {max(tail):.2f})")
 except Exception as e:
@@ -65,7 +65,7 @@ pm = [f"# rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --no-ext
       "# kernel/grid | us | FETCH_SIZE KiB (raw) | read MB (x2, gfx950) | WRITE_SIZE KiB | write MB | moved TB/s | VALU wave-instr | VALU busy | CU busy", ""]
 traffic = {"batch_per_gpu": 128}
 for key in sorted(f):
-    if "ntt_" not in key[0]:
+    if "ntt_" not in key[0] or "cols_mixed" not in key[0] and "pass16" not in key[0] and "fwd_pass" not in key[0]:
         continue
     rd, wr = 2 * f[key]["FETCH_SIZE"] * 1024, w[key]["WRITE_SIZE"] * 1024
     us = v[key]["us"]
@@ -73,7 +73,7 @@ for key in sorted(f):
     valu_busy = v[key]["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (v[key]["SQ_BUSY_CU_CYCLES"] / 256)
     pm.append(f"{key[0]}/g{key[1]} | {us:8.1f} | {f[key]['FETCH_SIZE']:10.1f} | {rd / 1e6:8.1f} | {w[key]['WRITE_SIZE']:10.1f} | {wr / 1e6:8.1f} | "
               f"{(rd + wr) / us / 1e6:5.2f} | {v[key]['SQ_INSTS_VALU']:.4g} | {valu_busy:5.3f} | cycles/CU {v[key]['SQ_BUSY_CU_CYCLES'] / 256:.4g} (~{clk_cu:.2f} GHz x launch)")
-    name = "ntt_fwd_pass_mixed" if "fwd_pass" in key[0] else "ntt_fwd_cols_mixed"
+    name = "ntt_fwd_pass_mixed" if ("fwd_pass" in key[0] or "pass16" in key[0]) else "ntt_fwd_cols_mixed"
     traffic[f"{name}_bytes_per_launch"] = rd + wr
     traffic[f"{name}_valu_wave_instr_per_launch"] = v[key]["SQ_INSTS_VALU"]
     traffic[f"{name}_valu_busy_frac"] = valu_busy
