@@ -388,65 +388,8 @@ struct StepTw {
 };
 
 // the three stages of a forward radix-8 step on 8 words held in registers (x[e] = word at distance e << LOGDL)
-#ifdef LF_STAGE_GUARD
-// exact fp64 class: per stage the 4 products first (independent chains), ONE wave-uniform test for the rare lazy-fix
-// case (the repair leaves the fast path), then the 4 add / sub pairs
-template <int LOGDL>
-__device__ __forceinline__ void fwd_regs8_dp_exact(double (&x)[8], const StepTw<ArithDp, LOGDL> &tw, const Ctx &c) {
-    auto stage = [&](const int (&ia)[4], const int (&ib)[4], const double (&w)[4], const int (&idx)[4]) {
-        double V[4];
-        bool rare = false;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            V[k] = dp_mulmod(x[ib[k]], w[k], c.d);
-            rare |= dp_below_fix_limit(V[k]);
-        }
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (dp_below_fix_limit(V[k]))
-                    V[k] = dp_lazy_fix(V[k], (u64)c.tw_mont[idx[k]], (u64)dp_reduce(x[ib[k]], c.d.q2, c.d.q2inv), c.d.q);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double U = x[ia[k]];
-            x[ia[k]] = U + V[k];
-            x[ib[k]] = U - V[k];
-        }
-    };
-    {
-        const int ia[4] = {0, 1, 2, 3}, ib[4] = {4, 5, 6, 7}, idx[4] = {tw.i0, tw.i0, tw.i0, tw.i0};
-        const double w[4] = {tw.w0[0], tw.w0[0], tw.w0[0], tw.w0[0]};
-        stage(ia, ib, w, idx);
-    }
-    {
-        const int ia[4] = {0, 1, 4, 5}, ib[4] = {2, 3, 6, 7};
-        const int idx[4] = {tw.i0 << 1, tw.i0 << 1, (tw.i0 << 1) + 1, (tw.i0 << 1) + 1};
-        const double w[4] = {tw.w1[0], tw.w1[0], tw.w1[1], tw.w1[1]};
-        stage(ia, ib, w, idx);
-    }
-    {
-        const int ia[4] = {0, 2, 4, 6}, ib[4] = {1, 3, 5, 7};
-        const int idx[4] = {tw.i0 << 2, (tw.i0 << 2) + 1, (tw.i0 << 2) + 2, (tw.i0 << 2) + 3};
-        const double w[4] = {tw.w2[0], tw.w2[1], tw.w2[2], tw.w2[3]};
-        stage(ia, ib, w, idx);
-    }
-}
-#endif
-
-template <class A> struct is_dp_exact { static constexpr bool value = false; };
-template <> struct is_dp_exact<ArithDp> { static constexpr bool value = true; };
-
 template <class A, int LOGDL>
 __device__ __forceinline__ void fwd_regs8(typename A::T (&x)[8], const StepTw<A, LOGDL> &tw, const Ctx &c) {
-#ifdef LF_STAGE_GUARD
-    if constexpr (is_dp_exact<A>::value) {
-        if (!c.relaxed) {
-            fwd_regs8_dp_exact<LOGDL>(x, tw, c);
-            return;
-        }
-    }
-#endif
 #pragma unroll
     for (int t = 0; t < 4; ++t) A::fwd(c, x[t], x[t + 4], tw.w0[0], tw.i0);
 #pragma unroll

@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_mixed(const i64 *
     }
 }
 
-// one arithmetic class per launch (used when a transform has a single class, or LF16_SPLIT)
+// one arithmetic class per launch (used when a transform has a single class)
 template <bool DP, bool RLX, bool INV>
 __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16(const i64 *src, i64 *dst, PassGeom g, RowList rl,
                                                                 const i64 *__restrict__ tw_br, const double *__restrict__ tw_dp,
@@ -483,11 +483,7 @@ inline void launch_pass16(bool inverse, int relaxed, int polys, hipStream_t st, 
                           const RowList &in, const RowList &dp, const i64 *tw_br, const double *tw_dp, const i64 *ql,
                           const i64 *qh, const i64 *kl, const i64 *kh) {
     const unsigned per_row = (unsigned)polys << (g.logN - 12);
-#ifdef LF16_SPLIT
-    const bool split = true;
-#else
-    const bool split = !(in.n && dp.n);
-#endif
+    const bool split = !(in.n && dp.n);   // a single class: its own instantiation (no register cost of the other)
     if (split) {   // integer class first: its few, long blocks should not be the tail
         if (in.n) launch_pass16_class<false>(inverse, relaxed, per_row * (unsigned)in.n, st, src, dst, g, in, tw_br, tw_dp, ql, qh, kl, kh);
         if (dp.n) launch_pass16_class<true>(inverse, relaxed, per_row * (unsigned)dp.n, st, src, dst, g, dp, tw_br, tw_dp, ql, qh, kl, kh);
