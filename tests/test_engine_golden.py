@@ -298,3 +298,41 @@ def test_ks_fwd_groups_plus_tail_equal_ks_core(name, splits):
         eng.backend.ks_fwd(st, first, count, rows, logN, desc, E, Ed, ext2, tw, cs)
     eng.backend.ks_tail(nparts, rows, logN, kp, tabs["first_part"], eng.ntt.starts[level][d], ext2, s2, itw, ninv, cs)
     assert torch.equal(ext1, ext2) and torch.equal(s1, s2)
+
+
+@pytest.mark.gpu
+def test_c3_silver_cc_mult_decode_within_2_pow_minus_30_of_the_checker():
+    """BASELINE configs[2] / SURVEY §8(d) C3: silver cc_mult + relinearize with REAL keys and ciphertexts (HIP samplers)
+    on the HIP engine and, on the very same tensors, on the checker engine (reference composition over the C oracle):
+    the integer ciphertexts are identical, so the decoded slots differ by less than 2^-30 relative — by exactly 0."""
+    from liberate_fhe_amd.fhe import ckks_engine, presets
+    from tests.oracle_backend import OracleBackend
+    params = {k: v for k, v in presets.params["silver"].items() if k != "devices"}
+    hip = ckks_engine(devices=["cuda:0"], **params)
+    chk = ckks_engine(devices=["cpu"], backend=OracleBackend(), **params)
+
+    def to_cpu(x):
+        if isinstance(x, torch.Tensor):
+            return x.cpu().clone()
+        if hasattr(x, "_replace") and hasattr(x, "data"):
+            return x._replace(data=to_cpu(x.data))
+        if isinstance(x, tuple):
+            return tuple(to_cpu(y) for y in x)
+        if isinstance(x, list):
+            return [to_cpu(y) for y in x]
+        return x
+
+    sk = hip.create_secret_key()
+    pk, evk = hip.create_public_key(sk), hip.create_evk(sk)
+    np.random.seed(11)
+    m1, m2 = hip.example(-1, 1), hip.example(-1, 1)
+    c1, c2 = hip.encorypt(m1, pk), hip.encorypt(m2, pk)
+    prod_hip = hip.cc_mult(c1, c2, evk)
+    prod_chk = chk.cc_mult(to_cpu(c1), to_cpu(c2), to_cpu(evk))
+    for a, b in zip(prod_hip.data, prod_chk.data):
+        assert torch.equal(a[0].cpu(), b[0])
+    dec_hip = hip.decrode(prod_hip, sk)
+    dec_chk = chk.decrode(prod_chk, to_cpu(sk))
+    rel = np.abs(dec_hip - dec_chk).max() / np.abs(dec_chk).max()
+    assert rel < 2.0 ** -30, rel
+    assert np.abs(dec_hip - m1 * m2).max() < 2e-7        # and both are the product, to CKKS accuracy
