@@ -138,6 +138,91 @@ void launch_cols_mixed_rs(int K, unsigned per_limb, hipStream_t st, i64 *base, c
     }
 }
 
+// ---- chunked forward transform: tiled pass of one chunk and column pass of the NEXT chunk in one launch ---------
+// The column pass is HBM-bound with idle issue slots, the tiled pass issue-bound with idle HBM; launches on one
+// stream serialise and launches on two streams only overlap in their tails (measured).  So a large
+// batch is cut into chunks and launch k carries BOTH roles: blocks alternate in runs of 8 (one per XCD, so every
+// XCD — every CU — holds a mix) between tiles of chunk k-1 and columns of chunk k.  The dependency (tiles of a
+// chunk after its columns) is the launch order.  `ratio` column blocks per tile block: 16 >> K.
+struct DuoGeom {
+    PassGeom tile, col;
+    int tile_in_blocks, tile_in_real, tile_blocks;
+    int col_in_blocks, col_in_real, col_blocks;
+    int ratio;
+};
+
+template <int K, bool RLX>
+__global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_fwd_duo(i64 *tile_base, i64 *col_base, DuoGeom d, RowList in, RowList dp,
+                                                                 const i64 *__restrict__ psi_br, const double *__restrict__ psi_dp,
+                                                                 const i64 *__restrict__ Rs, const i64 *__restrict__ ql,
+                                                                 const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                                                 const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT16_LDS_WORDS + 1];
+    const int x = blockIdx.x & 7, oct = blockIdx.x >> 3;
+    // ratio 1 (logN 16): strict alternation would hand every other workgroup of an XCD — i.e. one role — to the same
+    // half of its shader engines / CUs (the dispatcher walks them round-robin; measured: each role then runs on half
+    // the chip).  The Thue-Morse order (role = parity of the bits of the index) is balanced on every residue class
+    // modulo a power of two, and the pair (2i, 2i+1) always holds one block of each role, so the rank is oct >> 1.
+    const int period = 1 + d.ratio;
+    int pos, grp;
+    if (d.ratio == 1) pos = __builtin_popcount((unsigned)oct) & 1, grp = oct >> 1;
+    else pos = oct % period, grp = oct / period;
+    if (pos == 0) {
+        const int b = grp * 8 + x;
+        if (b >= d.tile_blocks) return;
+        if (b < d.tile_in_blocks) {
+            if (b < d.tile_in_real) pass16_body<false, RLX, false>(sm, b, tile_base, tile_base, d.tile, in, psi_br, psi_dp, ql, qh, kl, kh);
+        } else {
+            pass16_body<true, RLX, false>(sm, b - d.tile_in_blocks, tile_base, tile_base, d.tile, dp, psi_br, psi_dp, ql, qh, kl, kh);
+        }
+    } else {
+        const int b = (grp * d.ratio + pos - 1) * 8 + x;
+        if (b >= d.col_blocks) return;
+        if (b < d.col_in_blocks) {
+            if (b < d.col_in_real) fwd_cols_body<false, K>(b, col_base, d.col, in, psi_br, psi_dp, Rs, ql, qh, kl, kh);
+        } else {
+            fwd_cols_body<true, K>(b - d.col_in_blocks, col_base, d.col, dp, psi_br, psi_dp, Rs, ql, qh, kl, kh);
+        }
+    }
+}
+
+template <int K>
+void launch_duo_k(bool relaxed, unsigned blocks, hipStream_t st, i64 *tile_base, i64 *col_base, const DuoGeom &d,
+                  const RowList &in, const RowList &dp, const int64_t *psi_br, const double *psi_dp, const i64 *rs,
+                  const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh) {
+    if (relaxed)
+        hipLaunchKernelGGL((ntt_fwd_duo<K, true>), dim3(blocks), dim3(NTT16_THREADS), 0, st, tile_base, col_base, d, in, dp,
+                           (const i64 *)psi_br, psi_dp, rs, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+    else
+        hipLaunchKernelGGL((ntt_fwd_duo<K, false>), dim3(blocks), dim3(NTT16_THREADS), 0, st, tile_base, col_base, d, in, dp,
+                           (const i64 *)psi_br, psi_dp, rs, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+}
+
+// tiles of `tile_polys` polynomials at tile_base + columns of `col_polys` polynomials at col_base
+void launch_duo(int K, bool relaxed, hipStream_t st, i64 *tile_base, int tile_polys, i64 *col_base, int col_polys,
+                const PassGeom &gt, const PassGeom &gc, const RowList &in, const RowList &dp, const int64_t *psi_br,
+                const double *psi_dp, const i64 *rs, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh) {
+    DuoGeom d;
+    d.tile = gt, d.col = gc;
+    d.tile.batch = tile_polys, d.col.batch = col_polys;
+    const unsigned per_row = (unsigned)tile_polys << K, per_limb = (unsigned)col_polys * ((1u << NTT_TILE_LOG_MAX) / NTT_COL_THREADS);
+    d.tile_in_real = (int)(per_row * (unsigned)in.n), d.tile_in_blocks = (d.tile_in_real + 7) & ~7;
+    d.tile_blocks = d.tile_in_blocks + (int)(per_row * (unsigned)dp.n);
+    d.col_in_real = (int)(per_limb * (unsigned)in.n), d.col_in_blocks = (d.col_in_real + 7) & ~7;
+    d.col_blocks = d.col_in_blocks + (int)(per_limb * (unsigned)dp.n);
+    d.ratio = 16 >> K;
+    const unsigned tile_octs = ((unsigned)d.tile_blocks + 7u) / 8u, col_octs = ((unsigned)d.col_blocks + 7u) / 8u;
+    const unsigned col_groups = (col_octs + (unsigned)d.ratio - 1u) / (unsigned)d.ratio;
+    const unsigned groups = tile_octs > col_groups ? tile_octs : col_groups;
+    const unsigned blocks = groups * (1u + (unsigned)d.ratio) * 8u;
+    switch (K) {
+        case 1: launch_duo_k<1>(relaxed, blocks, st, tile_base, col_base, d, in, dp, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+        case 2: launch_duo_k<2>(relaxed, blocks, st, tile_base, col_base, d, in, dp, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+        case 3: launch_duo_k<3>(relaxed, blocks, st, tile_base, col_base, d, in, dp, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+        case 4: launch_duo_k<4>(relaxed, blocks, st, tile_base, col_base, d, in, dp, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+    }
+}
+
 // forward transform of a stack; `rsrc` (optional): the column pass takes its input from a rescale on the fly
 int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
                 const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *ql, const int64_t *qh,
@@ -228,6 +313,47 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
 #ifndef LF_NTT_PIPE_MIN_POLYS
 #define LF_NTT_PIPE_MIN_POLYS 16   // polynomials per chunk below which launch tails eat the overlap
 #endif
+#ifndef LF_NTT_DUO
+#define LF_NTT_DUO 1               // chunks of a large batch whose passes are co-scheduled (ntt_fwd_duo); 1 = off.
+                                   // Parity-green and measured on MI355X at 2 / 4 / 8 chunks: 1.75-1.80 ms per step against
+                                   // 1.79 ms — the two roles share the CU's register file (4 x 128 VGPRs per SIMD lane), so
+                                   // each runs at the speed its share of the wave slots allows and the sum is unchanged
+                                   // (DESIGN.md §4).  Kept as a compile-time switch.
+#endif
+#ifndef LF_NTT_DUO_MIN_BLOCKS
+#define LF_NTT_DUO_MIN_BLOCKS 4096 // tile blocks per chunk below which the extra launch tails eat the overlap
+#endif
+    if (LF_NTT_DUO > 1 && LF_TILE16 && S1 >= 1 && S1 <= 4 && tl == NTT_TILE_LOG_MAX && !rsrc && !only_pass) {
+        const int min_polys = (LF_NTT_DUO_MIN_BLOCKS + (rows << S1) - 1) / (rows << S1);
+        int nd = batch / min_polys;
+        if (nd > LF_NTT_DUO) nd = LF_NTT_DUO;
+        if (nd >= 2) {
+            const PassGeom gc{logN, tl, 1, S1, 0, tl - S1, rows, 0, relaxed, 0, plain};
+            const PassGeom gt{logN, tl, 0, tl, S1, 0, rows, 0, relaxed, 1, plain, regtile_disabled()};
+            const int chunk = (batch + nd - 1) / nd;
+            i64 *prev = nullptr;
+            int prev_nb = 0;
+            for (int b0 = 0; b0 < batch; b0 += chunk) {
+                const int nb = batch - b0 < chunk ? batch - b0 : chunk;
+                i64 *base = (i64 *)a + ((i64)b0 * rows << logN);
+                if (!prev) {
+                    PassGeom g = gc;
+                    g.batch = nb;
+                    launch_cols_mixed(S1, (unsigned)nb * ((1u << tl) / NTT_COL_THREADS), st, base, g, in, dp, psi_br, psi_dp,
+                                      (const i64 *)Rs, ql, qh, kl, kh);
+                } else {
+                    launch_duo(S1, relaxed != 0, st, prev, prev_nb, base, nb, gt, gc, in, dp, psi_br, psi_dp, (const i64 *)Rs,
+                               ql, qh, kl, kh);
+                }
+                prev = base, prev_nb = nb;
+            }
+            PassGeom g = gt;
+            g.batch = prev_nb;
+            launch_pass16(false, relaxed, prev_nb, st, prev, prev, g, in, dp, (const i64 *)psi_br, psi_dp, (const i64 *)ql,
+                          (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+            return (int)hipGetLastError();
+        }
+    }
     int nchunks = 1;
     if (LF_NTT_PIPE > 1 && S1 > 0 && !rsrc && !only_pass && batch >= 2 * LF_NTT_PIPE_MIN_POLYS) {
         nchunks = LF_NTT_PIPE;

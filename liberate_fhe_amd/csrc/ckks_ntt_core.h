@@ -1033,6 +1033,14 @@ __global__ void __launch_bounds__(NTT_THREADS, LF_PASS_WAVES) ntt_fwd_pass_mixed
 // ------------------------------------------------------------------------------------------------
 #define NTT_COL_THREADS 256
 
+// row pointer of a column step as an opaque SGPR pair: keeps the compiler from folding the lane index into 2^K
+// per-lane 64-bit addresses (32 VGPRs held from the loads to the stores at K = 4)
+__device__ __forceinline__ i64 *uniform_row(i64 *base, i64 off) {
+    i64 *p = base + off;
+    asm("" : "+s"(p));
+    return p;
+}
+
 template <class A, int K>
 __device__ __forceinline__ void cols_fwd_stages(typename A::T (&x)[1 << K], const Ctx &c) {
 #pragma unroll
@@ -1070,7 +1078,8 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
     const int logC = g.logN - K;
     const int chunks = (1 << logC) / NTT_COL_THREADS;
     const int chunk = b % chunks, r = b / chunks;
-    const int poly = r % g.batch, crow = rl.id[r / g.batch];
+    // (the integer divisions run on the VALU: pin their wave-uniform results back into SGPRs)
+    const int poly = __builtin_amdgcn_readfirstlane(r % g.batch), crow = __builtin_amdgcn_readfirstlane((int)rl.id[r / g.batch]);
     const bool enter = (Rs != nullptr) && !(DP && g.plain);
 
     Ctx c;
@@ -1081,7 +1090,10 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
     c.relaxed = g.relaxed;
     c.inv_reduce = 0;
     const i64 rs = enter ? Rs[crow] : 0;
-    i64 *col = a + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS + threadIdx.x;
+    // wave-uniform base + lane index: the 2^K row addresses stay in SGPRs (a per-lane pointer would pin 2^K 64-bit
+    // addresses in VGPRs from the loads to the stores)
+    i64 *colu = a + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS;
+    const unsigned lane = threadIdx.x;
 
     i64 w[R];
     if (RS) {
@@ -1097,7 +1109,7 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < R; ++k) w[k] = col[(i64)k << logC];
+        for (int k = 0; k < R; ++k) w[k] = uniform_row(colu, (i64)k << logC)[lane];
     }
     int odd = 0;
 #pragma unroll
@@ -1122,7 +1134,7 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
         else cols_fwd_stages<ArithDp, K>(x, c);
         const double md = g.relaxed ? c.d.q : c.d.q2, mi = g.relaxed ? c.d.qinv : c.d.q2inv;
 #pragma unroll
-        for (int k = 0; k < R; ++k) col[(i64)k << logC] = dp_to_word(dp_reduce(x[k], md, mi));
+        for (int k = 0; k < R; ++k) uniform_row(colu, (i64)k << logC)[lane] = dp_to_word(dp_reduce(x[k], md, mi));
     } else {
         // integer class, or a lane of the fp64 class holding signed-lazy words
         if (enter) {
@@ -1135,7 +1147,7 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
         if (odd || DP) cols_fwd_stages<ArithInt<true>, K>(w, c);
         else cols_fwd_stages<ArithInt<false>, K>(w, c);
 #pragma unroll
-        for (int k = 0; k < R; ++k) col[(i64)k << logC] = w[k];
+        for (int k = 0; k < R; ++k) uniform_row(colu, (i64)k << logC)[lane] = w[k];
     }
 }
 
@@ -1339,7 +1351,8 @@ __device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const 
     const int logC = g.logN - K;
     const int chunks = (1 << logC) / NTT_COL_THREADS;
     const int chunk = b % chunks, r = b / chunks;
-    const int poly = r % g.batch, crow = rl.id[r / g.batch];
+    // (the integer divisions run on the VALU: pin their wave-uniform results back into SGPRs)
+    const int poly = __builtin_amdgcn_readfirstlane(r % g.batch), crow = __builtin_amdgcn_readfirstlane((int)rl.id[r / g.batch]);
     Ctx c;
     c.m = load_mod(ql, qh, kl, kh, crow);
     c.tw_mont = ipsi_br + ((i64)crow << g.logN);
@@ -1348,11 +1361,14 @@ __device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const 
     c.relaxed = g.relaxed;
     c.inv_reduce = 0;
     const i64 ninv_mont = (tail != TAIL_NONE) ? Ninv[crow] : 0;
-    i64 *col = a + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS + threadIdx.x;
+    // wave-uniform base + lane index: the 2^K row addresses stay in SGPRs (a per-lane pointer would pin 2^K 64-bit
+    // addresses in VGPRs from the loads to the stores)
+    i64 *colu = a + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS;
+    const unsigned lane = threadIdx.x;
 
     i64 w[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) w[k] = col[(i64)k << logC];
+    for (int k = 0; k < R; ++k) w[k] = uniform_row(colu, (i64)k << logC)[lane];
     int odd = 0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -1384,13 +1400,13 @@ __device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const 
                 if (dp_below_fix_limit(z)) z = dp_lazy_fix(z, (u64)tr, (u64)ninv_mont, c.d.q);
                 if (tail == 1) z = (z == c.d.q) ? c.d.q : dp_mulmod(z, rinv, c.d);   // redc(q) = q (K.cu:587-606)
             }
-            col[(i64)k << logC] = (tail >= 3) ? (i64)z : dp_to_word(z);
+            uniform_row(colu, (i64)k << logC)[lane] = (tail >= 3) ? (i64)z : dp_to_word(z);
         }
     } else {
         if (odd || DP) cols_inv_stages<ArithInt<true>, K>(w, c);
         else cols_inv_stages<ArithInt<false>, K>(w, c);
 #pragma unroll
-        for (int k = 0; k < R; ++k) col[(i64)k << logC] = inv_tail_int(w[k], tail, ninv_mont, c);
+        for (int k = 0; k < R; ++k) uniform_row(colu, (i64)k << logC)[lane] = inv_tail_int(w[k], tail, ninv_mont, c);
     }
 }
 

@@ -338,3 +338,50 @@ def test_ntt_pass_entry_is_the_two_halves_of_lf_ntt():
     assert torch.equal(got, want)
     assert lib.lf_ntt_pass(got.data_ptr(), batch, rows, logN, psi.data_ptr(), dp, q_host.ctypes.data, 0, 0, 3, *cp, 0, st) == 10001
     assert lib.lf_ntt_pass(got.data_ptr(), batch, rows, 12, psi.data_ptr(), dp, q_host.ctypes.data, 0, 0, 1, *cp, 0, st) == 10001
+
+
+@pytest.mark.parametrize("logN", [13, 14, 15, 16])
+@pytest.mark.parametrize("flags", [0, 1])
+def test_large_batch_co_scheduled_passes_equal_the_two_separate_passes(mods, logN, flags):
+    """Large batches (4 chunks' worth, the last one shorter): with -DLF_NTT_DUO > 1 they run as chunks whose tiled
+    pass shares a launch with the next chunk's column pass (ntt_fwd_duo; off in the shipped build, DESIGN.md §4 —
+    tools/mkvariant.sh + LF_HIP_LIB run this test against such a build).  Words must equal the two plain passes launched one after the other (lf_ntt_pass, which the
+    previous test ties to lf_ntt at small batch), and the oracle on polynomials of the first, a middle and the
+    last (shorter) chunk — including tiles that leave the fast form (signed words) inside the merged launch."""
+    from liberate_fhe_amd._native import lib, check
+    from liberate_fhe_amd.ntt import twiddles
+    nc, orc = mods
+    lim = Limbs(logN, pick_primes(logN, 3, 2))
+    rows = lim.rows
+    min_polys = -(-4096 // (rows << (logN - 12)))
+    batch = 4 * min_polys + 3                       # 4 chunks, the last one shorter
+    psi_np = lim.mont_tables()[0]
+    psi, q2 = dev(psi_np), dev(lim._2q)
+    c = [dev(v) for v in (lim.ql, lim.qh, lim.kl, lim.kh)]
+    cp = [t.data_ptr() for t in c]
+    st = torch.cuda.current_stream().cuda_stream
+    dp = twiddles.dp_pointer(psi, *c, 0, st)
+    q_host = np.array(lim.q, dtype=np.int64)
+    g = torch.Generator(device="cuda").manual_seed(logN * 7 + flags)
+    x = torch.empty((batch, rows, lim.N), dtype=torch.int64, device="cuda")
+    for r, q in enumerate(lim.q):
+        x[:, r] = torch.randint(0, 2 * q, (batch, lim.N), generator=g, device="cuda", dtype=torch.int64)
+    picks = [0, batch // 2, batch - 1]
+    if not flags:
+        for p in picks:                              # signed-lazy words: those tiles take the integer routine
+            for r, q in enumerate(lim.q):
+                x[p, r, 5] = -(q - 3)
+                x[p, r, lim.N - 9] = 2 * q + 1
+    want, got = x.clone(), x.clone()
+    for which in (1, 2):
+        check(lib.lf_ntt_pass(want.data_ptr(), batch, rows, logN, psi.data_ptr(), dp, q_host.ctypes.data, 0, flags, which, *cp, 0, st), "pass")
+    check(lib.lf_ntt(got.data_ptr(), batch, rows, logN, psi.data_ptr(), dp, q_host.ctypes.data, 0, flags, q2.data_ptr(), *cp, 0, st), "ntt")
+    assert torch.equal(got, want)
+    for p in picks:
+        ref = x[p].cpu().numpy().copy()
+        orc.ntt(ref, psi_np, rows, logN, lim._2q, *lim.mont_args())
+        out = got[p].cpu().numpy()
+        if flags:                                    # relaxed: canonical residues of the same values
+            ref = ref % q_host[:, None]
+            out = out % q_host[:, None]
+        assert (out == ref).all(), p
