@@ -281,7 +281,7 @@ __device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int t
     constexpr bool CHECK = !(RLX && DP);   // relaxed fp64 tiles accept any word the library's own first pass wrote
     i64 raw[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) raw[e] = row[base + w + (e << 8)];
+    for (int e = 0; e < 16; ++e) raw[e] = uniform_row(row + base, e << 8)[(unsigned)w];   // SGPR row pointers + lane index
     if (CHECK) {
         int odd = 0;
 #pragma unroll
@@ -392,7 +392,7 @@ __device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst
 #pragma unroll
         for (int e = 0; e < 16; ++e) raw[e] = sp[e];
     }
-    i64 *out = dst_row + base + w;
+    i64 *out = dst_row + base;                                    // wave-uniform; the lane index is added per store
     Ctx cc = c;
     cc.inv_reduce = 1;                                            // fp64 classes: fold at the end of every radix-16 step
     bool ok;
@@ -404,13 +404,13 @@ __device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst
         ok = inv_tile16_steps<AD, true, RLX>(reinterpret_cast<double *>(sm), sm, x, w, base, logN, s, cc, CHECK);
         if (ok) {   // exact: the lazy word in [0, 2q); relaxed: balanced residue -> canonical
 #pragma unroll
-            for (int e = 0; e < 16; ++e) out[e << 8] = dp_to_word(RLX ? dp_addmask(x[e], c.d.q) : x[e]);
+            for (int e = 0; e < 16; ++e) uniform_row(out, e << 8)[(unsigned)w] = dp_to_word(RLX ? dp_addmask(x[e], c.d.q) : x[e]);
         }
     } else {
         ok = inv_tile16_steps<ArithInt<false>, false, RLX>(sm, sm, raw, w, base, logN, s, cc, true);
         if (ok) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) out[e << 8] = raw[e];
+            for (int e = 0; e < 16; ++e) uniform_row(out, e << 8)[(unsigned)w] = raw[e];
         }
     }
     if (!ok) {
@@ -427,6 +427,9 @@ __device__ __forceinline__ void pass16_body(i64 *sm, int b, const i64 *src, i64 
                                             const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
     int poly, crow, tile;
     block_coords(g, rl, b, poly, crow, tile);
+    // (integer divisions run on the VALU: pin the wave-uniform coordinates back into SGPRs)
+    poly = __builtin_amdgcn_readfirstlane(poly), crow = __builtin_amdgcn_readfirstlane(crow);
+    tile = __builtin_amdgcn_readfirstlane(tile);
     Ctx c;
     c.m = load_mod(ql, qh, kl, kh, crow);
     c.tw_mont = tw_br + ((i64)crow << g.logN);
