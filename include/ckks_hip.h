@@ -34,7 +34,7 @@ extern "C" {
 
 #define LF_ERR_ARG 10001
 
-/* Library probe: returns the ABI version (currently 6; __graft_entry__.build() asserts it). */
+/* Library probe: returns the ABI version (currently 7; __graft_entry__.build() asserts it). */
 int lf_abi_version(void);
 
 /* Compile-time capacities of the fused kernels, so that callers can refuse a parameter set BEFORE any launch
@@ -84,9 +84,11 @@ int lf_mont_sub(const int64_t *a, const int64_t *b, int64_t *c, int rows, int64_
  * `batch` polynomials of `rows` limbs each, stored back to back ([batch][rows][N]); limb i of every
  * polynomial uses constant/twiddle row i.  The reference API is batch = 1.
  *
- * psi_dp / ipsi_dp (optional, may be NULL): the same compact twiddle table as plain canonical residues
- * stored as doubles (fill it with lf_twiddle_dp).  When given, limbs whose prime is below 2^41 run the
- * fp64-FMA butterfly path; results are bit-identical to the integer path.
+ * psi_dp / ipsi_dp (optional for the exact ops, may be NULL; REQUIRED with LF_NTT_RELAXED and by lf_ks_*): the
+ * AUXILIARY twiddle table, one row of 2N 8-byte words per limb, filled by lf_twiddle_dp.  Limbs whose prime is
+ * below 2^41 hold the plain canonical twiddles as doubles in words [0, N) and run the fp64-FMA butterfly path;
+ * results are bit-identical to the integer path.  Limbs with a larger prime hold N pairs (floor(w 2^64 / q), w)
+ * with w the plain twiddle: the Shoup products of the relaxed transforms (the exact ops never read them).
  * q_host (optional, may be NULL): HOST array of the `rows` primes, used only to split the rows into the
  * two arithmetic classes at launch time (each class has its own kernel instantiation); with NULL every
  * row runs the integer class.
@@ -100,9 +102,11 @@ int lf_mont_sub(const int64_t *a, const int64_t *b, int64_t *c, int rows, int64_
  * cc_mult, whose tensor product then needs one plain modular product per term (lf_tensor, plain = 1). */
 #define LF_NTT_PLAIN 2
 
-/* plain twiddles as doubles from the Montgomery-form compact table: out = reduce_q(redc(mont)).  Entry 0 of every
- * row (psi^0 = 1, which no butterfly stage reads) receives 1 / q_row instead: the fp64-class kernels take the
- * reciprocal from there.  Tables handed to lf_ntt / lf_intt / lf_ks_* as psi_dp / ipsi_dp must come from here. */
+/* The auxiliary table from the Montgomery-form compact table mont[rows][N]: out[rows][2N] (8-byte words).
+ * Primes below 2^41: out[r][j] = (double)reduce_q(redc(mont[r][j])) for j < N; entry 0 of the row (psi^0 = 1, which
+ * no butterfly stage reads) receives 1 / q_row instead — the fp64-class kernels take the reciprocal from there; words
+ * [N, 2N) are unused.  Larger primes: pairs (out[r][2j], out[r][2j + 1]) = (floor(w 2^64 / q), w), w = reduce_q(redc(
+ * mont[r][j])), as unsigned 64-bit integers.  Tables handed to lf_ntt / lf_intt / lf_ks_* must come from here. */
 int lf_twiddle_dp(const int64_t *mont, double *out, int rows, int64_t N, const int64_t *ql, const int64_t *qh,
                   const int64_t *kl, const int64_t *kh, int device, void *stream);
 

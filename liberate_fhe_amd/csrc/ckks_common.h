@@ -108,6 +108,44 @@ static __device__ __forceinline__ i64 redc62(i64 x, u64 q, u64 k) {
 
 static __device__ __forceinline__ i64 csub(i64 v, i64 m) { return v < m ? v : v - m; }
 
+// ------------------------------------------------------------------------------------------------
+// Shoup multiplication: the integer class of the RELAXED transforms (key switching), where only residues count.
+// A twiddle w (PLAIN residue) comes with its quotient wq = floor(w * 2^64 / q); for ANY 64-bit y
+//     y * w - floor(y * wq / 2^64) * q   lies in [0, 2q)                      (Shoup / Harvey)
+// and the quotient taken from three 32-bit multiplies (high product + the high halves of the two cross products,
+// the low product dropped) is short by at most 2, so the value below lies in [0, 4q): 64-bit wrap-around arithmetic,
+// 18 instructions against the 46 of the REDC62 butterfly the exact ops must use.  q < 2^60 leaves room for lazy words
+// up to 16q; conditional subtractions (4 instructions on the carry flag) keep them below 8q.
+// ------------------------------------------------------------------------------------------------
+struct ShoupW {
+    u64 wq, w;   // quotient, plain twiddle: one 16-byte table entry
+};
+
+// y * w mod q as a lazy word in [0, 4q); y any 64-bit value
+static __device__ __forceinline__ u64 shoup_mul(u64 y, const ShoupW t, u64 q) {
+    const unsigned yh = (unsigned)(y >> 32), yl = (unsigned)y, wh = (unsigned)(t.wq >> 32), wl = (unsigned)t.wq;
+    const u64 mid = (u64)__umulhi(yh, wl) + (u64)__umulhi(yl, wh);
+    const u64 quo = (u64)yh * (u64)wh + mid;
+    return y * t.w - quo * q;
+}
+
+// x >= m ? x - m : x for a wave-uniform m: subtract, then select on the borrow (the compiler spends a 64-bit compare
+// and a move on top)
+static __device__ __forceinline__ u64 csub_u(u64 x, u64 m) {
+    const unsigned xl = (unsigned)x, xh = (unsigned)(x >> 32), ml = (unsigned)m, mh = (unsigned)(m >> 32);
+    unsigned tl, th;
+    // (the borrow-in already occupies the constant bus of the second subtraction: its modulus half sits in a VGPR)
+    asm("v_subrev_co_u32 %0, vcc, %4, %2\n\tv_subb_co_u32 %1, vcc, %3, %5, vcc\n\t"
+        "v_cndmask_b32 %0, %0, %2, vcc\n\tv_cndmask_b32 %1, %1, %3, vcc"
+        : "=&v"(tl), "=&v"(th)
+        : "v"(xl), "v"(xh), "s"(ml), "v"(mh)
+        : "vcc");
+    return ((u64)th << 32) | tl;
+}
+
+// lazy word below 8q -> canonical residue
+static __device__ __forceinline__ u64 shoup_canon(u64 x, u64 q) { return csub_u(csub_u(csub_u(x, q << 2), q << 1), q); }
+
 struct RowMod {
     u64 q, k;
     i64 q2;

@@ -75,7 +75,7 @@ __device__ __forceinline__ void ks_ext_body(i64 *sm, int b, const i64 *__restric
     Ctx c;
     c.m = load_mod(ql, qh, kl, kh, crow);
     c.tw_mont = psi_br + ((i64)crow << kg.logN);
-    c.tw_dp = DP ? psi_dp + ((i64)crow << kg.logN) : nullptr;
+    set_aux<DP>(c, psi_dp, crow, kg.logN);
     c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
     c.relaxed = 1;
     c.inv_reduce = 0;
@@ -161,8 +161,13 @@ __device__ __forceinline__ void ks_ext_body(i64 *sm, int b, const i64 *__restric
             sm[PAD(L + 1)] = a1 < 0 ? a1 + c.m.q2 : a1;
         }
         lds_barrier();
-        run_fwd_stages<ArithInt<false>, true>(sm, g, tile, c);
-        store_tile_raw(sm, row, g, tile);
+        run_fwd_stages<ArithShoup, true>(sm, g, tile, c);            // residues only: Shoup products, lazy words < 8q
+        for (int L = threadIdx.x * 2; L < T; L += NTT_THREADS * 2) {
+            longlong2 o;
+            o.x = ArithShoup::canon(c, sm[PAD(L)]);
+            o.y = ArithShoup::canon(c, sm[PAD(L + 1)]);
+            *reinterpret_cast<longlong2 *>(row + tile_gaddr(g, tile, L)) = o;
+        }
     }
 }
 
@@ -300,6 +305,7 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
                const int64_t *E, const double *Ed, int64_t *tmp, const int64_t *psi_br, const double *psi_dp,
                const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
                hipStream_t st) {
+    if (!psi_dp) return LF_ERR_ARG;   // the relaxed arithmetic of both classes lives in the auxiliary table
     const int tl = NTT_TILE_LOG_MAX, S1 = logN - tl;
     const KsGeom kg{logN, tl, S1, rows, nparts, (i64)1 << logN, nct, (i64)state_stride};
     RowList dp, in;
@@ -350,6 +356,7 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
             int64_t row_off, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp,
             const int64_t *Ninv, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
             const int64_t *kh, hipStream_t st) {
+    if (!ipsi_dp) return LF_ERR_ARG;
     const int tl = NTT_TILE_LOG_MAX, S1 = logN - tl;
     RowList dp, in;
     classify_rows(rows, q_host, dp, in);

@@ -299,6 +299,7 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
     const int S1 = logN - tl;
     const int relaxed = flags & LF_NTT_RELAXED;
     const int plain = (relaxed && (flags & LF_NTT_PLAIN)) ? 1 : 0;
+    if (relaxed && !psi_dp) return LF_ERR_ARG;   // relaxed arithmetic lives in the auxiliary table (fp64 twiddles, Shoup pairs)
     RowList dp, in;
     classify(rows, q_host, psi_dp, dp, in);
     hipStream_t st = (hipStream_t)stream;
@@ -441,6 +442,7 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
     const int SB = logN - tl;
     const int relaxed = flags & LF_NTT_RELAXED;
     const int plain = (relaxed && (flags & LF_NTT_PLAIN)) ? 1 : 0;
+    if (relaxed && !ipsi_dp) return LF_ERR_ARG;
     RowList dp, in;
     classify(rows, q_host, ipsi_dp, dp, in);
     hipStream_t st = (hipStream_t)stream;

@@ -226,9 +226,20 @@ struct Ctx {
     RowDp d;
     const i64 *tw_mont;     // compact Montgomery twiddles of this limb (always valid)
     const double *tw_dp;    // compact plain twiddles as doubles (fp64 class)
+    const ShoupW *tw_sh;    // integer class, relaxed transforms: (quotient, plain twiddle) pairs — the same auxiliary row
     int relaxed;
     int inv_reduce;         // fp64 inverse steps: reduce mod 2q at the end of this step
 };
+
+// The auxiliary twiddle table (psi_dp / ipsi_dp of the C ABI, built by lf_twiddle_dp): one row of 2N 8-byte words per
+// limb.  fp64 class: words [0, N) are the plain twiddles as doubles (slot 0: 1/q).  Integer class: N pairs
+// (quotient, plain twiddle) for the Shoup products of the relaxed transforms.
+template <bool DP>
+__device__ __forceinline__ void set_aux(Ctx &c, const double *aux, int crow, int logN) {
+    const double *row = aux ? aux + ((i64)crow << (logN + 1)) : nullptr;
+    c.tw_dp = DP ? row : nullptr;
+    c.tw_sh = DP ? nullptr : reinterpret_cast<const ShoupW *>(row);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Arithmetic policies
@@ -258,6 +269,37 @@ struct ArithInt {
     static __device__ __forceinline__ void fwd_end(const Ctx &, T (&)[NN]) {}
     template <int NN>
     static __device__ __forceinline__ void inv_end(const Ctx &, T (&)[NN]) {}
+};
+
+// Integer class, RELAXED: Shoup products (ckks_common.h) on lazy 64-bit words.  Invariant: every word < 8q (< 2^63).
+//   forward:  a' = U + V < 12q, b' = U + 4q - V < 12q, each folded once by 8q;
+//   inverse:  a' = U + V < 16q folded by 8q, b' = (U + 8q - V) * w < 4q.
+// Words leave a pass through canon() as canonical residues.
+struct ArithShoup {
+    typedef i64 T;
+    typedef ShoupW W;
+    static __device__ __forceinline__ W tw(const Ctx &c, int idx) { return c.tw_sh[(unsigned)idx]; }
+    template <int MAXC>
+    static __device__ __forceinline__ void tw_group(const Ctx &c, int idx0, int cnt, W (&w)[MAXC]) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i)
+            if (i < cnt) w[i] = c.tw_sh[(unsigned)(idx0 + i)];
+    }
+    static __device__ __forceinline__ void fwd(const Ctx &c, T &a, T &b, W w, int) {
+        const u64 U = (u64)a, V = shoup_mul((u64)b, w, c.m.q), q8 = c.m.q << 3;
+        a = (T)csub_u(U + V, q8);
+        b = (T)csub_u(U + (c.m.q << 2) - V, q8);
+    }
+    static __device__ __forceinline__ void inv(const Ctx &c, T &a, T &b, W w, int) {
+        const u64 U = (u64)a, V = (u64)b, q8 = c.m.q << 3;
+        a = (T)csub_u(U + V, q8);
+        b = (T)shoup_mul(U + q8 - V, w, c.m.q);
+    }
+    template <int NN>
+    static __device__ __forceinline__ void fwd_end(const Ctx &, T (&)[NN]) {}
+    template <int NN>
+    static __device__ __forceinline__ void inv_end(const Ctx &, T (&)[NN]) {}
+    static __device__ __forceinline__ T canon(const Ctx &c, T x) { return (T)shoup_canon((u64)x, c.m.q); }
 };
 
 // fp64 class.  Words are representatives (< 2^52) of the reference's lazy values mod 2q.  Forward sums
@@ -915,7 +957,7 @@ __device__ __forceinline__ void fwd_pass_body(i64 *sm, int b, i64 *__restrict__ 
         Ctx c;
         c.m = load_mod(ql, qh, kl, kh, crow);
         c.tw_mont = psi_br + ((i64)crow << g.logN);
-        c.tw_dp = DP ? psi_dp + ((i64)crow << g.logN) : nullptr;
+        set_aux<DP>(c, psi_dp, crow, g.logN);
         c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
         c.relaxed = g.relaxed;
         c.inv_reduce = 0;
@@ -1085,7 +1127,7 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
     Ctx c;
     c.m = load_mod(ql, qh, kl, kh, crow);
     c.tw_mont = psi_br + ((i64)crow << g.logN);
-    c.tw_dp = DP ? psi_dp + ((i64)crow << g.logN) : nullptr;
+    set_aux<DP>(c, psi_dp, crow, g.logN);
     c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
     c.relaxed = g.relaxed;
     c.inv_reduce = 0;
@@ -1143,6 +1185,13 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
                 w[k] = mm62s(w[k], rs, c.m.q, c.m.k);
                 odd |= ((u64)w[k] >= (u64)c.m.q2);
             }
+        }
+        if (!DP && g.relaxed) {
+            // residues only: Shoup products on lazy words (the fold / the entry left them in [0, 2q)), canonical out
+            cols_fwd_stages<ArithShoup, K>(w, c);
+#pragma unroll
+            for (int k = 0; k < R; ++k) uniform_row(colu, (i64)k << logC)[lane] = ArithShoup::canon(c, w[k]);
+            return;
         }
         if (odd || DP) cols_fwd_stages<ArithInt<true>, K>(w, c);
         else cols_fwd_stages<ArithInt<false>, K>(w, c);
@@ -1209,7 +1258,7 @@ __device__ __forceinline__ void inv_pass_body(i64 *sm, int b, const i64 *src, i6
         Ctx c;
         c.m = load_mod(ql, qh, kl, kh, crow);
         c.tw_mont = ipsi_br + ((i64)crow << g.logN);
-        c.tw_dp = DP ? ipsi_dp + ((i64)crow << g.logN) : nullptr;
+        set_aux<DP>(c, ipsi_dp, crow, g.logN);
         c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
         c.relaxed = g.relaxed;
         c.inv_reduce = 0;
@@ -1356,7 +1405,7 @@ __device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const 
     Ctx c;
     c.m = load_mod(ql, qh, kl, kh, crow);
     c.tw_mont = ipsi_br + ((i64)crow << g.logN);
-    c.tw_dp = DP ? ipsi_dp + ((i64)crow << g.logN) : nullptr;
+    set_aux<DP>(c, ipsi_dp, crow, g.logN);
     c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
     c.relaxed = g.relaxed;
     c.inv_reduce = 0;
@@ -1403,6 +1452,13 @@ __device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const 
             uniform_row(colu, (i64)k << logC)[lane] = (tail >= 3) ? (i64)z : dp_to_word(z);
         }
     } else {
+        if (!DP && g.relaxed) {   // residues only (the words are canonical: this library's relaxed tiled pass wrote them)
+            cols_inv_stages<ArithShoup, K>(w, c);
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                uniform_row(colu, (i64)k << logC)[lane] = inv_tail_int(ArithShoup::canon(c, w[k]), tail, ninv_mont, c);
+            return;
+        }
         if (odd || DP) cols_inv_stages<ArithInt<true>, K>(w, c);
         else cols_inv_stages<ArithInt<false>, K>(w, c);
 #pragma unroll
@@ -1520,7 +1576,21 @@ __global__ void __launch_bounds__(256) twiddle_dp_kernel(const i64 *__restrict__
     const RowMod m = load_mod(ql, qh, kl, kh, r);
     i64 v = redc62(mont[(i64)r * N + j], m.q, m.k);
     v = v < (i64)m.q ? v : v - (i64)m.q;
-    out[(i64)r * N + j] = j == 0 ? 1.0 / (double)m.q : (double)v;   // slot 0 (= psi^0, never used): 1 / q, see make_dp_tab
+    double *row = out + 2 * (i64)r * N;                              // auxiliary rows are 2N words (set_aux)
+    if (m.q < SMALL_PRIME_LIMIT) {
+        row[j] = j == 0 ? 1.0 / (double)m.q : (double)v;            // slot 0 (= psi^0, never used): 1 / q, see make_dp_tab
+        return;
+    }
+    // integer class: (floor(w * 2^64 / q), w) by 64 steps of binary long division (w < q < 2^60; runs once per table)
+    u64 rem = (u64)v, quo = 0;
+    for (int i = 0; i < 64; ++i) {
+        rem <<= 1;
+        quo <<= 1;
+        if (rem >= m.q) rem -= m.q, quo |= 1;
+    }
+    ShoupW *pairs = reinterpret_cast<ShoupW *>(row);
+    pairs[j].wq = quo;
+    pairs[j].w = (u64)v;
 }
 
 }  // namespace

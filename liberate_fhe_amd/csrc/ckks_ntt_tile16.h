@@ -278,7 +278,7 @@ template <bool DP, bool RLX>
 __device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int tile, const PassGeom &g, const Ctx &c) {
     const int w = lf_tid();
     const int base = tile << 12, E = g.logN, s = g.s0;
-    constexpr bool CHECK = !(RLX && DP);   // relaxed fp64 tiles accept any word the library's own first pass wrote
+    constexpr bool CHECK = !RLX;   // relaxed tiles take the canonical words the library's own first pass wrote
     i64 raw[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) raw[e] = uniform_row(row + base, e << 8)[(unsigned)w];   // SGPR row pointers + lane index
@@ -300,6 +300,10 @@ __device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int t
         const double md = RLX ? c.d.q : c.d.q2, mi = RLX ? c.d.qinv : c.d.q2inv;
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[e] = dp_to_word(dp_reduce(x[e], md, mi));
+    } else if (RLX) {   // residues only: Shoup products on lazy words (ArithShoup), canonical on the way out
+        ok = fwd_tile16_steps<ArithShoup, false, true>(sm, sm, raw, w, base, E, s, c, false);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = ArithShoup::canon(c, raw[e]);
     } else {
         ok = fwd_tile16_steps<ArithInt<false>, false, RLX>(sm, sm, raw, w, base, E, s, c, true);
 #pragma unroll
@@ -369,7 +373,7 @@ template <bool DP, bool RLX>
 __device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst_row, int tile, const PassGeom &g, const Ctx &c) {
     const int w = lf_tid();
     const int base = tile << 12, logN = g.logN, s = g.s0;
-    constexpr bool CHECK = !(RLX && DP);   // relaxed inverse transforms take non-negative words (include/ckks_hip.h)
+    constexpr bool CHECK = !RLX;   // relaxed inverse transforms take lazy words in [0, 2q) (include/ckks_hip.h)
     const int L0 = ((w >> 6) << 10) + ((w & 63) << 1);
     {
         longlong2 in[8];
@@ -406,6 +410,10 @@ __device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst
 #pragma unroll
             for (int e = 0; e < 16; ++e) uniform_row(out, e << 8)[(unsigned)w] = dp_to_word(RLX ? dp_addmask(x[e], c.d.q) : x[e]);
         }
+    } else if (RLX) {
+        ok = inv_tile16_steps<ArithShoup, false, true>(sm, sm, raw, w, base, logN, s, cc, false);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) uniform_row(out, e << 8)[(unsigned)w] = ArithShoup::canon(c, raw[e]);
     } else {
         ok = inv_tile16_steps<ArithInt<false>, false, RLX>(sm, sm, raw, w, base, logN, s, cc, true);
         if (ok) {
@@ -433,7 +441,7 @@ __device__ __forceinline__ void pass16_body(i64 *sm, int b, const i64 *src, i64 
     Ctx c;
     c.m = load_mod(ql, qh, kl, kh, crow);
     c.tw_mont = tw_br + ((i64)crow << g.logN);
-    c.tw_dp = DP ? tw_dp + ((i64)crow << g.logN) : nullptr;
+    set_aux<DP>(c, tw_dp, crow, g.logN);
     c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
     c.relaxed = RLX ? 1 : 0;
     c.inv_reduce = 0;

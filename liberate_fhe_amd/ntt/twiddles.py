@@ -1,4 +1,5 @@
-"""fp64 copies of the compact twiddle tables (plain residues as doubles) for the fp64 butterfly path.
+"""Auxiliary twins of the compact twiddle tables: per limb 2N words — plain residues as doubles for the fp64
+butterflies (primes below 2^41), (quotient, plain twiddle) Shoup pairs for the relaxed integer-class butterflies.
 
 A table the kernels see may be a row-slice of a bigger per-device tensor (ntt_context hands out views per
 level / per key-switch digit).  The fp64 copy therefore mirrors the whole underlying storage and rows are
@@ -23,7 +24,8 @@ def dp_pointer(table: torch.Tensor, ql, qh, kl, kh, dev: int, stream: int) -> in
     key = id(base)
     entry = _tables.get(key)
     if entry is None or entry["ref"]() is not base or entry["version"] != base._version:
-        entry = {"dp": torch.empty(base.untyped_storage().nbytes() // 8, dtype=torch.float64, device=table.device),
+        # auxiliary rows are 2N words (fp64 class: N doubles; integer class: N (quotient, twiddle) Shoup pairs)
+        entry = {"dp": torch.empty(2 * (base.untyped_storage().nbytes() // 8), dtype=torch.float64, device=table.device),
                  "built": set(), "ref": weakref.ref(base), "version": base._version}
         _tables[key] = entry
         weakref.finalize(base, _tables.pop, key, None)
@@ -35,11 +37,11 @@ def dp_pointer(table: torch.Tensor, ql, qh, kl, kh, dev: int, stream: int) -> in
     missing = [r for r in range(rows) if (r0 + r) not in entry["built"]]
     if missing:
         lo, hi = missing[0], missing[-1] + 1
-        check(lib.lf_twiddle_dp(table.data_ptr() + lo * N * 8, entry["dp"].data_ptr() + (r0 + lo) * N * 8, hi - lo, N,
+        check(lib.lf_twiddle_dp(table.data_ptr() + lo * N * 8, entry["dp"].data_ptr() + (r0 + lo) * N * 16, hi - lo, N,
                                 ql.data_ptr() + lo * 8, qh.data_ptr() + lo * 8, kl.data_ptr() + lo * 8,
                                 kh.data_ptr() + lo * 8, dev, stream), "lf_twiddle_dp")
         entry["built"].update(range(r0 + lo, r0 + hi))
-    return entry["dp"].data_ptr() + off * 8
+    return entry["dp"].data_ptr() + off * 16
 
 
 _host_q = {}

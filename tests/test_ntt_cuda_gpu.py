@@ -385,3 +385,73 @@ def test_large_batch_co_scheduled_passes_equal_the_two_separate_passes(mods, log
             ref = ref % q_host[:, None]
             out = out % q_host[:, None]
         assert (out == ref).all(), p
+
+
+def test_auxiliary_table_layout_and_shoup_quotients():
+    """lf_twiddle_dp: rows of 2N words — plain twiddles as doubles (slot 0: 1/q) for primes below 2^41, pairs
+    (floor(w 2^64 / q), w) for the integer class — against big-integer arithmetic on the plain table."""
+    from liberate_fhe_amd._native import lib, check
+    logN = 13
+    lim = Limbs(logN, pick_primes(logN, 2, 2))
+    N = lim.N
+    psi = dev(lim.mont_tables()[0])
+    c = [dev(v) for v in (lim.ql, lim.qh, lim.kl, lim.kh)]
+    out = torch.zeros((lim.rows, 2 * N), dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.lf_twiddle_dp(psi.data_ptr(), out.data_ptr(), lim.rows, N, *[t.data_ptr() for t in c], 0, st), "twiddle_dp")
+    host = out.cpu()
+    for r, q in enumerate(lim.q):
+        q = int(q)
+        plain = [int(v) for v in lim.psi_plain[r]]
+        if q < (1 << 41):
+            got = host[r, :N].numpy()
+            assert got[0] == 1.0 / q and (got[1:] == np.array(plain[1:], dtype=np.float64)).all()
+        else:
+            pairs = host[r].view(torch.int64).numpy().view(np.uint64).reshape(N, 2)
+            for j in (1, 2, 3, N // 2, N - 1):
+                assert int(pairs[j, 1]) == plain[j] and int(pairs[j, 0]) == (plain[j] << 64) // q, (r, j)
+
+
+@pytest.mark.parametrize("logN", [13, 14, 15, 16])
+def test_relaxed_transforms_integer_class_shoup_round_trip(mods, logN):
+    """The relaxed transforms run the integer class on Shoup products (lazy 64-bit words, canonical on the way out of
+    every pass): forward == the oracle's transform modulo q, forward then inverse (tail 2) == the input; 60-bit rows
+    alone and next to fp64-class rows; inputs at the edges of the accepted range."""
+    from liberate_fhe_amd._native import lib, check
+    from liberate_fhe_amd.ntt import twiddles
+    nc, orc = mods
+    for n40, n60 in ((0, 3), (2, 2)):
+        lim = Limbs(logN, pick_primes(logN, n40, n60))
+        rows, batch = lim.rows, 3
+        psi_np, ipsi_np = lim.mont_tables()
+        psi, ipsi, q2, Ninv = dev(psi_np), dev(ipsi_np), dev(lim._2q), dev(lim.Ninv)
+        c = [dev(v) for v in (lim.ql, lim.qh, lim.kl, lim.kh)]
+        cp = [t.data_ptr() for t in c]
+        st = torch.cuda.current_stream().cuda_stream
+        dp, idp = twiddles.dp_pointer(psi, *c, 0, st), twiddles.dp_pointer(ipsi, *c, 0, st)
+        q_host = np.array(lim.q, dtype=np.int64)
+        x_np = np.stack([lim.uniform(900 + logN + b) for b in range(batch)])
+        for r, q in enumerate(lim.q):
+            x_np[0, r, :4] = [0, 1, q - 1, q - 2]
+        x = dev(x_np)
+        y = x.clone()
+        check(lib.lf_ntt(y.data_ptr(), batch, rows, logN, psi.data_ptr(), dp, q_host.ctypes.data, 0, 1, q2.data_ptr(), *cp, 0, st), "ntt")
+        got = y.cpu().numpy()
+        assert (got >= 0).all() and (got < q_host[None, :, None]).all()          # canonical residues
+        for b in range(batch):
+            ref = x_np[b].copy()
+            orc.ntt(ref, psi_np, rows, logN, lim._2q, *lim.mont_args())
+            assert (got[b] == ref % q_host[:, None]).all(), (n40, n60, b)
+        # lazy words in [0, 2q) are what the inverse accepts (include/ckks_hip.h)
+        z = y + torch.from_numpy(q_host)[None, :, None].cuda() * (torch.arange(lim.N, device="cuda") % 2)[None, None, :]
+        # the reference chain needs Montgomery-form input for intt_exit_reduce to return x: enter first
+        for t in (y, z):
+            w = t.clone()
+            check(lib.lf_intt(w.data_ptr(), batch, rows, logN, ipsi.data_ptr(), idp, q_host.ctypes.data, Ninv.data_ptr(), 2, 1,
+                              q2.data_ptr(), *cp, 0, st), "intt")
+            for b in range(batch):
+                ref = got[b].copy()
+                orc.intt(ref, ipsi_np, lim.Ninv, rows, logN, lim._2q, *lim.mont_args())
+                orc.mont_redc(ref, rows, *lim.mont_args())
+                orc.reduce_2q(ref, rows, lim._2q)
+                assert (w[b].cpu().numpy() == ref).all(), (n40, n60, b)
