@@ -200,6 +200,135 @@ __global__ void __launch_bounds__(NTT_THREADS, 6) ks_ext_pass1_mixed(const i64 *
     }
 }
 
+// ---- K2, column form (used for S1 = logN - 12 <= 3): extend + the S1 leading stages as ONE register step per column ---------
+// Thread = one column of one (digit, target limb): its 2^S1 words sit N / 2^S1 apart and every one of them is the
+// extension sum over the digit's alpha limbs at that coefficient, so the step needs no LDS, no barrier and no
+// per-lane twiddle (the 2^S1 - 1 twiddles are the table entries 1 .. 2^S1 - 1, scalar loads) — the shape of
+// ntt_fwd_cols with the rescale-free extension as its source.  A wave reads / writes 512 contiguous bytes per row.
+// The blocks of one (digit, column chunk) pair differ in the target limb and re-read the same digit words: they sit
+// on one XCD (as in ks_ext_body).
+template <bool DP, int K>
+__device__ __forceinline__ void ks_ext_cols_body(int b, const i64 *__restrict__ state, i64 *__restrict__ tmp, const KsGeom &kg,
+                                                 const RowList &rl, const i64 *__restrict__ desc, const i64 *__restrict__ E,
+                                                 const double *__restrict__ Ed, const i64 *__restrict__ psi_br,
+                                                 const double *__restrict__ psi_dp, const i64 *__restrict__ ql,
+                                                 const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                                 const i64 *__restrict__ kh) {
+    constexpr int R = 1 << K;
+    const int logC = kg.logN - K;
+    const int chunks = (1 << logC) / NTT_COL_THREADS;
+    const int per_ct = chunks * kg.nparts * rl.n;
+    const int ct = b / per_ct;
+    b -= ct * per_ct;
+    int ri, pc;
+    if (((chunks * kg.nparts) & 7) == 0) {
+        const int x = b & 7, r = b >> 3;
+        ri = r % rl.n;
+        pc = (r / rl.n) * 8 + x;
+    } else {
+        ri = b % rl.n;
+        pc = b / rl.n;
+    }
+    // (integer divisions run on the VALU: pin the wave-uniform coordinates back into SGPRs)
+    const int chunk = __builtin_amdgcn_readfirstlane(pc % chunks), p = __builtin_amdgcn_readfirstlane(pc / chunks);
+    const int crow = __builtin_amdgcn_readfirstlane((int)rl.id[ri]);
+    const int ctu = __builtin_amdgcn_readfirstlane(ct);
+
+    Ctx c;
+    c.m = load_mod(ql, qh, kl, kh, crow);
+    c.tw_mont = psi_br + ((i64)crow << kg.logN);
+    set_aux<DP>(c, psi_dp, crow, kg.logN);
+    c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
+    c.relaxed = 1;
+    c.inv_reduce = 0;
+    const int row_start = (int)desc[p * 3 + 0], alpha = (int)desc[p * 3 + 1] & 0xff;
+    const bool wide = ((int)desc[p * 3 + 1] >> 8) & 1;
+    const i64 e_off = desc[p * 3 + 2] + crow;
+    const unsigned lane = threadIdx.x;
+    const i64 *src = state + (i64)ctu * kg.state_stride + (i64)row_start * kg.N + chunk * NTT_COL_THREADS;
+    i64 *dst = tmp + ((((i64)ctu * kg.nparts + p) * kg.rows + crow) << kg.logN) + chunk * NTT_COL_THREADS;
+
+    if (DP) {
+        double cst[KS_MAX_ALPHA], cst31[KS_MAX_ALPHA];
+#pragma unroll
+        for (int i = 0; i < KS_MAX_ALPHA; ++i) {
+            cst[i] = i < alpha ? Ed[e_off + (i64)i * kg.rows] : 0.0;
+            cst31[i] = wide ? dp_mulmod(cst[i], 2147483648.0, c.d) : 0.0;
+        }
+        double x[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) x[k] = 0.0;
+#pragma unroll
+        for (int i = 0; i < KS_MAX_ALPHA; ++i) {
+            if (i < alpha) {
+                const i64 *rowi = src + (i64)i * kg.N;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const i64 y = uniform_row(const_cast<i64 *>(rowi), (i64)k << logC)[lane];
+                    if (!wide)   // signed digit words (|y| < 2^43): the formula is sign-agnostic
+                        x[k] += dp_mulmod_bal(dp_from_signed(y), cst[i], c.d);
+                    else         // 60-bit digit words: 31-bit halves through the native 32-bit conversions
+                        x[k] += dp_mulmod_bal((double)(int)(y >> 31), cst31[i], c.d) +
+                                dp_mulmod_bal((double)(unsigned)(y & 0x7fffffffll), cst[i], c.d);
+                }
+            }
+        }
+        cols_fwd_stages<ArithDpR, K>(x, c);          // |x| < alpha * q on the way in (balanced terms)
+#pragma unroll
+        for (int k = 0; k < R; ++k) uniform_row(dst, (i64)k << logC)[lane] = dp_to_word(dp_reduce(x[k], c.d.q, c.d.qinv));
+    } else {
+        i64 cst[KS_MAX_ALPHA];
+#pragma unroll
+        for (int i = 0; i < KS_MAX_ALPHA; ++i) cst[i] = i < alpha ? E[e_off + (i64)i * kg.rows] : 0;
+        i64 w[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            i64 a;
+            if (wide && alpha > 1) {   // several 60-bit limbs in one digit (no preset has that): term by term
+                a = 0;
+#pragma unroll
+                for (int i = 0; i < KS_MAX_ALPHA; ++i) {
+                    if (i < alpha) {
+                        const i64 y = uniform_row(const_cast<i64 *>(src + (i64)i * kg.N), (i64)k << logC)[lane];
+                        const i64 t = mm62s(y, cst[i], c.m.q, c.m.k);
+                        a = i == 0 ? t : csub(a + t, c.m.q2);
+                    }
+                }
+            } else {                   // sum_i y_i * (L_{i-1} R^2 mod q) in 128 bits, ONE REDC (see ks_ext_body)
+                i128 acc = 0;
+#pragma unroll
+                for (int i = 0; i < KS_MAX_ALPHA; ++i) {
+                    if (i < alpha) {
+                        const i64 y = uniform_row(const_cast<i64 *>(src + (i64)i * kg.N), (i64)k << logC)[lane];
+                        acc += (i128)y * (i128)cst[i];
+                    }
+                }
+                a = redc62_wide(acc, c.m.q, c.m.k);
+            }
+            w[k] = a < 0 ? a + c.m.q2 : a;           // residues only: fold into [0, 2q)
+        }
+        cols_fwd_stages<ArithShoup, K>(w, c);
+#pragma unroll
+        for (int k = 0; k < R; ++k) uniform_row(dst, (i64)k << logC)[lane] = ArithShoup::canon(c, w[k]);
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(NTT_COL_THREADS) ks_ext_cols_mixed(const i64 *__restrict__ state, i64 *__restrict__ tmp,
+                                                                     KsGeom kg, ClassLists cl, const i64 *__restrict__ desc,
+                                                                     const i64 *__restrict__ E, const double *__restrict__ Ed,
+                                                                     const i64 *__restrict__ psi_br,
+                                                                     const double *__restrict__ psi_dp,
+                                                                     const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                     const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    const int b = blockIdx.x;
+    if (b < cl.in_blocks) {
+        if (b < cl.in_real) ks_ext_cols_body<false, K>(b, state, tmp, kg, cl.in, desc, E, Ed, psi_br, psi_dp, ql, qh, kl, kh);
+    } else {
+        ks_ext_cols_body<true, K>(b - cl.in_blocks, state, tmp, kg, cl.dp, desc, E, Ed, psi_br, psi_dp, ql, qh, kl, kh);
+    }
+}
+
 // The key (gold: 429 MB per key switch) is read exactly once: nontemporal loads (global_load_dwordx4 .. nt) keep it
 // from displacing the digits, which the forward pass has just written, out of L2 / Infinity Cache
 // (measured at gold: 124.8 -> 96.2 us together with one 16-byte column per thread instead of two).
@@ -313,8 +442,25 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
     const unsigned tiles = 1u << (logN - tl);
     const unsigned polys = (unsigned)nparts * (unsigned)nct;   // extended digits of all ciphertexts: one stack
     const bool mixed = dp.n && in.n && mixed_enabled();   // both arithmetic classes in one launch per step
-    // K2: extend + strided pass
-    if (mixed) {
+    // K2: extend + strided pass — as one register step per column when the strided pass has at most 4 stages
+#ifndef LF_KS_EXT_COLS
+#define LF_KS_EXT_COLS 1   // 0: the LDS-tiled form for every size (A/B switch)
+#endif
+    // (measured on MI355X, extension kernel alone: silver / logN 15 22.5 -> 20.0 us; gold / logN 16 95 -> 116 us — 16 words
+    // per column cost 90 VGPRs and 64 loads in flight per thread — so logN 16 keeps the LDS-tiled form)
+    if (LF_KS_EXT_COLS && S1 <= 3) {
+        const unsigned per_limb = ((1u << tl) / NTT_COL_THREADS) * polys;   // column chunks x digits x ciphertexts
+        const ClassLists cl = class_lists(in, dp, per_limb * (unsigned)in.n);   // either list may be empty
+        const dim3 grid((unsigned)cl.in_blocks + per_limb * (unsigned)dp.n), block(NTT_COL_THREADS);
+#define LF_EXT_COLS_CASE(KK)                                                                                            \
+    case KK:                                                                                                            \
+        hipLaunchKernelGGL((ks_ext_cols_mixed<KK>), grid, block, 0, st, (const i64 *)state, (i64 *)tmp, kg, cl,          \
+                           (const i64 *)desc, (const i64 *)E, Ed, (const i64 *)psi_br, psi_dp, (const i64 *)ql,         \
+                           (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);                                         \
+        break;
+        switch (S1) { LF_EXT_COLS_CASE(1) LF_EXT_COLS_CASE(2) LF_EXT_COLS_CASE(3) }
+#undef LF_EXT_COLS_CASE
+    } else if (mixed) {
         const ClassLists cl = class_lists(in, dp, tiles * in.n * polys);
         hipLaunchKernelGGL(ks_ext_pass1_mixed, dim3((unsigned)cl.in_blocks + tiles * dp.n * polys), dim3(NTT_THREADS), 0, st,
                            (const i64 *)state, (i64 *)tmp, kg, cl, (const i64 *)desc, (const i64 *)E, Ed, (const i64 *)psi_br,
