@@ -13,8 +13,12 @@
 //   K3  ks_inner2_kernel : per coefficient, the digits' products with the two key polynomials accumulated
 //                          in registers; the key is streamed exactly once
 //   K4  ntt_inv_pass_io  : the stock inverse passes (relaxed, tail 2) -> canonical coefficients
-// (A variant that also fused P2 with K3 — transform a tile in LDS, multiply, accumulate over the digits in
-// registers — was measured 1.6x SLOWER: too few, too long blocks; see DESIGN.md.)
+// (Variants that fuse P2 with K3 — transform a tile, multiply, accumulate over the digits in registers — were
+// measured twice: round 1 on the 8-words-per-thread tile 1.6x SLOWER; round 2 on the 16-words tile, with the contiguous
+// inverse pass fused in as well (one block = one (ciphertext, limb, tile), 154 / 168 VGPRs, 3 blocks per CU): gold 231 us
+// against 224 us for the three launches it replaces, silver 152 against 95 us (170 blocks for 256 CUs), batches of 16
+// and 64 ciphertexts +1-2 %.  Too few, too long blocks for one ciphertext, and no gain from the 490 MB of HBM traffic it
+// saves once the grid is full: these passes are bound by their LDS exchanges and barriers, not by HBM; see DESIGN.md.)
 //
 // All of it is "relaxed" arithmetic: only residues matter because the consumer (mod-down) needs the
 // canonical coefficients, which the inverse chain's tail produces.  For limbs with a prime below 2^41
