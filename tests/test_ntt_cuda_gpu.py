@@ -455,3 +455,23 @@ def test_relaxed_transforms_integer_class_shoup_round_trip(mods, logN):
                 orc.mont_redc(ref, rows, *lim.mont_args())
                 orc.reduce_2q(ref, rows, lim._2q)
                 assert (w[b].cpu().numpy() == ref).all(), (n40, n60, b)
+
+
+def test_relaxed_transforms_require_the_auxiliary_table():
+    """LF_NTT_RELAXED without psi_dp / ipsi_dp is an argument error (the relaxed arithmetic of both classes lives in that
+    table), reported before anything is launched: the buffer is untouched."""
+    from liberate_fhe_amd._native import lib
+    logN = 13
+    lim = Limbs(logN, pick_primes(logN, 2, 1))
+    psi, ipsi = (dev(t) for t in lim.mont_tables())
+    c = [dev(v) for v in (lim.ql, lim.qh, lim.kl, lim.kh)]
+    cp = [t.data_ptr() for t in c]
+    q2, Ninv = dev(lim._2q), dev(lim.Ninv)
+    st = torch.cuda.current_stream().cuda_stream
+    q_host = np.array(lim.q, dtype=np.int64)
+    x = dev(lim.uniform(3))
+    keep = x.clone()
+    assert lib.lf_ntt(x.data_ptr(), 1, lim.rows, logN, psi.data_ptr(), 0, q_host.ctypes.data, 0, 1, q2.data_ptr(), *cp, 0, st) == 10001
+    assert lib.lf_intt(x.data_ptr(), 1, lim.rows, logN, ipsi.data_ptr(), 0, q_host.ctypes.data, Ninv.data_ptr(), 2, 1, q2.data_ptr(), *cp, 0, st) == 10001
+    torch.cuda.synchronize()
+    assert torch.equal(x, keep)
