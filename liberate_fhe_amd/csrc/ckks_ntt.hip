@@ -29,7 +29,8 @@
 //     A tile containing a word outside [0, 2q) (the rare signed-lazy inputs) is run by
 //     a compact fully-signed integer routine inside the same kernel, exactly as the reference would.
 //   * LF_NTT_RELAXED transforms are for callers that only need the result modulo q (the fused key
-//     switch): negative input words are folded, outputs are canonical residues.
+//     switch): negative input words are folded, outputs are canonical residues.  Their integer class (logN 13..16)
+//     multiplies by PLAIN twiddles with precomputed Shoup quotients from the auxiliary table (ckks_common.h).
 #include "../../include/ckks_hip.h"
 #include "ckks_ntt_core.h"
 #include "ckks_ntt_tile16.h"
