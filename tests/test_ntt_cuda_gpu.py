@@ -433,6 +433,8 @@ def test_relaxed_transforms_integer_class_shoup_round_trip(mods, logN):
         x_np = np.stack([lim.uniform(900 + logN + b) for b in range(batch)])
         for r, q in enumerate(lim.q):
             x_np[0, r, :4] = [0, 1, q - 1, q - 2]
+            x_np[1, r, :] = q - 1                      # every lazy sum at its upper bound
+            x_np[1, r, 1::3] = 0                       # ... and every difference too
         x = dev(x_np)
         y = x.clone()
         check(lib.lf_ntt(y.data_ptr(), batch, rows, logN, psi.data_ptr(), dp, q_host.ctypes.data, 0, 1, q2.data_ptr(), *cp, 0, st), "ntt")
