@@ -188,7 +188,11 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ks_ext_pass1(const i6
 }
 
 // both arithmetic classes in one launch (integer-class blocks first), see ntt_fwd_pass_mixed
-__global__ void __launch_bounds__(NTT_THREADS, 6) ks_ext_pass1_mixed(const i64 *__restrict__ state, i64 *__restrict__ tmp,
+#ifndef LF_KS_EXT_WAVES
+#define LF_KS_EXT_WAVES 8   // waves per SIMD the kernel is compiled for: 63 VGPRs, no spill, four blocks per CU (LDS) instead of
+                            // the three of the 6-wave build (80 VGPRs); measured at gold: rotate 409-414 -> 402 us, cc_mult 557 -> 540-545 us
+#endif
+__global__ void __launch_bounds__(NTT_THREADS, LF_KS_EXT_WAVES) ks_ext_pass1_mixed(const i64 *__restrict__ state, i64 *__restrict__ tmp,
                                                                        KsGeom kg, ClassLists cl, const i64 *__restrict__ desc,
                                                                        const i64 *__restrict__ E, const double *__restrict__ Ed,
                                                                        const i64 *__restrict__ psi_br,
