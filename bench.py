@@ -226,9 +226,10 @@ def multi_gpu_rates(dev, world, rank, out, sharded=True):
     """N > 1.  Fills `out` (a dict that main() prints even if a leg below never returns, see the watchdog):
       replicas      gold cc_mult(+relinearize) on N independent engines, zero communication: N x single rate;
       config 5      64 gold ciphertexts rotated under one key, 64 / N per rank (batch replicas, full key per GPU);
-      config 4      gold cc_mult LIMB-SHARDED over the N ranks by rns_partition: rescale row by RCCL broadcast,
-                    key-switch digits by per-digit RCCL all-gathers overlapped with the extension of the previous
-                    digit group (fhe/comm.py); plus limb-sharded rotate_single.
+      config 4      gold cc_mult LIMB-SHARDED over the N ranks by rns_partition: rescale rows by one in-place RCCL
+                    broadcast, key-switch digits by one asynchronous in-place broadcast per run of same-owner digits,
+                    each group extended + transformed as it lands (fhe/comm.py, lf_ks_fwd / lf_ks_tail); plus
+                    limb-sharded rotate_single.
     Every leg is fenced by barriers on the default group and catches its own exceptions; the sharded legs run on
     their OWN process group with a short timeout, so a rank that fails inside them cannot hang the line."""
     import datetime
