@@ -95,7 +95,8 @@ int lf_mont_sub(const int64_t *a, const int64_t *b, int64_t *c, int rows, int64_
  * flags: LF_NTT_RELAXED = the caller only needs the result modulo q (outputs are then canonical
  * residues instead of the reference's lazy representatives) — for fused internal use, never for the
  * drop-in ops.  A relaxed FORWARD transform accepts the reference's signed-lazy words (|a| < 2q); a relaxed
- * INVERSE transform takes non-negative words below 2^52 (what lf_tensor / lf_ks_inner / the fused core write). */
+ * INVERSE transform takes non-negative words: below 2^52 on fp64-class limbs, lazy words in [0, 2q) on integer-class
+ * limbs (what lf_tensor / lf_ks_inner / the fused core write). */
 #define LF_NTT_RELAXED 1
 /* with LF_NTT_RELAXED: fp64-class limbs stay in the PLAIN domain — lf_ntt applies Rs to integer-class limbs
  * only, lf_intt (tail >= 2) multiplies fp64-class limbs by N^-1 instead of N^-1 R^-1.  Used by the fused
