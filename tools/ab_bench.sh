@@ -1,5 +1,5 @@
 #!/bin/bash
-# bench-only A/B of several library variants: tools/r02_ab4.sh lib1 lib2 ...
+# bench-only A/B of several library variants: tools/ab_bench.sh lib1 lib2 ...
 set -u
 for i in 1 2; do
   for L in "$@"; do

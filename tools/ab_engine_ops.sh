@@ -1,5 +1,5 @@
 #!/bin/bash
-# engine-op A/B of library variants: tools/r02_ab5.sh lib1 lib2 ...  (gold + silver, cc_mult + rotate)
+# engine-op A/B of library variants: tools/ab_engine_ops.sh lib1 lib2 ...  (gold + silver, cc_mult + rotate)
 set -u
 for i in 1 2; do
   for L in "$@"; do
