@@ -655,7 +655,7 @@ class ckks_engine(EvaluatorOps):
                 for k, ct in enumerate(cts):
                     buf[2 * k].copy_(ct.data[0][i][0])
                     buf[2 * k + 1].copy_(ct.data[1][i][0])
-            self.comm.broadcast_into(buf, owner)
+            self.comm.fanout_into(buf, owner, targets)   # one message per rank that still holds rows at the next level
             for k in range(len(cts)):
                 rows0.append([{d: buf[2 * k + comp] for d in targets if d in self.local_ids} for comp in range(2)])
         else:
@@ -848,7 +848,8 @@ class ckks_engine(EvaluatorOps):
         host memory first).  Returns {local device: (digits buffer [total_rows, N] in storage order,
         [(ready, first digit, digits), ...])}: the digits of a group may be read once `ready.wait()` has been
         called (ready None: already ordered on the current stream).  Buffers are allocated once per level; the
-        groups are issued in the order the key switch consumes them."""
+        list is in consumption order — one process per GPU: the digits this rank owns first, the foreign ones behind
+        the single wait on the point-to-point batch."""
         n_alive = self.len_devices[level]
         loc = self._loc(level)
         nparts = len(tabs["order"])
@@ -858,17 +859,25 @@ class ckks_engine(EvaluatorOps):
         groups = tabs["groups"]
         if self.comm is not None and self.comm.world_size > 1:
             me = self.local_ids[0]
-            # a rank without ordinary rows at this level still takes part in the collectives (scratch buffer)
+            if not loc:   # no rows at this level: nothing to switch, nothing to send, nothing to receive
+                return {}
             buf = self._ws("ks_digits_all", (tabs["total_rows"], N), me)
-            ready = []
             for owner, first, count, row0, nrows, src_row in groups:
-                dst = buf[row0:row0 + nrows]
                 if owner == me:
-                    dst.copy_(states[me][src_row:src_row + nrows])
-                ready.append((self.comm.broadcast_into(dst, owner, async_op=True), first, count))
-            if not loc:   # nothing to switch here: this rank only had to take part
-                for handle, _, _ in ready:
-                    handle.wait()
+                    buf[row0:row0 + nrows].copy_(states[me][src_row:src_row + nrows])
+            # one batch of point-to-point messages between the alive ranks (comm.py); asynchronous
+            handle = self.comm.exchange_rows(buf, [(g[0], g[3], g[4]) for g in groups], list(range(n_alive)))
+            # consumption order: the digits this rank owns first (already here: their extension + NTT overlaps the
+            # exchange), then — after ONE wait — the runs of foreign digits between them
+            ready = [(None, first, count) for owner, first, count, _, _, _ in groups if owner == me]
+            run = None
+            for owner, first, count, _, _, _ in groups + [(me, nparts, 0, 0, 0, 0)]:
+                if owner == me:
+                    if run is not None:
+                        ready.append((handle, run[0], run[1]))
+                        handle, run = None, None
+                else:
+                    run = (first, count) if run is None else (run[0], run[1] + count)
             return {d: (buf, ready) for d in loc}
         out = {}
         for t in loc:
@@ -905,7 +914,7 @@ class ckks_engine(EvaluatorOps):
             gal = None if galois is None else (galois[0], self._vec("_2q", d, level, False) if galois[1] else None)
             self.backend.ks_digits(src, st, nparts, desc, tab, self._consts(d, level, False), galois=gal)
             states[d] = st
-        # 2. digit exchange: asynchronous, one message per run of digits with the same owner
+        # 2. digit exchange: asynchronous, one batch of point-to-point messages between the alive ranks
         digits = self._exchange_digits(states, level, tabs)
 
         nparts = len(tabs["order"])
@@ -921,8 +930,8 @@ class ckks_engine(EvaluatorOps):
             dig, ready = digits[d]
             fused = logN >= self.backend.fused_ks_min_logN
             if fused and len(ready) > 1 and hasattr(self.backend, "ks_fwd"):
-                # 3. per exchange group, as it arrives: extend + forward NTT of its digits (the next groups are
-                # still on the wire); 4. once all are in: key inner product over all digits + inverse NTT
+                # 3. extend + forward NTT of this rank's own digits while the others are on the wire, then of the
+                # foreign runs; 4. once all are in: key inner product over all digits + inverse NTT
                 for handle, first, count in ready:
                     if handle is not None:
                         handle.wait()

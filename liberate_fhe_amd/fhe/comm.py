@@ -1,18 +1,20 @@
-"""Collectives used by the limb-sharded engine: one process per GPU, torch.distributed underneath.
+"""Exchanges of the limb-sharded engine: one process per GPU, torch.distributed underneath.
 
 On MI355X the backend is "nccl" (= RCCL) and the payloads travel over xGMI; the CPU test-suite runs the
 same code over "gloo".  The path has exactly two exchange steps, both IN PLACE on buffers the
-engine allocates once per level (`broadcast_into`):
+engine allocates once per level:
 
-  * rescale: the dropped limb's two rows (2 x N words) from their owner to every rank;
-  * key switch: every Garner digit from its owner to every rank, ONE collective per run of digits with the same
-    owner, each straight into its rows of the storage-order digit buffer — shards of unequal height travel
-    unpadded, nothing is concatenated or re-indexed afterwards.  The collectives are issued asynchronously, in
-    consumption order, before any extension starts; the engine waits on a group's handle only when it launches
-    that group's extension + NTT (lf_ks_fwd), so group g + 1 is on the wire while the kernels of group g run.
-    With RCCL the wait is a stream dependency (the communicator's stream -> the compute stream), not a host
-    block.  xGMI is point to point: a digit of 4 limbs at gold is 2 MiB = ~15 us on one 153 GB/s link, and the
-    owners of consecutive groups are different GPUs, so consecutive broadcasts leave over different links.
+  * key switch (`exchange_rows`): every rank needs every Garner digit.  xGMI is point to point — each GPU has its own
+    link to each of the other seven — so the digits travel as ONE batch of point-to-point messages (RCCL: one
+    ncclGroup of send / recv pairs): a rank sends the runs of digits it owns straight to every other alive rank and
+    receives every other run from its owner, each into its rows of the storage-order digit buffer.  Every link carries
+    only its own pair's traffic (gold, 8 GPUs: ~2.5 MB per link, all links at once) instead of ten ring collectives
+    of 2 MiB queued one behind the other on the communicator's stream.  Shards of unequal height travel unpadded,
+    nothing is concatenated or re-indexed afterwards, ranks without rows at the level take no part.  The batch is
+    asynchronous: the engine extends + transforms the digits it OWNS (lf_ks_fwd) while the others are on the wire,
+    then orders its stream after the batch (with RCCL a stream dependency, not a host block) and does the rest.
+  * rescale (`fanout_into`): the dropped limb's rows of all operands, one message from their owner to each rank that
+    still holds rows at the next level.
 
 The reference stages both exchanges through pinned host memory (src/liberate/fhe/ckks_engine.py:778-810,
 999-1011) and starts extending only when every digit has landed on every GPU.
@@ -21,6 +23,17 @@ from __future__ import annotations
 
 import torch
 import torch.distributed as dist
+
+
+class _Works:
+    """The handles of one batch of messages."""
+
+    def __init__(self, works):
+        self.works = list(works)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
 
 
 class DistComm:
@@ -52,6 +65,44 @@ class DistComm:
         if not buf.is_contiguous():
             raise ValueError("broadcast_into needs a contiguous buffer (a row range of a [rows, N] tensor is)")
         return dist.broadcast(buf, src=self._global(src), group=self.group, async_op=async_op)
+
+    # ---- point-to-point exchanges ---------------------------------------------------------------------------------
+    def _p2p(self, buf):
+        # gloo moves host memory only: a rehearsal of the GPU engine over gloo (tests/test_distributed_gpu.py) falls
+        # back to collectives; RCCL and CPU tensors over gloo take the point-to-point batch
+        return not (buf.is_cuda and dist.get_backend(self.group) == "gloo")
+
+    def exchange_rows(self, buf, pieces, peers):
+        """All-pairs exchange, in place on the contiguous [rows, N] `buf`.  pieces = [(owner, first row, rows), ..]
+        (group ranks; every rank passes the same list), peers = the group ranks taking part.  This rank sends the
+        pieces it owns to every other peer and receives every other piece from its owner — one batch of asynchronous
+        point-to-point messages.  Returns a handle; `.wait()` orders the caller's current stream after the batch."""
+        if self.rank not in peers:
+            return _Works([])
+        if not self._p2p(buf):
+            return _Works([dist.broadcast(buf[row0:row0 + n], src=self._global(owner), group=self.group, async_op=True)
+                           for owner, row0, n in pieces])
+        ops = []
+        for owner, row0, n in pieces:
+            part = buf[row0:row0 + n]
+            if owner == self.rank:
+                ops += [dist.P2POp(dist.isend, part, self._global(p), self.group) for p in peers if p != self.rank]
+            else:
+                ops.append(dist.P2POp(dist.irecv, part, self._global(owner), self.group))
+        return _Works(dist.batch_isend_irecv(ops) if ops else [])
+
+    def fanout_into(self, buf, src, peers):
+        """The contiguous `buf` from group rank `src` to every rank of `peers` (in place, blocking the stream only)."""
+        if not self._p2p(buf):
+            dist.broadcast(buf, src=self._global(src), group=self.group)
+            return
+        if self.rank == src:
+            ops = [dist.P2POp(dist.isend, buf, self._global(p), self.group) for p in peers if p != src]
+        elif self.rank in peers:
+            ops = [dist.P2POp(dist.irecv, buf, self._global(src), self.group)]
+        else:
+            ops = []
+        _Works(dist.batch_isend_irecv(ops) if ops else []).wait()
 
     def all_gather(self, tensor):
         out = [torch.empty_like(tensor) for _ in range(self.world_size)]

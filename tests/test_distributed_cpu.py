@@ -1,7 +1,7 @@
 """Limb-sharded engine with one process per rank (world_size 2 and 3, gloo on CPU).
 
 Each rank owns the limbs `rns_partition` gives its device, the rescale row travels by broadcast and the
-key-switch digits by one in-place broadcast per run of same-owner digits (liberate_fhe_amd/fhe/comm.py); arithmetic is the checker backend so
+key-switch digits by one batch of in-place point-to-point messages (liberate_fhe_amd/fhe/comm.py); arithmetic is the checker backend so
 the test needs no GPU.  The combined shards must reproduce the golden digests that the REFERENCE engine
 produced with the same number of in-process devices (tests/golden/engine_digests.json, "small_x2"),
 and must equal this repo's single-process multi-device run for world_size 3.
@@ -117,23 +117,33 @@ def _schedule_worker(rank, world, port, outdir):
     from tests.oracle_backend import OracleBackend
     log = []
 
-    class SpyWork:
-        def __init__(self, work, tag):
-            self.work, self.tag = work, tag
+    class SpyWorks:
+        def __init__(self, works):
+            self.works = works
 
         def wait(self):
-            log.append(("wait", self.tag))
-            return self.work.wait()
+            log.append(("wait",))
+            return self.works.wait()
 
     class SpyComm(DistComm):
-        def broadcast_into(self, buf, src, async_op=False):
-            log.append(("bcast", src, buf.data_ptr(), tuple(buf.shape), async_op))
-            w = super().broadcast_into(buf, src, async_op=async_op)
-            return SpyWork(w, (src, buf.data_ptr())) if async_op else w
+        def exchange_rows(self, buf, pieces, peers):
+            log.append(("exchange", buf.data_ptr(), tuple(buf.shape), tuple(pieces), tuple(peers)))
+            return SpyWorks(super().exchange_rows(buf, pieces, peers))
+
+        def broadcast_into(self, *a, **k):
+            log.append(("broadcast_into",))
+            return super().broadcast_into(*a, **k)
 
         def all_gather(self, tensor):
             log.append(("all_gather",))
             return super().all_gather(tensor)
+
+    real_batch = dist.batch_isend_irecv
+
+    def spy_batch(ops):
+        log.append(("p2p", tuple(("send" if op.op is dist.isend else "recv", op.peer, tuple(op.tensor.shape)) for op in ops)))
+        return real_batch(ops)
+    dist.batch_isend_irecv = spy_batch
 
     class SpyBackend(OracleBackend):
         def ks_fwd(self, state, first, count, *a, **k):
@@ -155,52 +165,59 @@ def _schedule_worker(rank, world, port, outdir):
     tabs = eng._ks_tables(0)
     np.save(os.path.join(outdir, f"out.{rank}.npy"), np.stack([out.data[0][0].numpy(), out.data[1][0].numpy()]))
     import pickle
-    pickle.dump({"runs": runs, "groups": tabs["groups"], "total_rows": tabs["total_rows"], "N": eng.ctx.N},
+    pickle.dump({"runs": runs, "groups": tabs["groups"], "total_rows": tabs["total_rows"], "N": eng.ctx.N, "rank": rank},
                 open(os.path.join(outdir, f"log.{rank}.pkl"), "wb"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_key_switch_exchanges_per_digit_group_into_preallocated_buffers():
-    """One in-place broadcast per run of same-owner digits, un-padded, all issued before the first wait; each
-    group's extension + NTT (ks_fwd) starts right after ITS wait, the tail after the last; no all-gather, no
-    per-call buffer (the same addresses in a second call); results equal the single-process two-device run."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_key_switch_exchanges_point_to_point_into_preallocated_buffers(world):
+    """ONE batch of point-to-point messages per key switch: a rank sends each run of digits it owns to every other rank
+    and receives every other run from its owner, un-padded, straight into its rows of the storage-order buffer (the same
+    allocation in a second call); no collective.  The rank's own digits are extended + transformed (ks_fwd) BEFORE the
+    single wait, the foreign runs after it, the tail last; results equal the single-process multi-device run."""
     import pickle
     warnings.filterwarnings("ignore")
-    world = 2
-    port = 31500 + (os.getpid() % 2000)
+    port = 31500 + (os.getpid() % 2000) + world
     with tempfile.TemporaryDirectory() as outdir:
         mp.spawn(_schedule_worker, args=(world, port, outdir), nprocs=world, join=True)
         logs = [pickle.load(open(os.path.join(outdir, f"log.{r}.pkl"), "rb")) for r in range(world)]
         outs = [np.load(os.path.join(outdir, f"out.{r}.npy")) for r in range(world)]
     for rec in logs:
-        groups, N = rec["groups"], rec["N"]
+        groups, N, me = rec["groups"], rec["N"], rec["rank"]
         assert len(groups) >= 2
         first, second = rec["runs"]
         for run in (first, second):
-            assert ("all_gather",) not in run
-            bc = [e for e in run if e[0] == "bcast"]
-            assert [e[1] for e in bc] == [g[0] for g in groups]                       # one message per group, from its owner
-            assert [e[3] for e in bc] == [(g[4], N) for g in groups]                  # exactly the group's rows: no padding
-            assert all(e[4] for e in bc)                                              # asynchronous
-            # every message is issued before anything is waited for
-            assert max(i for i, e in enumerate(run) if e[0] == "bcast") < min(i for i, e in enumerate(run) if e[0] == "wait")
-            # wait(g) -> ks_fwd(g) -> wait(g+1) -> ... -> ks_tail
-            tail = [e for e in run if e[0] in ("wait", "ks_fwd", "ks_tail")]
-            want = []
-            for g, e in zip(groups, bc):
-                want += [("wait", (g[0], e[2])), ("ks_fwd", g[1], g[2])]
-            assert tail == want + [("ks_tail",)]
-        # destination rows of one storage-order buffer, the same allocation in both calls
-        p1 = [e[2] for e in first if e[0] == "bcast"]
-        p2 = [e[2] for e in second if e[0] == "bcast"]
-        assert p1 == p2
-        assert [p - p1[0] for p in p1] == [(g[3] - groups[0][3]) * N * 8 for g in groups]
-    # same words as one process driving two devices
+            assert ("all_gather",) not in run and ("broadcast_into",) not in run
+            ex = [e for e in run if e[0] == "exchange"]
+            assert len(ex) == 1 and ex[0][2] == (rec["total_rows"], N)
+            assert ex[0][3] == tuple((g[0], g[3], g[4]) for g in groups) and ex[0][4] == tuple(range(world))
+            p2p = [e for e in run if e[0] == "p2p"]
+            assert len(p2p) == 1
+            want_ops = []
+            for g in groups:
+                if g[0] == me:
+                    want_ops += [("send", p, (g[4], N)) for p in range(world) if p != me]
+                else:
+                    want_ops.append(("recv", g[0], (g[4], N)))
+            assert list(p2p[0][1]) == want_ops                                        # exactly the rows, no padding
+            # own digits before the wait, every foreign digit after it, in runs; then the tail
+            seq = [e for e in run if e[0] in ("wait", "ks_fwd", "ks_tail")]
+            assert seq.count(("wait",)) == 1 and seq[-1] == ("ks_tail",)
+            w = seq.index(("wait",))
+            own = [(g[1], g[2]) for g in groups if g[0] == me]
+            assert [(e[1], e[2]) for e in seq[:w]] == own
+            after = [(e[1], e[2]) for e in seq[w + 1:-1]]
+            covered = sorted(d for f, c in own + after for d in range(f, f + c))
+            assert covered == list(range(sum(g[2] for g in groups)))                  # every digit exactly once
+            assert all(g[0] != me for g in groups for f, c in after if f <= g[1] < f + c)
+        assert first[[e[0] for e in first].index("exchange")][1] == second[[e[0] for e in second].index("exchange")][1]
+    # same words as one process driving the devices
     from liberate_fhe_amd.fhe import ckks_engine
     from liberate_fhe_amd.utils import synth
     from tests.oracle_backend import OracleBackend
-    eng = ckks_engine(devices=["cpu"] * 2, backend=OracleBackend(), **FUSED)
+    eng = ckks_engine(devices=["cpu"] * world, backend=OracleBackend(), **FUSED)
     want = eng.rotate_single(synth.ciphertext(eng, 3, 0), synth.key_switch_key(eng, 6, origin="rotation key:1"))
     for r in range(world):
         assert (outs[r][0] == want.data[0][r].numpy()).all() and (outs[r][1] == want.data[1][r].numpy()).all()
