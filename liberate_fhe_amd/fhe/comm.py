@@ -59,13 +59,6 @@ class DistComm:
         dist.broadcast(tensor, src=self._global(src), group=self.group)
         return tensor
 
-    def broadcast_into(self, buf, src, async_op=False):
-        """In-place broadcast of the preallocated, contiguous `buf` (payload on group rank `src`, destination
-        elsewhere).  async_op: returns the work handle; `.wait()` orders the caller's current stream after it."""
-        if not buf.is_contiguous():
-            raise ValueError("broadcast_into needs a contiguous buffer (a row range of a [rows, N] tensor is)")
-        return dist.broadcast(buf, src=self._global(src), group=self.group, async_op=async_op)
-
     # ---- point-to-point exchanges ---------------------------------------------------------------------------------
     def _p2p(self, buf):
         # gloo moves host memory only: a rehearsal of the GPU engine over gloo (tests/test_distributed_gpu.py) falls

@@ -130,9 +130,9 @@ def _schedule_worker(rank, world, port, outdir):
             log.append(("exchange", buf.data_ptr(), tuple(buf.shape), tuple(pieces), tuple(peers)))
             return SpyWorks(super().exchange_rows(buf, pieces, peers))
 
-        def broadcast_into(self, *a, **k):
-            log.append(("broadcast_into",))
-            return super().broadcast_into(*a, **k)
+        def broadcast(self, *a, **k):
+            log.append(("broadcast",))
+            return super().broadcast(*a, **k)
 
         def all_gather(self, tensor):
             log.append(("all_gather",))
@@ -189,7 +189,7 @@ def test_sharded_key_switch_exchanges_point_to_point_into_preallocated_buffers(w
         assert len(groups) >= 2
         first, second = rec["runs"]
         for run in (first, second):
-            assert ("all_gather",) not in run and ("broadcast_into",) not in run
+            assert ("all_gather",) not in run and ("broadcast",) not in run
             ex = [e for e in run if e[0] == "exchange"]
             assert len(ex) == 1 and ex[0][2] == (rec["total_rows"], N)
             assert ex[0][3] == tuple((g[0], g[3], g[4]) for g in groups) and ex[0][4] == tuple(range(world))
