@@ -43,6 +43,7 @@ class DistComm:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
+        self._ops = {}
         self.local_device = local_device if local_device is not None else (
             f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cpu")
 
@@ -75,13 +76,21 @@ class DistComm:
         if not self._p2p(buf):
             return _Works([dist.broadcast(buf[row0:row0 + n], src=self._global(owner), group=self.group, async_op=True)
                            for owner, row0, n in pieces])
-        ops = []
-        for owner, row0, n in pieces:
-            part = buf[row0:row0 + n]
-            if owner == self.rank:
-                ops += [dist.P2POp(dist.isend, part, self._global(p), self.group) for p in peers if p != self.rank]
-            else:
-                ops.append(dist.P2POp(dist.irecv, part, self._global(owner), self.group))
+        # the message list of a (buffer, schedule) pair is built once: the engine's buffers and schedules live as long
+        # as the engine does, and the key switch is called thousands of times per second
+        key = (buf.data_ptr(), tuple(buf.shape), tuple(pieces), tuple(peers))
+        ops = self._ops.get(key)
+        if ops is None:
+            ops = []
+            for owner, row0, n in pieces:
+                part = buf[row0:row0 + n]
+                if owner == self.rank:
+                    ops += [dist.P2POp(dist.isend, part, self._global(p), self.group) for p in peers if p != self.rank]
+                else:
+                    ops.append(dist.P2POp(dist.irecv, part, self._global(owner), self.group))
+            if len(self._ops) > 256:
+                self._ops.clear()
+            self._ops[key] = ops
         return _Works(dist.batch_isend_irecv(ops) if ops else [])
 
     def fanout_into(self, buf, src, peers):
