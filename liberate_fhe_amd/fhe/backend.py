@@ -15,10 +15,15 @@ from .._native import lib, check
 from ..ntt import ntt_cuda, twiddles
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the stream handle without a Stream object per call
+
+
 def _ds(t: torch.Tensor):
     if t.device.type != "cuda":
         raise RuntimeError(f"HipBackend: tensor on {t.device}; device memory required (no CPU fallback)")
     idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    if _raw_stream is not None:
+        return idx, _raw_stream(idx)
     return idx, torch.cuda.current_stream(idx).cuda_stream
 
 
@@ -53,17 +58,20 @@ def _parr(tensors):
 
 class Consts:
     """Per-row Montgomery constants of a contiguous run of limbs on one device."""
-    __slots__ = ("ql", "qh", "kl", "kh", "_2q", "q_host")
+    __slots__ = ("ql", "qh", "kl", "kh", "_2q", "q_host", "_mont", "_qptr")
 
     def __init__(self, ql, qh, kl, kh, _2q, q_host=None):
         self.ql, self.qh, self.kl, self.kh, self._2q = ql, qh, kl, kh, _2q
         self.q_host = q_host   # numpy int64 copy of the primes (launch-time row classification)
+        # the vectors live as long as the object: validated and resolved once, not on every launch
+        self._mont = (_p(ql), _p(qh), _p(kl), _p(kh))
+        self._qptr = 0 if q_host is None else q_host.ctypes.data
 
     def qptr(self):
-        return 0 if self.q_host is None else self.q_host.ctypes.data
+        return self._qptr
 
     def mont(self):
-        return _p(self.ql), _p(self.qh), _p(self.kl), _p(self.kh)
+        return self._mont
 
 
 class HipBackend:

@@ -132,12 +132,22 @@ class ckks_engine(EvaluatorOps):
         return self.ntt.stops[0 if special else 1][dev] - self.ntt.starts[level][dev]
 
     def _tw(self, dev, level, special, inverse=False):
-        a, b = self.ntt.starts[level][dev], self.ntt.stops[0 if special else 1][dev]
-        return (self.ntt.ipsi if inverse else self.ntt.psi)[dev][a:b]
+        """Twiddle rows of device `dev`'s limbs at `level` (one view object per key: the backend keys its per-table
+        lookups on it)."""
+        key = ("tw", dev, level, special, inverse)
+        t = self._tables.get(key)
+        if t is None:
+            a, b = self.ntt.starts[level][dev], self.ntt.stops[0 if special else 1][dev]
+            t = self._tables[key] = (self.ntt.ipsi if inverse else self.ntt.psi)[dev][a:b]
+        return t
 
     def _vec(self, name, dev, level, special):
-        a, b = self.ntt.starts[level][dev], self.ntt.stops[0 if special else 1][dev]
-        return getattr(self.ntt, name)[dev][a:b]
+        key = ("vec", name, dev, level, special)
+        t = self._tables.get(key)
+        if t is None:
+            a, b = self.ntt.starts[level][dev], self.ntt.stops[0 if special else 1][dev]
+            t = self._tables[key] = getattr(self.ntt, name)[dev][a:b]
+        return t
 
     def _ws(self, key, shape, dev_id):
         """Reusable scratch tensor (never returned to the caller); one set per pipeline lane (see _lanes)."""
