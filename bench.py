@@ -222,26 +222,51 @@ def _max_over_ranks(ms, dev):
     return float(t.item())
 
 
+def _natural(eng, ct):
+    """{prime index: [comp 0 row, comp 1 row]} of the rows THIS process holds of a ciphertext."""
+    dest = eng.ntt.p.destination_arrays[ct.level]
+    out = {}
+    for i, d in enumerate(dd for dd in eng.local_ids if dd < len(dest)):
+        for r, prime in enumerate(dest[d]):
+            out[prime] = [ct.data[0][i][r], ct.data[1][i][r]]
+    return out
+
+
 def multi_gpu_rates(dev, world, rank, out, sharded=True):
     """N > 1.  Fills `out` (a dict that main() prints even if a leg below never returns, see the watchdog):
       replicas      gold cc_mult(+relinearize) on N independent engines, zero communication: N x single rate;
       config 5      64 gold ciphertexts rotated under one key, 64 / N per rank (batch replicas, full key per GPU);
-      config 4      gold cc_mult LIMB-SHARDED over the N ranks by rns_partition: rescale rows by one in-place RCCL
-                    broadcast, key-switch digits by one asynchronous in-place broadcast per run of same-owner digits,
-                    each group extended + transformed as it lands (fhe/comm.py, lf_ks_fwd / lf_ks_tail); plus
-                    limb-sharded rotate_single.
-    Every leg is fenced by barriers on the default group and catches its own exceptions; the sharded legs run on
-    their OWN process group with a short timeout, so a rank that fails inside them cannot hang the line."""
+      config 4      gold cc_mult LIMB-SHARDED over the N ranks by rns_partition: the dropped limb's rows fan out point
+                    to point from their owner, the key-switch digits travel as ONE batch of point-to-point messages
+                    (RCCL send / recv over xGMI) while each rank extends + transforms the digits it owns (fhe/comm.py,
+                    lf_ks_fwd / lf_ks_tail); plus limb-sharded rotate_single.
+    The sharded legs are PARITY-GATED: before anything is timed every rank compares the rows it holds of the sharded
+    results — level 0 -> 1, and 9 -> 10 + two key switches at level 10, where the last rank has run out of rows —
+    word for word with the unsharded engine of the replica leg on the same rank; a mismatch anywhere withholds the
+    rates.  Every leg is fenced by barriers on the default group and catches its own exceptions; the sharded legs run
+    on their OWN process group with a short timeout, so a rank that fails inside them cannot hang the line."""
     import datetime
     import torch.distributed as dist
     from liberate_fhe_amd.fhe import ckks_engine, presets
     from liberate_fhe_amd.utils import synth
     params = {k: v for k, v in presets.params["gold"].items() if k != "devices"}
+
+    def parity_ops(eng, evk, rotk):
+        a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
+        a9, b9 = synth.ciphertext(eng, 7, 9), synth.ciphertext(eng, 8, 9)
+        res = [eng.cc_mult(a, b, evk), eng.rotate_single(a, rotk), eng.cc_mult(a9, b9, evk)]
+        res.append(eng.rotate_single(res[-1], rotk))
+        res.append(eng.rotate_single(res[-1], rotk))      # same digit buffer, same cached message list
+        return res
+
+    want = None
     try:
         eng = ckks_engine(devices=[dev], **params)
         a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
         evk = synth.key_switch_key(eng, 5)
         rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
+        if sharded:
+            want = [_natural(eng, ct) for ct in parity_ops(eng, evk, rotk)]
         for _ in range(40):
             eng.cc_mult(a, b, evk)
         torch.cuda.synchronize()
@@ -274,9 +299,25 @@ def multi_gpu_rates(dev, world, rank, out, sharded=True):
         from liberate_fhe_amd.fhe.comm import DistComm
         grp = dist.new_group(ranks=list(range(world)), timeout=datetime.timedelta(seconds=120))
         eng = ckks_engine(devices=[dev], comm=DistComm(group=grp, local_device=dev), **params)
-        a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
         evk = synth.key_switch_key(eng, 5)
         rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
+        # parity gate (every rank, every row it holds)
+        bad = 1 if want is None else 0
+        if want is not None:
+            for ref, ct in zip(want, parity_ops(eng, evk, rotk)):
+                for prime, rows in _natural(eng, ct).items():
+                    for comp in range(2):
+                        if not torch.equal(rows[comp], ref[prime][comp]):
+                            bad += 1
+        t = torch.tensor([bad], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=grp)
+        if int(t.item()):
+            out["multi_gpu_limb_sharded_error"] = (f"parity gate: {int(t.item())} row(s) of the limb-sharded results differ from the "
+                                                   "unsharded engine (or no reference was computed); rates withheld")
+            return
+        out["limb_sharded_parity"] = ("bit-exact vs the unsharded engine on every rank: cc_mult 0->1, rotate at 0, cc_mult 9->10, "
+                                      "two rotations at level 10 (at 8 ranks the last one holds no rows there)")
+        a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
         for _ in range(20):
             eng.cc_mult(a, b, evk)
         torch.cuda.synchronize()
@@ -294,6 +335,28 @@ def multi_gpu_rates(dev, world, rank, out, sharded=True):
         out["multi_gpu_limb_sharded_error"] = f"{type(e).__name__}: {e}"[:300]
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: this process has made NO GPU call (importing torch makes none);
+    it starts N fresh rank processes through torch.distributed.run — one per GPU, RCCL — lets rank 0's single JSON line
+    through on the inherited stdout, and leaves with the launcher's exit code (non-zero if any rank failed).  Nothing
+    is exec'ed over a process that has touched the GPU."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()          # does not initialise the GPU
+    if have < n and os.environ.get("LF_BENCH_REHEARSE") != "1":
+        print(f"bench.py --gpus {n}: this box has {have} GPU(s)", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -307,6 +370,8 @@ def main():
                     help="N > 1: seconds after which the multi-GPU engine legs are abandoned and the line is printed without them")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -325,6 +390,8 @@ def main():
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")   # a failed collective raises instead of blocking
         if rehearse:
             dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
+            from tests import gloo_device_p2p      # gloo moves host memory only: device messages are staged (test transport)
+            gloo_device_p2p.install()
         else:
             dist.init_process_group("nccl", device_id=torch.device(dev), timeout=datetime.timedelta(seconds=900))
 
@@ -481,8 +548,8 @@ def main():
         result["cpu_baseline"] = None   # reported by the N=1 run only
     if world > 1 and not args.no_extra:
         # The engine legs run under a watchdog: if they are not back after --leg-timeout seconds (a rank stuck in
-        # a collective), rank 0 prints the line with what has been measured so far and every rank leaves with
-        # os._exit — nothing is re-exec'ed, the process just ends.
+        # an exchange), rank 0 prints the line with what has been measured so far and every rank leaves with
+        # os._exit(3) — nothing is re-exec'ed, the process just ends, and the launcher reports the failure.
         import threading
         done = threading.Event()
 
@@ -491,7 +558,7 @@ def main():
                 extra["multi_gpu_legs_abandoned_after_s"] = args.leg_timeout
                 if rank == 0:
                     print(json.dumps(result), flush=True)
-                os._exit(0)
+                os._exit(3)     # a hung leg is a failure: the partial line is printed, the exit code says so
         threading.Thread(target=watchdog, daemon=True).start()
         multi_gpu_rates(dev, world, rank, extra, sharded=not args.no_sharded)
         done.set()

@@ -89,9 +89,11 @@ int lf_mont_sub(const int64_t *a, const int64_t *b, int64_t *c, int rows, int64_
  * below 2^41 hold the plain canonical twiddles as doubles in words [0, N) and run the fp64-FMA butterfly path;
  * results are bit-identical to the integer path.  Limbs with a larger prime hold N pairs (floor(w 2^64 / q), w)
  * with w the plain twiddle: the Shoup products of the relaxed transforms (the exact ops never read them).
- * q_host (optional, may be NULL): HOST array of the `rows` primes, used only to split the rows into the
- * two arithmetic classes at launch time (each class has its own kernel instantiation); with NULL every
- * row runs the integer class.
+ * q_host (optional for the exact ops, may be NULL; REQUIRED with LF_NTT_RELAXED): HOST array of the `rows` primes,
+ * used to split the rows into the two arithmetic classes at launch time (each class has its own kernel
+ * instantiation); with NULL every row of an exact op runs the integer class.  A relaxed call without psi_dp or
+ * without q_host returns LF_ERR_ARG before anything is launched: lf_twiddle_dp lays each auxiliary row out by the
+ * size of its prime, so the launch must know the primes to read it.
  * flags: LF_NTT_RELAXED = the caller only needs the result modulo q (outputs are then canonical
  * residues instead of the reference's lazy representatives) — for fused internal use, never for the
  * drop-in ops.  A relaxed FORWARD transform accepts the reference's signed-lazy words (|a| < 2q); a relaxed

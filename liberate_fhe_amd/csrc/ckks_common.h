@@ -39,51 +39,18 @@ static __device__ __forceinline__ i64 mm62s(i64 a, i64 b, u64 q, u64 k) {
     return xh + (i64)__umul64hi(s << 2, q) + (i64)(xl != 0);
 }
 
-// x >> 32 of a 64-bit value as ONE instruction: the compiler builds the zero-extended pair with a move and a
-// zero-initialised register per use (ten v_mov per butterfly in the integer-class kernels)
-static __device__ __forceinline__ u64 shr32(u64 x) {
-    u64 r;
-    asm("v_lshrrev_b64 %0, 32, %1" : "=v"(r) : "v"(x));
-    return r;
-}
-static __device__ __forceinline__ u64 mad32(unsigned a, unsigned b, u64 c) { return (u64)a * (u64)b + c; }   // v_mad_u64_u32
-
 // Same for operands known to be non-negative and below 2^61 (butterflies, key products: both in [0, 2q), q < 2^60).
 // One operand enters pre-shifted by 2 (4a < 2^63): the 128-bit product 4ab then has (ab >> 62) as its high word and
 // 4 * (ab mod 2^62) as its low word, and low * k mod 2^64 IS 4 * s — no masks, no 62-bit realignment.
-// -DLF_MM62U_LIMBS (experiment, measured no faster in the kernels: 320 vs 311 us for the integer-class tiled pass,
-// although 4 instructions shorter per butterfly in isolation) writes it on 32-bit limbs so that every multiply-add
-// chain carries its running sum in the 64-bit addend:
-//   product : t0 = a0 b0;  m = a1 b0 + (t0 >> 32);  m += a0 b1  (< 2^64: a1 < 2^31, b1 < 2^29);  xh = a1 b1 + (m >> 32)
-//   s = lo * k mod 2^64 on the low words (l0, l1) = (t0, m)
-//   (s q + lo) >> 64, whose low 64 bits cancel:  u0 = s0 q0 + l0;  u1 = s0 q1 + (u0 >> 32);  d = s1 q0 + l1;
-//             e = (u1 >> 32) + (d >> 32) + [low words of u1, d not both zero];  r = s1 q1 + e
-// Equal to the closed form for all operands in range (checked on random words against big integers, and by every
-// bit-exactness test of the integer class).
+// (The same function on explicit 32-bit limbs, every multiply-add chain carrying its sum in the 64-bit addend, is 4
+// instructions shorter in isolation and measured no faster inside the kernels: 320 vs 311 us for the integer-class
+// tiled pass)
 static __device__ __forceinline__ i64 mm62u(u64 a, u64 b, u64 q, u64 k) {
-#ifndef LF_MM62U_LIMBS
     const u128 x = (u128)(a << 2) * (u128)b;
     const u64 lo = (u64)x;              // 4 * xl
     const u64 xh = (u64)(x >> 64);      // (a * b) >> 62
     const u64 s4 = lo * k;              // 4 * ((xl * k) mod 2^62), exactly (mod 2^64)
     return (i64)(xh + __umul64hi(s4, q) + (u64)(lo != 0));
-#else
-    const u64 a4 = a << 2;
-    const unsigned a0 = (unsigned)a4, a1 = (unsigned)(a4 >> 32), b0 = (unsigned)b, b1 = (unsigned)(b >> 32);
-    const unsigned k0 = (unsigned)k, k1 = (unsigned)(k >> 32), q0 = (unsigned)q, q1 = (unsigned)(q >> 32);
-    const u64 t0 = mad32(a0, b0, 0);
-    u64 m = mad32(a1, b0, shr32(t0));
-    m = mad32(a0, b1, m);
-    const u64 xh = mad32(a1, b1, shr32(m));
-    const unsigned l0 = (unsigned)t0, l1 = (unsigned)m;
-    const u64 p = mad32(l0, k0, 0);
-    const unsigned s0 = (unsigned)p, s1 = (unsigned)(p >> 32) + l0 * k1 + l1 * k0;
-    const u64 u0 = mad32(s0, q0, (u64)l0);
-    const u64 u1 = mad32(s0, q1, shr32(u0));
-    const u64 d = mad32(s1, q0, (u64)l1);
-    const u64 e = shr32(u1) + shr32(d) + (u64)(((unsigned)u1 | (unsigned)d) != 0);
-    return (i64)(xh + mad32(s1, q1, e));
-#endif
 }
 
 // REDC62 of a signed 128-bit value x, |x| < 2^124: (x + ((x*k) mod R) * q) / R — the tail of mm62s without the product.

@@ -188,11 +188,9 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ks_ext_pass1(const i6
 }
 
 // both arithmetic classes in one launch (integer-class blocks first), see ntt_fwd_pass_mixed
-#ifndef LF_KS_EXT_WAVES
-#define LF_KS_EXT_WAVES 8   // waves per SIMD the kernel is compiled for: 63 VGPRs, no spill, four blocks per CU (LDS) instead of
-                            // the three of the 6-wave build (80 VGPRs); measured at gold: rotate 409-414 -> 402 us, cc_mult 557 -> 540-545 us
-#endif
-__global__ void __launch_bounds__(NTT_THREADS, LF_KS_EXT_WAVES) ks_ext_pass1_mixed(const i64 *__restrict__ state, i64 *__restrict__ tmp,
+#define KS_EXT_WAVES 8   // waves per SIMD the kernel is compiled for: 63 VGPRs, no spill, four blocks per CU (LDS) instead of
+                         // the three of the 6-wave build (80 VGPRs); measured at gold: rotate 409-414 -> 402 us, cc_mult 557 -> 540-545 us
+__global__ void __launch_bounds__(NTT_THREADS, KS_EXT_WAVES) ks_ext_pass1_mixed(const i64 *__restrict__ state, i64 *__restrict__ tmp,
                                                                        KsGeom kg, ClassLists cl, const i64 *__restrict__ desc,
                                                                        const i64 *__restrict__ E, const double *__restrict__ Ed,
                                                                        const i64 *__restrict__ psi_br,
@@ -449,14 +447,11 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
     classify_rows(rows, q_host, dp, in);
     const unsigned tiles = 1u << (logN - tl);
     const unsigned polys = (unsigned)nparts * (unsigned)nct;   // extended digits of all ciphertexts: one stack
-    const bool mixed = dp.n && in.n && mixed_enabled();   // both arithmetic classes in one launch per step
+    const bool mixed = dp.n && in.n;   // both arithmetic classes in one launch per step
     // K2: extend + strided pass — as one register step per column when the strided pass has at most 4 stages
-#ifndef LF_KS_EXT_COLS
-#define LF_KS_EXT_COLS 1   // 0: the LDS-tiled form for every size (A/B switch)
-#endif
     // (measured on MI355X, extension kernel alone: silver / logN 15 22.5 -> 20.0 us; gold / logN 16 95 -> 116 us — 16 words
     // per column cost 90 VGPRs and 64 loads in flight per thread — so logN 16 keeps the LDS-tiled form)
-    if (LF_KS_EXT_COLS && S1 <= 3) {
+    if (S1 <= 3) {
         const unsigned per_limb = ((1u << tl) / NTT_COL_THREADS) * polys;   // column chunks x digits x ciphertexts
         const ClassLists cl = class_lists(in, dp, per_limb * (unsigned)in.n);   // either list may be empty
         const dim3 grid((unsigned)cl.in_blocks + per_limb * (unsigned)dp.n), block(NTT_COL_THREADS);
@@ -484,23 +479,8 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
     // contiguous forward pass, in place on tmp (relaxed)
     {
         const PassGeom g{logN, tl, 0, tl, S1, 0, rows, (int)polys, 1, 1, 0};
-        const unsigned per_row = polys << (logN - tl);
-        if (LF_TILE16) {
-            launch_pass16(false, 1, (int)polys, st, (const i64 *)tmp, (i64 *)tmp, g, in, dp, (const i64 *)psi_br, psi_dp,
-                          (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
-        } else if (mixed) {
-            const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
-            hipLaunchKernelGGL((ntt_fwd_pass_mixed<true>), dim3((unsigned)cl.in_blocks + per_row * dp.n), dim3(NTT_THREADS), 0, st,
-                               (i64 *)tmp, g, cl, (const i64 *)psi_br, psi_dp, (const i64 *)nullptr, (const i64 *)ql,
-                               (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
-        } else if (dp.n)
-            hipLaunchKernelGGL((ntt_fwd_pass<true, true>), dim3(per_row * dp.n), dim3(NTT_THREADS), 0, st, (i64 *)tmp, g, dp,
-                               (const i64 *)psi_br, psi_dp, (const i64 *)nullptr, (const i64 *)ql, (const i64 *)qh,
-                               (const i64 *)kl, (const i64 *)kh);
-        if (!LF_TILE16 && in.n && !mixed)
-            hipLaunchKernelGGL((ntt_fwd_pass<false, true>), dim3(per_row * in.n), dim3(NTT_THREADS), 0, st, (i64 *)tmp, g, in,
-                               (const i64 *)psi_br, psi_dp, (const i64 *)nullptr, (const i64 *)ql, (const i64 *)qh,
-                               (const i64 *)kl, (const i64 *)kh);
+        launch_pass16(false, 1, (int)polys, st, (const i64 *)tmp, (i64 *)tmp, g, in, dp, (const i64 *)psi_br, psi_dp,
+                      (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     }
     return (int)hipGetLastError();
 }
@@ -514,7 +494,7 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
     const int tl = NTT_TILE_LOG_MAX, S1 = logN - tl;
     RowList dp, in;
     classify_rows(rows, q_host, dp, in);
-    const bool mixed = dp.n && in.n && mixed_enabled();
+    const bool mixed = dp.n && in.n;
     // K3: inner product with the key, summed over the digits
     {
         const i64 N = (i64)1 << logN;
@@ -536,12 +516,12 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
     for (int pass = 0; pass < 2; ++pass) {
         PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, inv_polys, 1, 0, 0}
                                : PassGeom{logN, tl, 1, S1, tl, tl - S1, rows, inv_polys, 1, 1, 0};
-        if (LF_TILE16 && pass == 0) {
+        if (pass == 0) {
             launch_pass16(true, 1, inv_polys, st, (const i64 *)s, (i64 *)s, g, in, dp, (const i64 *)ipsi_br, ipsi_dp,
                           (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
             continue;
         }
-        if (pass == 1 && S1 <= 4 && cols_enabled()) {
+        if (pass == 1 && S1 <= 4) {
             if (mixed) {
                 launch_inv_cols_mixed(S1, inv_polys, st, (i64 *)s, g, in, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,
                                       (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);

@@ -6,9 +6,8 @@
 #include <stdlib.h>
 
 #define NTT_THREADS 512
-#ifndef LF_PASS_WAVES
-#define LF_PASS_WAVES 6   // waves per SIMD the mixed pass kernels are compiled for (80 VGPRs = 3 blocks per CU)
-#endif
+#define NTT_PASS_WAVES 6   // waves per SIMD the mixed pass kernels are compiled for (80 VGPRs = 3 blocks per CU; 4 and 8
+                           // were measured slower)
 #define NTT_LDS_WORDS ((1 << NTT_TILE_LOG_MAX) + (1 << (NTT_TILE_LOG_MAX - 3)))
 #define TAIL_NONE (-1)
 #define SMALL_PRIME_LIMIT (1ull << 41)
@@ -69,7 +68,6 @@ struct PassGeom {
     int last;      // 1: last pass of the transform
     int plain;     // relaxed only: fp64-class limbs work in the PLAIN domain — no Montgomery entry on the way in
                    // (Rs applies to integer-class limbs only), inverse tail multiplies by N^-1 instead of N^-1 R^-1
-    int noreg;     // experiment knob (LF_NTT_REGTILE=0): 4096-word contiguous passes in the LDS-resident form
 };
 
 // tile-local index -> coefficient index of the row
@@ -140,20 +138,15 @@ struct RowDp {
     double q, q2, qinv, q2inv;
 };
 
-// r < 0 ? r + m : r in three fp64 instructions: floor(r * 2^-64) is -1 for r < 0 and 0 otherwise (|r| < 2^53).
-// (Masking m with the sign bit costs four: shift, two 32-bit ANDs, add; measured 1 % slower on the tiled pass.)
+// r < 0 ? r + m : r in two fp64 instructions (|r| < 2^53).
+// (floor(r * 2^-64) as the indicator costs three; masking m with the sign bit four: both measured slower.)
 __device__ __forceinline__ double dp_addmask(double r, double m) {
-#ifdef LF_NO_CLAMP_FIX
-    const double neg = __builtin_floor(r * 5.421010862427522e-20);
-    return __builtin_fma(-neg, m, r);
-#else
     // r is an INTEGER-valued double: r < 0 means r <= -1, so clamp(-r) to [0, 1] (the VOP3 output modifier) IS the
     // indicator [r < 0] — one instruction instead of the multiply + floor pair (-0.0 never occurs: a zero sum of
     // two opposite doubles is +0.0 under round-to-nearest)
     // (fmin(fmax(x, 0), 1) is the form the compiler folds into the clamp bit: v_max_f64 neg, -r, -r clamp)
     const double neg = __builtin_fmin(__builtin_fmax(-r, 0.0), 1.0);
     return __builtin_fma(neg, m, r);
-#endif
 }
 
 // (a * w) mod q, canonical, for a < 2^52, w < q: exact via the FMA low part.
@@ -314,16 +307,8 @@ struct ArithDp {
     // lazy REDC62(S * O) for O = o (any representative < 2^52 of the lazy word mod 2q)
     static __device__ __forceinline__ T mul(const Ctx &c, W w, T o, int idx) {
         T v = dp_mulmod(o, w, c.d);
-#ifdef LF_UNIFORM_GUARD
-        // wave-uniform test first: the scalar branch lets the compiler move the (rare) repair out of the fast path
-        if (!c.relaxed && __builtin_expect(__builtin_amdgcn_ballot_w64(dp_below_fix_limit(v)) != 0, 0)) {
-            if (dp_below_fix_limit(v))
-                v = dp_lazy_fix(v, (u64)c.tw_mont[idx], (u64)dp_reduce(o, c.d.q2, c.d.q2inv), c.d.q);
-        }
-#else
         if (!c.relaxed && dp_below_fix_limit(v))
             v = dp_lazy_fix(v, (u64)c.tw_mont[idx], (u64)dp_reduce(o, c.d.q2, c.d.q2inv), c.d.q);
-#endif
         return v;
     }
     static __device__ __forceinline__ void fwd(const Ctx &c, T &a, T &b, W w, int idx) {
@@ -696,9 +681,6 @@ __device__ __forceinline__ void wave_lds_sync() {
 // KEEP: the thread index stays in ONE register for the whole tile (relaxed kernels: no out-of-line call that would
 // spill it); otherwise it is rebuilt from the wave index and v_mbcnt at every use (see lf_tid).
 // CHECK: the tile may hold a word outside [0, 2q) (flag word written by wave_flag_set): relaxed fp64 tiles never do.
-#ifndef LF_EXACT_KEEP
-#define LF_EXACT_KEEP false
-#endif
 #define LF_TID(KEEP, w0) ((KEEP) ? (w0) : lf_tid())
 template <class A, bool KEEP, bool CHECK>
 __device__ __forceinline__ bool fwd_tile12_core(typename A::T *smt, i64 *sm, typename A::T (&x)[8], int s, int E, int base,
@@ -788,7 +770,7 @@ __device__ __forceinline__ bool fwd_tile12(i64 *sm, i64 *__restrict__ row, int t
         }
         if (!RLX) wave_flag_set(sm, odd);
         const bool ok = RLX ? fwd_tile12_core<ArithDpR, true, false>(smd, sm, x, g.s0, g.logN, base, c, w)
-                            : fwd_tile12_core<ArithDp, LF_EXACT_KEEP, true>(smd, sm, x, g.s0, g.logN, base, c, w);
+                            : fwd_tile12_core<ArithDp, false, true>(smd, sm, x, g.s0, g.logN, base, c, w);
         if (!ok) return false;
         // the pass accumulated without subtractions: back to the lazy word in [0, 2q) (relaxed: canonical residue)
         const double md = RLX ? c.d.q : c.d.q2, mi = RLX ? c.d.qinv : c.d.q2inv;
@@ -807,7 +789,7 @@ __device__ __forceinline__ bool fwd_tile12(i64 *sm, i64 *__restrict__ row, int t
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = raw[e];
     }
-    store_tile12_regs(sm, o, row + base, LF_TID(RLX || LF_EXACT_KEEP, w));
+    store_tile12_regs(sm, o, row + base, LF_TID(RLX, w));
     return true;
 }
 
@@ -966,7 +948,7 @@ __device__ __forceinline__ void fwd_pass_body(i64 *sm, int b, i64 *__restrict__ 
         const i64 rs = enter ? Rs[crow] : 0;
 
         // contiguous 4096-word pass: register-fed form; false = the tile holds a word outside [0, 2q)
-        if (g.tl == 12 && g.S == 12 && !g.strided && !g.noreg) {
+        if (g.tl == 12 && g.S == 12 && !g.strided) {
             if (fwd_tile12<DP, RLX>(sm, row, tile, g, c, enter, rs)) return;
         }
 
@@ -1049,7 +1031,7 @@ struct ClassLists {
 };
 
 template <bool RLX>
-__global__ void __launch_bounds__(NTT_THREADS, LF_PASS_WAVES) ntt_fwd_pass_mixed(i64 *__restrict__ a, PassGeom g, ClassLists cl,
+__global__ void __launch_bounds__(NTT_THREADS, NTT_PASS_WAVES) ntt_fwd_pass_mixed(i64 *__restrict__ a, PassGeom g, ClassLists cl,
                                                                        const i64 *__restrict__ psi_br,
                                                                        const double *__restrict__ psi_dp,
                                                                        const i64 *__restrict__ Rs, const i64 *__restrict__ ql,
@@ -1267,7 +1249,7 @@ __device__ __forceinline__ void inv_pass_body(i64 *sm, int b, const i64 *src, i6
         const i64 qq = (i64)c.m.q;
 
         // contiguous 4096-word pass: register-fed form; false = the tile holds a word outside [0, 2q)
-        if (g.tl == 12 && g.S == 12 && !g.strided && !g.noreg) {
+        if (g.tl == 12 && g.S == 12 && !g.strided) {
             if (inv_tile12<DP, RLX>(sm, src + ((i64)(poly * g.rows + crow) << g.logN), row, tile, g, c, Ninv, tail, crow)) return;
         }
 
@@ -1355,7 +1337,7 @@ __global__ void __launch_bounds__(NTT_THREADS, DP ? 6 : 4) ntt_inv_pass_io(const
 }
 
 template <bool RLX>
-__global__ void __launch_bounds__(NTT_THREADS, LF_PASS_WAVES) ntt_inv_pass_mixed(const i64 *src, i64 *dst, PassGeom g, ClassLists cl,
+__global__ void __launch_bounds__(NTT_THREADS, NTT_PASS_WAVES) ntt_inv_pass_mixed(const i64 *src, i64 *dst, PassGeom g, ClassLists cl,
                                                                        const i64 *__restrict__ ipsi_br,
                                                                        const double *__restrict__ ipsi_dp,
                                                                        const i64 *__restrict__ Ninv, int tail,
@@ -1510,10 +1492,8 @@ inline void launch_inv_cols(int K, int polys, hipStream_t st, i64 *base, const P
 #undef LF_ICOLS_CASE
 }
 
-// both arithmetic classes of a pass go into one launch whenever both are present (the split form — integer class
-// on a side stream — was the round-1 A/B loser and is only used when a transform has a single class)
-inline bool mixed_enabled() { return true; }
-
+// (both arithmetic classes of a pass go into one launch whenever both are present: the split form — integer class on
+// a side stream — was the round-1 A/B loser; single-class launches only serve transforms that have a single class)
 inline ClassLists class_lists(const RowList &in, const RowList &dp, unsigned in_blocks) {
     ClassLists cl;
     cl.in = in;
@@ -1546,10 +1526,8 @@ inline void launch_inv_cols_mixed(int K, int polys, hipStream_t st, i64 *base, c
     }
 }
 
-// the strided pass runs as a column kernel whenever it has at most 4 stages (logN <= 16); beyond that the
-// LDS-tiled strided pass takes over
-inline bool cols_enabled() { return true; }
-
+// (the strided pass runs as a column kernel whenever it has at most 4 stages, logN <= 16; beyond that the LDS-tiled
+// strided pass takes over)
 // the tiled-pass kernels carry their arithmetic mode (exact lazy words / relaxed residues) as a template parameter
 #define LF_LAUNCH_MIXED(KERN, relaxed, ...)                                   \
     do {                                                                      \
@@ -1561,10 +1539,6 @@ inline bool cols_enabled() { return true; }
         if (relaxed) hipLaunchKernelGGL((KERN<DP, true>), __VA_ARGS__);       \
         else hipLaunchKernelGGL((KERN<DP, false>), __VA_ARGS__);              \
     } while (0)
-
-// 4096-word contiguous passes run in the register-fed form (the LDS-resident form is its fallback for tiles
-// holding words outside [0, 2q))
-inline int regtile_disabled() { return 0; }
 
 // plain canonical twiddles as doubles from the Montgomery table: w = reduce(redc(S))
 __global__ void __launch_bounds__(256) twiddle_dp_kernel(const i64 *__restrict__ mont, double *__restrict__ out, i64 N,

@@ -24,9 +24,6 @@
 #pragma once
 #include "ckks_ntt_core.h"
 
-#ifndef LF_TILE16
-#define LF_TILE16 1   // 0: keep the 8-words-per-thread kernels for every size (A/B switch)
-#endif
 #define NTT16_THREADS 256
 #define PAD16(L) ((L) + ((L) >> 4))
 #define NTT16_LDS_WORDS (4096 + 256)

@@ -67,7 +67,10 @@ class Consts:
         self._mont = (_p(ql), _p(qh), _p(kl), _p(kh))
         self._qptr = 0 if q_host is None else q_host.ctypes.data
 
-    def qptr(self):
+    def qptr(self, relaxed=False):
+        if relaxed and not self._qptr:
+            raise ValueError("relaxed transforms need the host primes (Consts(q_host=...)): the auxiliary twiddle rows "
+                             "are laid out by the size of the prime")
         return self._qptr
 
     def mont(self):
@@ -92,7 +95,7 @@ class HipBackend:
         plain (with relaxed): fp64-class limbs stay in the plain domain (see LF_NTT_PLAIN)."""
         dev, st = _ds(buf)
         dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
-        check(lib.lf_ntt(_p(buf), batch, rows, logN, _p(psi), dp, c.qptr(), _p(Rs), (1 if relaxed else 0) | (2 if relaxed and plain else 0), _p(c._2q),
+        check(lib.lf_ntt(_p(buf), batch, rows, logN, _p(psi), dp, c.qptr(relaxed), _p(Rs), (1 if relaxed else 0) | (2 if relaxed and plain else 0), _p(c._2q),
                          *c.mont(), dev, st), "lf_ntt")
 
     def rescale_ntt(self, srcs, row0s, buf, rows, logN, scales, round_at, psi, Rs, c: Consts, relaxed=False, plain=False):
@@ -100,13 +103,13 @@ class HipBackend:
         dev, st = _ds(buf)
         dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
         check(lib.lf_rescale_ntt(_parr(srcs), _parr(row0s), len(srcs), _p(buf), rows, logN, _p(scales), round_at, _p(psi), dp,
-                                 c.qptr(), _p(Rs), (1 if relaxed else 0) | (2 if relaxed and plain else 0), _p(c._2q),
+                                 c.qptr(relaxed), _p(Rs), (1 if relaxed else 0) | (2 if relaxed and plain else 0), _p(c._2q),
                                  *c.mont(), dev, st), "lf_rescale_ntt")
 
     def intt(self, buf, batch, rows, logN, ipsi, Ninv, tail, c: Consts, relaxed=False, plain=False):
         dev, st = _ds(buf)
         dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
-        check(lib.lf_intt(_p(buf), batch, rows, logN, _p(ipsi), dp, c.qptr(), _p(Ninv), tail,
+        check(lib.lf_intt(_p(buf), batch, rows, logN, _p(ipsi), dp, c.qptr(relaxed and tail >= 2), _p(Ninv), tail,
                           (3 if plain else 1) if relaxed and tail >= 2 else 0, _p(c._2q), *c.mont(), dev, st), "lf_intt")
 
     def galois(self, a, dst, rows, logN, p, _2q):

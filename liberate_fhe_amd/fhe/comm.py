@@ -21,6 +21,8 @@ The reference stages both exchanges through pinned host memory (src/liberate/fhe
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -61,26 +63,24 @@ class DistComm:
         return tensor
 
     # ---- point-to-point exchanges ---------------------------------------------------------------------------------
-    def _p2p(self, buf):
-        # gloo moves host memory only: a rehearsal of the GPU engine over gloo (tests/test_distributed_gpu.py) falls
-        # back to collectives; RCCL and CPU tensors over gloo take the point-to-point batch
-        return not (buf.is_cuda and dist.get_backend(self.group) == "gloo")
-
+    # Device buffers need a backend that moves device memory point to point: RCCL ("nccl").  gloo carries host tensors
+    # only — the CPU test-suite runs this very code over it; a GPU rehearsal over gloo installs the host-staging
+    # transport of tests/gloo_device_p2p.py underneath dist.batch_isend_irecv (test infrastructure, not a fallback).
     def exchange_rows(self, buf, pieces, peers):
         """All-pairs exchange, in place on the contiguous [rows, N] `buf`.  pieces = [(owner, first row, rows), ..]
         (group ranks; every rank passes the same list), peers = the group ranks taking part.  This rank sends the
         pieces it owns to every other peer and receives every other piece from its owner — one batch of asynchronous
-        point-to-point messages.  Returns a handle; `.wait()` orders the caller's current stream after the batch."""
+        point-to-point messages.  Returns a handle; `.wait()` orders the caller's current stream after the batch.
+        Ranks outside `peers` (no rows at the level) neither send nor receive: nothing here is a whole-group collective."""
         if self.rank not in peers:
             return _Works([])
-        if not self._p2p(buf):
-            return _Works([dist.broadcast(buf[row0:row0 + n], src=self._global(owner), group=self.group, async_op=True)
-                           for owner, row0, n in pieces])
         # the message list of a (buffer, schedule) pair is built once: the engine's buffers and schedules live as long
         # as the engine does, and the key switch is called thousands of times per second
         key = (buf.data_ptr(), tuple(buf.shape), tuple(pieces), tuple(peers))
-        ops = self._ops.get(key)
-        if ops is None:
+        hit = self._ops.get(key)
+        if hit is not None and hit[0]() is not buf:
+            hit = None      # the address was recycled by another tensor: the cached messages point at freed storage
+        if hit is None:
             ops = []
             for owner, row0, n in pieces:
                 part = buf[row0:row0 + n]
@@ -90,14 +90,12 @@ class DistComm:
                     ops.append(dist.P2POp(dist.irecv, part, self._global(owner), self.group))
             if len(self._ops) > 256:
                 self._ops.clear()
-            self._ops[key] = ops
+            hit = self._ops[key] = (weakref.ref(buf), ops)
+        ops = hit[1]
         return _Works(dist.batch_isend_irecv(ops) if ops else [])
 
     def fanout_into(self, buf, src, peers):
         """The contiguous `buf` from group rank `src` to every rank of `peers` (in place, blocking the stream only)."""
-        if not self._p2p(buf):
-            dist.broadcast(buf, src=self._global(src), group=self.group)
-            return
         if self.rank == src:
             ops = [dist.P2POp(dist.isend, buf, self._global(p), self.group) for p in peers if p != src]
         elif self.rank in peers:

@@ -35,17 +35,27 @@ def _safe_storage_from_bytes(blob):
 # Every global a container file can legitimately name.  Files are exchanged between parties (client keys,
 # server results), so an untrusted .pkl is the NORMAL input: anything outside this list is refused instead of
 # being imported and called, which is what pickle.load would do (the reference's load() has that hole, eng.py:2024-2029).
+def _np_core():
+    """numpy's private core package: `numpy._core` from 1.26.1 / 2.x on, `numpy.core` before."""
+    return getattr(np, "_core", None) or np.core
+
+
 _SAFE_GLOBALS = {
     ("torch._utils", "_rebuild_tensor_v2"): lambda: torch._utils._rebuild_tensor_v2,
     ("torch.storage", "_load_from_bytes"): lambda: _safe_storage_from_bytes,
     ("collections", "OrderedDict"): lambda: __import__("collections").OrderedDict,
+    ("builtins", "complex"): lambda: complex,                       # a Python complex inside a container
+    ("__builtin__", "complex"): lambda: complex,                    # .. as pickle protocols <= 2 spell the module
+    ("_codecs", "encode"): lambda: __import__("_codecs").encode,    # ndarray payloads of pickle protocols <= 2
     ("numpy", "dtype"): lambda: np.dtype,
     ("numpy", "ndarray"): lambda: np.ndarray,
-    ("numpy._core.multiarray", "scalar"): lambda: __import__("numpy")._core.multiarray.scalar,
-    ("numpy.core.multiarray", "_reconstruct"): lambda: __import__("numpy")._core.multiarray._reconstruct,
-    ("numpy._core.multiarray", "_reconstruct"): lambda: __import__("numpy")._core.multiarray._reconstruct,
 }
-_SAFE_GLOBALS[("numpy.core.multiarray", "scalar")] = _SAFE_GLOBALS[("numpy._core.multiarray", "scalar")]   # numpy 1.x files
+# numpy's reconstructors under both spellings of the core package (files written by numpy 1.x and 2.x); protocol 5
+# writes ndarrays through numeric._frombuffer
+for _mod in ("numpy._core", "numpy.core"):
+    _SAFE_GLOBALS[(_mod + ".multiarray", "scalar")] = lambda: _np_core().multiarray.scalar
+    _SAFE_GLOBALS[(_mod + ".multiarray", "_reconstruct")] = lambda: _np_core().multiarray._reconstruct
+    _SAFE_GLOBALS[(_mod + ".numeric", "_frombuffer")] = lambda: _np_core().numeric._frombuffer
 for _name in ("LongStorage", "DoubleStorage", "FloatStorage", "IntStorage", "ShortStorage", "CharStorage", "ByteStorage",
               "BoolStorage", "HalfStorage", "ComplexDoubleStorage", "ComplexFloatStorage", "UntypedStorage"):
     if hasattr(torch, _name):

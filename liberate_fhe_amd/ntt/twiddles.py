@@ -14,7 +14,7 @@ import torch
 from .._native import lib, check
 
 _tables = {}   # id(base tensor) -> entry; entries die with their tensor (a freed tensor's address can be reused)
-_views = {}    # id(view) -> (weakref, version, pointer, rows built): the per-launch fast path
+_views = {}    # id(view) -> (weakref, version, pointer, rows built, twin tensor): the per-launch fast path
 
 
 def dp_pointer(table: torch.Tensor, ql, qh, kl, kh, dev: int, stream: int) -> int:
@@ -45,9 +45,14 @@ def dp_pointer(table: torch.Tensor, ql, qh, kl, kh, dev: int, stream: int) -> in
                                 ql.data_ptr() + lo * 8, qh.data_ptr() + lo * 8, kl.data_ptr() + lo * 8,
                                 kh.data_ptr() + lo * 8, dev, stream), "lf_twiddle_dp")
         entry["built"].update(range(r0 + lo, r0 + hi))
+        # The rows were filled by a launch on `stream`; the fast path above hands the address to launches on ANY
+        # stream.  A build happens once per table and level, so it simply completes here (not per launch): afterwards
+        # the rows are visible to every stream of the device.
+        torch.cuda.ExternalStream(stream, device=dev).synchronize() if stream else torch.cuda.synchronize(dev)
     ptr = entry["dp"].data_ptr() + off * 16
     vkey = id(table)
-    _views[vkey] = (weakref.ref(table), table._version, ptr, rows)
+    # the tuple holds the twin itself: the cached address cannot outlive its allocation
+    _views[vkey] = (weakref.ref(table), table._version, ptr, rows, entry["dp"])
     weakref.finalize(table, _views.pop, vkey, None)
     return ptr
 

@@ -70,6 +70,24 @@ def run(name, params, n_dev=1):
     return rec
 
 
+def run_levels(params, n_dev, levels):
+    """cc_mult (+ relinearize) and rotate_single of level-l ciphertexts for deep levels: rows (and whole devices) drop
+    out of the partition as the level grows (rns_partition.py:64-170)."""
+    t0 = time.time()
+    eng = rd.reference_engine(n_dev, **params)
+    rec = {"params": params, "n_devices": n_dev, "q": [int(x) for x in eng.ctx.q], "hash": eng.hash, "ops": {},
+           "seeds": {"ct_a": 11, "ct_b": 12, "evk": 13, "rotk": 14, "rot_delta": 7}, "levels": list(levels)}
+    evk = synth.key_switch_key(eng, 13)
+    rotk = synth.key_switch_key(eng, 14, origin="rotation key:7")
+    for level in levels:
+        a, b = synth.ciphertext(eng, 11, level), synth.ciphertext(eng, 12, level)
+        rec["ops"][f"cc_mult(a,b,evk)@{level}"] = digest(eng.cc_mult(a, b, evk))
+        rec["ops"][f"rotate_single(a,rotk)@{level}"] = digest(eng.rotate_single(a, rotk))
+        rec["ops"][f"rescale(a)@{level}"] = digest(eng.rescale(a))
+        print(f"levels x{n_dev} level {level}: {time.time() - t0:.1f} s", flush=True)
+    return rec
+
+
 def galois_key(eng, seed0):
     """Synthetic galois key: one synthetic rotation key per power-of-two delta."""
     parts = [synth.key_switch_key(eng, seed0 + i, origin=f"rotation key:{d}") for i, d in enumerate(eng.galois_deltas)]
@@ -255,6 +273,16 @@ if __name__ == "__main__":
              "keygen_bronze": run_keygen(CONFIGS["bronze"], 1),
              "encdec_small": run_encdec(CONFIGS["small"], 1024), "encdec_silver": run_encdec(CONFIGS["silver"], 128)}
         json.dump(k, open(kpath, "w"), indent=1)
+    if "gold_x8" in which:      # BASELINE configs[3]: the gold chain over 8 devices (11 / 8 rows with the special limbs)
+        which.remove("gold_x8")
+        out["gold_x8"] = run("gold", CONFIGS["gold"], 8)
+        json.dump(out, open(path, "w"), indent=1)
+    if "gold_levels" in which:  # gold below level 0, on 1 and on 8 devices (devices run out of rows: 7 alive at 10, 4 at 20, 1 at 32)
+        which.remove("gold_levels")
+        out["gold_levels"] = run_levels(CONFIGS["gold"], 1, (10, 20, 32))
+        json.dump(out, open(path, "w"), indent=1)
+        out["gold_levels_x8"] = run_levels(CONFIGS["gold"], 8, (10, 20, 32))
+        json.dump(out, open(path, "w"), indent=1)
     for name in which:
         out[name] = run(name, CONFIGS[name])
         if name == "small":

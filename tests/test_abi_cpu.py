@@ -93,3 +93,43 @@ def test_unpickler_refuses_foreign_globals(tmp_path):
     golden = os.path.join(ROOT, "tests", "golden", "reference_saved_ct.pkl")
     ct = _PortableUnpickler(open(golden, "rb")).load()   # a file the reference wrote still loads
     assert ct.origin == "cipher text"
+
+
+def test_relaxed_transforms_need_table_and_host_primes():
+    """LF_NTT_RELAXED with psi_dp == NULL or q_host == NULL is LF_ERR_ARG — refused from the arguments
+    alone, before any device call (so it can be checked without a GPU) — and the Python Consts refuses the same."""
+    import ctypes
+    import numpy as np
+    import pytest
+    import torch
+    from liberate_fhe_amd._native import lib
+    from liberate_fhe_amd.fhe.backend import Consts
+    dummy = ctypes.c_void_p(64)          # never dereferenced: every call below fails its argument check
+    q = np.array([1099511922689], dtype=np.int64)
+    for psi_dp, q_host in ((None, q.ctypes.data), (dummy, None), (None, None)):
+        assert lib.lf_ntt(dummy, 1, 1, 13, dummy, psi_dp, q_host, None, 1, dummy, dummy, dummy, dummy, dummy, 0, None) == 10001
+        assert lib.lf_intt(dummy, 1, 1, 13, dummy, psi_dp, q_host, dummy, 2, 1, dummy, dummy, dummy, dummy, dummy, 0, None) == 10001
+        arr = (ctypes.c_void_p * 1)(64)
+        assert lib.lf_rescale_ntt(arr, arr, 1, dummy, 1, 13, dummy, 0, dummy, psi_dp, q_host, None, 1, dummy, dummy, dummy,
+                                  dummy, dummy, 0, None) == 10001
+    assert lib.lf_intt(dummy, 1, 1, 13, dummy, dummy, q.ctypes.data, dummy, 1, 1, dummy, dummy, dummy, dummy, dummy, 0, None) == 10001
+    z = torch.zeros(1, dtype=torch.int64)
+    c = Consts.__new__(Consts)
+    c._qptr = 0
+    with pytest.raises(ValueError):
+        c.qptr(relaxed=True)
+
+
+def test_unpickler_accepts_what_the_reference_load_accepts(tmp_path):
+    """Python complex, ndarrays pickled at protocols 2 and 5 inside a container still load."""
+    import io
+    import pickle
+    import numpy as np
+    import torch
+    from liberate_fhe_amd.fhe.data_struct import data_struct
+    from liberate_fhe_amd.fhe.evaluator import _PortableUnpickler
+    payload = data_struct(data=[np.arange(6, dtype=np.int64).reshape(2, 3), 1.5 + 2j, torch.arange(4)], include_special=False,
+                          ntt_state=False, montgomery_state=False, origin="cipher text", level=0, hash="h", version="v")
+    for proto in (2, 4, 5):
+        back = _PortableUnpickler(io.BytesIO(pickle.dumps(payload, protocol=proto))).load()
+        assert (back.data[0] == payload.data[0]).all() and back.data[1] == 1.5 + 2j and torch.equal(back.data[2], payload.data[2])

@@ -221,3 +221,69 @@ def test_sharded_key_switch_exchanges_point_to_point_into_preallocated_buffers(w
     want = eng.rotate_single(synth.ciphertext(eng, 3, 0), synth.key_switch_key(eng, 6, origin="rotation key:1"))
     for r in range(world):
         assert (outs[r][0] == want.data[0][r].numpy()).all() and (outs[r][1] == want.data[1][r].numpy()).all()
+
+
+# ---- BASELINE configs[3] in shape: the gold chain (34 scale primes + base + 4 special = 39 limbs, dnum 10) over 8 ranks ----
+GOLD_SHAPE = dict(logN=13, num_scales=34, num_special_primes=4, is_secured=False)
+
+
+def _chain_ops(eng, synth):
+    """Level 0 (8 ranks alive, rows 11/8/../8 with the special limbs), the rescale 9 -> 10 after which rank 7 holds
+    nothing, level 20 (4 alive) and level 32 -> 33 (rank 0 alone): rns_partition(35, 4, 8)."""
+    evk = synth.key_switch_key(eng, 5)
+    rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
+    out = {}
+    a0, b0 = synth.ciphertext(eng, 40, 0), synth.ciphertext(eng, 41, 0)
+    out["mult0"] = eng.cc_mult(a0, b0, evk)
+    out["rot0"] = eng.rotate_single(a0, rotk)
+    a9, b9 = synth.ciphertext(eng, 42, 9), synth.ciphertext(eng, 43, 9)
+    out["mult9"] = eng.cc_mult(a9, b9, evk)                       # level 9 -> 10: rank 7 drops out
+    out["rot10"] = eng.rotate_single(out["mult9"], rotk)
+    out["rot10b"] = eng.rotate_single(out["rot10"], rotk)         # the digit buffer and its message list again
+    a20 = synth.ciphertext(eng, 44, 20)
+    out["rot20"] = eng.rotate_single(a20, rotk)
+    out["mult20"] = eng.cc_mult(a20, a20, evk)
+    a32 = synth.ciphertext(eng, 45, 32)
+    out["mult32"] = eng.cc_mult(a32, a32, evk)
+    return out
+
+
+def _chain_worker(rank, world, port, outdir):
+    warnings.filterwarnings("ignore")
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    torch.set_num_threads(1)
+    import datetime
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+    from liberate_fhe_amd.fhe import ckks_engine
+    from liberate_fhe_amd.fhe.comm import DistComm
+    from liberate_fhe_amd.utils import synth
+    from tests.oracle_backend import OracleBackend
+    eng = ckks_engine(devices=["cpu"], backend=OracleBackend(), comm=DistComm(local_device="cpu"), **GOLD_SHAPE)
+    for name, ct in _chain_ops(eng, synth).items():
+        for comp, shards in enumerate(ct.data):
+            arr = shards[0].numpy() if shards else np.zeros((0, eng.ctx.N), dtype=np.int64)
+            np.save(os.path.join(outdir, f"{name}.{comp}.{rank}.npy"), arr)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_gold_chain_shape_through_levels_where_ranks_drop_out():
+    warnings.filterwarnings("ignore")
+    from liberate_fhe_amd.fhe import ckks_engine
+    from liberate_fhe_amd.utils import synth
+    from tests.oracle_backend import OracleBackend
+    eng = ckks_engine(devices=["cpu"] * 8, backend=OracleBackend(), **GOLD_SHAPE)
+    assert [len(d) for d in eng.ntt.p.destination_arrays_with_special[0]] == [11, 8, 8, 8, 8, 8, 8, 8]
+    assert (eng.len_devices[0], eng.len_devices[10], eng.len_devices[20], eng.len_devices[33]) == (8, 7, 4, 1)
+    want = _chain_ops(eng, synth)
+    port = 33500 + (os.getpid() % 2000)
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_chain_worker, args=(8, port, outdir), nprocs=8, join=True)
+        for name, ct in want.items():
+            for comp, shards in enumerate(ct.data):
+                for rank in range(8):
+                    got = np.load(os.path.join(outdir, f"{name}.{comp}.{rank}.npy"))
+                    exp = shards[rank].numpy() if rank < len(shards) else np.zeros((0, eng.ctx.N), dtype=np.int64)
+                    assert got.shape == exp.shape and (got == exp).all(), (name, comp, rank)

@@ -1,6 +1,8 @@
-"""Limb-sharded HIP engine with one process per rank, both ranks on the box's single GPU (gloo carries the
-collectives; RCCL refuses two ranks on one device).  Rehearses the device / stream / shard plumbing of the
-real multi-GPU path with the real kernels; results must match the reference's 2-device digests."""
+"""Limb-sharded HIP engine with one process per rank, all ranks on the box's single GPU.  RCCL refuses two ranks on
+one device, so gloo carries the messages: the product's point-to-point batches are built and cached against the DEVICE
+buffers exactly as for RCCL and travel through the host-staging transport of tests/gloo_device_p2p.py.  Rehearses the
+device / stream / shard plumbing of the real multi-GPU path with the real kernels; results must match the reference's
+2-device digests, and one process driving the same number of logical devices."""
 import json
 import os
 import sys
@@ -25,6 +27,8 @@ def _worker(rank, world, port, outdir):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
+    from tests import gloo_device_p2p
+    p2p_log = gloo_device_p2p.install()
     from liberate_fhe_amd.fhe import ckks_engine
     from liberate_fhe_amd.fhe.comm import DistComm
     from liberate_fhe_amd.utils import synth
@@ -34,6 +38,8 @@ def _worker(rank, world, port, outdir):
         for comp, shards in enumerate(ct.data):
             arr = shards[0].cpu().numpy() if shards else np.zeros((0, eng.ctx.N), dtype=np.int64)
             np.save(os.path.join(outdir, f"{name.replace('/', '_')}.{comp}.{rank}.npy"), arr)
+    # every message of the product's batches was a device buffer (the branch an RCCL run takes), none a collective
+    assert p2p_log and all(is_cuda for batch in p2p_log for _, _, _, is_cuda in batch)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -59,6 +65,8 @@ def _gold_worker(rank, world, port, outdir):
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
+    from tests import gloo_device_p2p
+    gloo_device_p2p.install()
     from liberate_fhe_amd.fhe import ckks_engine, presets
     from liberate_fhe_amd.fhe.comm import DistComm
     from liberate_fhe_amd.utils import synth
@@ -93,3 +101,56 @@ def test_two_ranks_gold_fused_exchange_equals_one_process_two_devices():
         for comp, shards in enumerate(ct.data):
             for rank, t in enumerate(shards):
                 assert (got[f"{name}.{comp}.{rank}.npy"] == t.cpu().numpy()).all(), (name, comp, rank)
+
+
+# ---- a level where a rank has run out of rows (the alive ranks must not wait for it) -----------------
+def _deep_ops(eng, synth):
+    """small ring over 3 devices: rows per device 2/2/2 at level 0, 2/2/1 at level 1, 2/2/- from level 2 on
+    (rns_partition(6, 2, 3)): the rescale 1 -> 2 is fed by a rank that then holds nothing, the key switches at level 2
+    and 3 run between ranks 0 and 1 only; two key switches back to back reuse the digit buffer."""
+    evk = synth.key_switch_key(eng, 5)
+    rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
+    a1, b1 = synth.ciphertext(eng, 31, 1), synth.ciphertext(eng, 32, 1)
+    prod = eng.cc_mult(a1, b1, evk)                       # level 1 -> 2
+    rot = eng.rotate_single(prod, rotk)                   # level 2
+    rot2 = eng.rotate_single(rot, rotk)                   # same buffers again
+    deeper = eng.cc_mult(rot2, prod, evk)                 # level 2 -> 3
+    return {"prod": prod, "rot": rot, "rot2": rot2, "deeper": deeper}
+
+
+def _deep_worker(rank, world, port, outdir):
+    warnings.filterwarnings("ignore")
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import datetime
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    torch.cuda.set_device(0)
+    from tests import gloo_device_p2p
+    gloo_device_p2p.install()
+    from liberate_fhe_amd.fhe import ckks_engine
+    from liberate_fhe_amd.fhe.comm import DistComm
+    from liberate_fhe_amd.utils import synth
+    eng = ckks_engine(devices=["cuda:0"], comm=DistComm(local_device="cuda:0"), **PARAMS)
+    for name, ct in _deep_ops(eng, synth).items():
+        for comp, shards in enumerate(ct.data):
+            arr = shards[0].cpu().numpy() if shards else np.zeros((0, eng.ctx.N), dtype=np.int64)
+            np.save(os.path.join(outdir, f"{name}.{comp}.{rank}.npy"), arr)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_ranks_with_a_rank_out_of_rows_equal_one_process_three_devices():
+    from liberate_fhe_amd.fhe import ckks_engine
+    from liberate_fhe_amd.utils import synth
+    port = 31700 + (os.getpid() % 1000)
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_deep_worker, args=(3, port, outdir), nprocs=3, join=True)
+        got = {f: np.load(os.path.join(outdir, f)) for f in os.listdir(outdir)}
+    eng = ckks_engine(devices=["cuda:0"] * 3, **PARAMS)
+    assert eng.len_devices[2] == 2 and eng.len_devices[1] == 3
+    for name, ct in _deep_ops(eng, synth).items():
+        for comp, shards in enumerate(ct.data):
+            for rank in range(3):
+                want = shards[rank].cpu().numpy() if rank < len(shards) else np.zeros((0, eng.ctx.N), dtype=np.int64)
+                assert (got[f"{name}.{comp}.{rank}.npy"] == want).all(), (name, comp, rank)

@@ -57,7 +57,7 @@ def test_checker_engine_reproduces_reference_digests(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["small", "small_x2", "bronze", "silver", "gold", "platinum", "sb30", "sb45"])
+@pytest.mark.parametrize("name", ["small", "small_x2", "bronze", "silver", "gold", "gold_x8", "platinum", "sb30", "sb45"])
 def test_hip_engine_reproduces_reference_digests(name):
     """All four presets (platinum: logN 17, 6 special primes, a five-stage strided pass — the LDS-tiled fallback
     of the column kernels) and the other scale-prime widths: sb30 = 30-bit scale primes (fp64 class), sb45 =
@@ -66,6 +66,70 @@ def test_hip_engine_reproduces_reference_digests(name):
     rec = GOLD[name]
     eng = ckks_engine(devices=["cuda:0"] * rec["n_devices"], **rec["params"])
     check_config(eng, rec)
+
+
+def check_levels(engine, rec):
+    assert [int(x) for x in engine.ctx.q] == rec["q"] and engine.hash == rec["hash"]
+    s = rec["seeds"]
+    evk = synth.key_switch_key(engine, s["evk"])
+    rotk = synth.key_switch_key(engine, s["rotk"], origin=f"rotation key:{s['rot_delta']}")
+    for level in rec["levels"]:
+        a, b = synth.ciphertext(engine, s["ct_a"], level), synth.ciphertext(engine, s["ct_b"], level)
+        assert digest(engine.cc_mult(a, b, evk)) == rec["ops"][f"cc_mult(a,b,evk)@{level}"], level
+        assert digest(engine.rotate_single(a, rotk)) == rec["ops"][f"rotate_single(a,rotk)@{level}"], level
+        assert digest(engine.rescale(a)) == rec["ops"][f"rescale(a)@{level}"], level
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["gold_levels", "gold_levels_x8"])
+def test_hip_engine_gold_below_level_zero(name):
+    """Gold at levels 10 / 20 / 32 against the reference engine, on one device and on 8 logical devices: rows per device
+    shrink with the level and whole devices run out of rows (7 alive at level 10, 4 at 20, 1 at 32 and 33) —
+    rns_partition.py:64-170, ckks_engine.py:746-904 (`len_devices`, parts of an exhausted device)."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    rec = GOLD[name]
+    eng = ckks_engine(devices=["cuda:0"] * rec["n_devices"], **rec["params"])
+    if rec["n_devices"] == 8:
+        assert [eng.len_devices[l] for l in (0, 10, 20, 32)] == [8, 7, 4, 1]
+    check_levels(eng, rec)
+
+
+def natural_rows(eng, ct):
+    """Components of a ciphertext as [rows, N] arrays with the rows in the order of the prime chain."""
+    dest = eng.ntt.p.destination_arrays[ct.level]
+    out = []
+    for comp in ct.data:
+        rows = {}
+        for d, t in enumerate(comp):
+            arr = t.cpu().numpy()
+            for r, prime in enumerate(dest[d]):
+                rows[prime] = arr[r]
+        out.append(np.stack([rows[k] for k in sorted(rows)]))
+    return out
+
+
+@pytest.mark.gpu
+def test_hip_gold_eight_logical_devices_equal_one_device():
+    """BASELINE configs[3]'s partition (rns_partition(35, 4, 8): 11 / 8 / .. / 8 rows with the special limbs, digit
+    exchange between 8 shards) against the undivided engine, row by row in prime order, at level 0 and across the
+    rescale 9 -> 10 that leaves device 7 without rows."""
+    from liberate_fhe_amd.fhe import ckks_engine, presets
+    params = {k: v for k, v in presets.params["gold"].items() if k != "devices"}
+    outs = []
+    for n_dev in (1, 8):
+        eng = ckks_engine(devices=["cuda:0"] * n_dev, **params)
+        evk = synth.key_switch_key(eng, 5)
+        rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
+        a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
+        a9, b9 = synth.ciphertext(eng, 7, 9), synth.ciphertext(eng, 8, 9)
+        res = [eng.cc_mult(a, b, evk), eng.rotate_single(a, rotk), eng.cc_mult(a9, b9, evk)]
+        res.append(eng.rotate_single(res[-1], rotk))
+        outs.append([natural_rows(eng, ct) for ct in res])
+        del eng, evk, rotk
+        torch.cuda.empty_cache()
+    for one, eight in zip(*outs):
+        for x, y in zip(one, eight):
+            assert x.shape == y.shape and (x == y).all()
 
 
 @pytest.mark.gpu
