@@ -34,7 +34,7 @@ extern "C" {
 
 #define LF_ERR_ARG 10001
 
-/* Library probe: returns the ABI version (currently 7; __graft_entry__.build() asserts it). */
+/* Library probe: returns the ABI version (currently 8; __graft_entry__.build() asserts it). */
 int lf_abi_version(void);
 
 /* Compile-time capacities of the fused kernels, so that callers can refuse a parameter set BEFORE any launch
@@ -136,6 +136,15 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
             const int64_t *q_host, const int64_t *Ninv, int tail, int flags, const int64_t *_2q,
             const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 
+/* lf_intt of an element-wise PRODUCT, formed as the first pass reads its tiles (no product tensor in HBM):
+ *   dst[p] = intt(a[p] * b[p]),  polynomial p of `a` / `b` at a + p * a_stride / b + p * b_stride (words), dst [batch][rows][N].
+ * cc_mult's third tensor component x1 * y1 (ckks_engine.py:1099-1101, 1129) enters the key switch this way.  Requires
+ * LF_NTT_RELAXED (tail >= 2) and logN >= 13; with LF_NTT_PLAIN the fp64-class limbs hold plain residues and get a plain
+ * product, integer-class limbs Montgomery-form words (below 2q) and the REDC62 product — lf_tensor's d2 (plain = 1). */
+int lf_intt_mul(int64_t *dst, const int64_t *a, int64_t a_stride, const int64_t *b, int64_t b_stride, int batch, int rows, int logN,
+                const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *q_host, const int64_t *Ninv, int tail, int flags,
+                const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+
 /* Galois automorphism of coefficient-domain rows (reference: encdec.py:224-270 `rotate`/`conjugate`,
  * done there with torch advanced indexing): dst[i][(p*n mod 2N) mod N] = +/- a[i][n], sign - iff
  * (p*n mod 2N) >= N.  If _2q != NULL the reference's follow-up make_unsigned + reduce_2q
@@ -232,6 +241,25 @@ int lf_ks_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_
                const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
                const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
                void *stream);
+
+/* Relinearisation inside cc_mult (ckks_engine.py:1095-1101, 1117-1151) without inverse transforms of d0 and d1:
+ * dividing by P is linear and P * d vanishes modulo every special prime, so moddown(s) + d == moddown(s + P * d on the
+ * ordinary rows).  lf_relin_core_batch / lf_relin_tail are lf_ks_core_batch / lf_ks_tail whose sums additionally receive,
+ * in the NTT domain, on the first `ell` (ordinary) of the `rows` limbs,
+ *     s[0] += P * (x0 * y0),    s[1] += P * (x0 * y1 + x1 * y0),
+ * from x = [nct][4][ell][N] (x0, x1, y0, y1 as lf_rescale_ntt with LF_NTT_RELAXED | LF_NTT_PLAIN leaves them; stacks of
+ * consecutive ciphertext pairs x_ct_stride words apart) and PR[r] = P * R mod q_r.  lf_ks_moddown_* of the result, with no
+ * addend, is the relinearised ciphertext: the same canonical words as the reference's chain. */
+int lf_relin_core_batch(const int64_t *state, int64_t state_stride, int nct, int nparts, int rows, int logN, const int64_t *desc,
+                        const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
+                        int64_t row_off, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
+                        const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *x, int64_t x_ct_stride,
+                        const int64_t *PR, int ell, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+                        const int64_t *kh, int device, void *stream);
+int lf_relin_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
+                  const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
+                  const int64_t *x, const int64_t *PR, int ell, const int64_t *q_host, const int64_t *ql, const int64_t *qh,
+                  const int64_t *kl, const int64_t *kh, int device, void *stream);
 
 /* Batched forms: `count` (<= 8) independent operand sets in ONE launch — the two components of a ciphertext, the
  * four polynomials cc_mult rescales.  The arrays of pointers are HOST arrays of device pointers; constants are

@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) galois_kernel(GaloisBatch gb, int logN, i
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int lf_abi_version(void) { return 7; }
+int lf_abi_version(void) { return 8; }
 
 // capacities compiled into the kernels (ckks_common.h)
 int lf_limits(int which) {

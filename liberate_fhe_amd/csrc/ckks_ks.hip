@@ -351,10 +351,24 @@ __device__ __forceinline__ longlong2 ld_nt(const i64 *p) {
 // reference's REDC(xR * kR) yields, one fp64 modular multiplication each.  Integer rows: REDC as the reference.
 // grid = (N / 1024, rows); the digits' products are accumulated in registers, the key is read exactly once.
 // NCT ciphertexts switched under the same key share every key word: it is read once for all of them.
-template <int NCT>
+// FOLD (relinearisation inside cc_mult, lf_relin_*): the first two components of the tensor product never get an inverse
+// transform of their own.  Dividing by P is linear and P * d vanishes modulo every special prime, so
+//     moddown(s) + d  ==  moddown(s + P * d  on the ordinary rows)
+// and the addends enter HERE, in the NTT domain, from the four transformed operand polynomials:
+//     s0 += P (x0 y0),   s1 += P (x0 y1 + x1 y0)          (ckks_engine.py:1095-1101, 1135-1140)
+// in the representation of the accumulators (Montgomery-form residues): fp64 rows hold plain residues, so the factor is
+// the number PR = P * R mod q as a double; integer rows hold Montgomery-form words and take REDC(d * PR).
+struct RelinFold {
+    const i64 *x;       // [nct][4][ell][N] = x0, x1, y0, y1 per ciphertext pair, as lf_rescale_ntt(RELAXED | PLAIN) leaves them
+    i64 ct_stride;      // words between the stacks of consecutive pairs
+    const i64 *PR;      // [ell]  P * R mod q_r
+    int ell;            // ordinary rows: the first `ell` of the `rows` limbs
+};
+
+template <int NCT, bool FOLD>
 __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ ext, const i64 *__restrict__ ksk,
                                                         i64 part_stride, i64 comp_stride, i64 row_off, i64 *__restrict__ s,
-                                                        int nparts, int rows, i64 N, const i64 *__restrict__ ql,
+                                                        int nparts, int rows, i64 N, RelinFold fold, const i64 *__restrict__ ql,
                                                         const i64 *__restrict__ qh, const i64 *__restrict__ kl,
                                                         const i64 *__restrict__ kh) {
     // each thread owns KI_V 16-byte column pairs 4 KiB apart: every block streams KI_V x 4 KiB contiguous runs
@@ -390,6 +404,25 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
                 acc[t][1][1] += dp_mulmod_bal(x1, k1y, d);
             }
         }
+        if (FOLD && r < fold.ell) {
+            const double pr = dp_from_word(fold.PR[r]);
+            const i64 pstride = (i64)fold.ell * N;
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) {
+                const i64 *xs = fold.x + t * fold.ct_stride + (i64)r * N + j0;
+                const longlong2 X0 = *reinterpret_cast<const longlong2 *>(xs), X1 = *reinterpret_cast<const longlong2 *>(xs + pstride);
+                const longlong2 Y0 = *reinterpret_cast<const longlong2 *>(xs + 2 * pstride), Y1 = *reinterpret_cast<const longlong2 *>(xs + 3 * pstride);
+                const double x0[2] = {dp_from_word(X0.x), dp_from_word(X0.y)}, x1[2] = {dp_from_word(X1.x), dp_from_word(X1.y)};
+                const double y0[2] = {dp_from_word(Y0.x), dp_from_word(Y0.y)}, y1[2] = {dp_from_word(Y1.x), dp_from_word(Y1.y)};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {   // balanced terms: |d0| <= q / 2, |d1| <= q
+                    const double d0 = dp_mulmod_bal(x0[e], y0[e], d);
+                    const double d1 = dp_mulmod_bal(x0[e], y1[e], d) + dp_mulmod_bal(x1[e], y0[e], d);
+                    acc[t][0][e] += dp_mulmod_bal(d0, pr, d);
+                    acc[t][1][e] += dp_mulmod_bal(d1, pr, d);
+                }
+            }
+        }
 #pragma unroll
         for (int t = 0; t < NCT; ++t)
 #pragma unroll
@@ -413,6 +446,25 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
                 acc[t][0][1] = csub(acc[t][0][1] + mm62u((u64)x.y, (u64)k0.y, m.q, m.k), m.q2);
                 acc[t][1][0] = csub(acc[t][1][0] + mm62u((u64)x.x, (u64)k1.x, m.q, m.k), m.q2);
                 acc[t][1][1] = csub(acc[t][1][1] + mm62u((u64)x.y, (u64)k1.y, m.q, m.k), m.q2);
+            }
+        }
+        if (FOLD && r < fold.ell) {
+            const u64 pr = (u64)fold.PR[r];
+            const i64 pstride = (i64)fold.ell * N;
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) {
+                const i64 *xs = fold.x + t * fold.ct_stride + (i64)r * N + j0;
+                const longlong2 X0 = *reinterpret_cast<const longlong2 *>(xs), X1 = *reinterpret_cast<const longlong2 *>(xs + pstride);
+                const longlong2 Y0 = *reinterpret_cast<const longlong2 *>(xs + 2 * pstride), Y1 = *reinterpret_cast<const longlong2 *>(xs + 3 * pstride);
+                const u64 x0[2] = {(u64)X0.x, (u64)X0.y}, x1[2] = {(u64)X1.x, (u64)X1.y};
+                const u64 y0[2] = {(u64)Y0.x, (u64)Y0.y}, y1[2] = {(u64)Y1.x, (u64)Y1.y};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const i64 d0 = mm62u(x0[e], y0[e], m.q, m.k);
+                    const i64 d1 = csub(mm62u(x0[e], y1[e], m.q, m.k) + mm62u(x1[e], y0[e], m.q, m.k), m.q2);
+                    acc[t][0][e] = csub(acc[t][0][e] + mm62u((u64)d0, pr, m.q, m.k), m.q2);
+                    acc[t][1][e] = csub(acc[t][1][e] + mm62u((u64)d1, pr, m.q, m.k), m.q2);
+                }
             }
         }
 #pragma unroll
@@ -489,7 +541,7 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
 int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
             int64_t row_off, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp,
             const int64_t *Ninv, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
-            const int64_t *kh, hipStream_t st) {
+            const int64_t *kh, hipStream_t st, const RelinFold *fold = nullptr) {
     if (!ipsi_dp) return LF_ERR_ARG;
     const int tl = NTT_TILE_LOG_MAX, S1 = logN - tl;
     RowList dp, in;
@@ -499,11 +551,17 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
     {
         const i64 N = (i64)1 << logN;
         dim3 grid((unsigned)((N + 512 * KI_COLS - 1) / (512 * KI_COLS)), (unsigned)rows);
+        const RelinFold nofold{nullptr, 0, nullptr, 0};
 #define LF_INNER_CASE(NCT)                                                                                             \
     case NCT:                                                                                                          \
-        hipLaunchKernelGGL((ks_inner2_kernel<NCT>), grid, dim3(256), 0, st, (const i64 *)tmp, (const i64 *)ksk,         \
-                           (i64)part_stride, (i64)comp_stride, (i64)row_off, (i64 *)s, nparts, rows, N, (const i64 *)ql, \
-                           (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);                                         \
+        if (fold)                                                                                                      \
+            hipLaunchKernelGGL((ks_inner2_kernel<NCT, true>), grid, dim3(256), 0, st, (const i64 *)tmp, (const i64 *)ksk, \
+                               (i64)part_stride, (i64)comp_stride, (i64)row_off, (i64 *)s, nparts, rows, N, *fold,     \
+                               (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);                    \
+        else                                                                                                           \
+            hipLaunchKernelGGL((ks_inner2_kernel<NCT, false>), grid, dim3(256), 0, st, (const i64 *)tmp, (const i64 *)ksk, \
+                               (i64)part_stride, (i64)comp_stride, (i64)row_off, (i64 *)s, nparts, rows, N, nofold,    \
+                               (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);                    \
         break;
         switch (nct) {
             LF_INNER_CASE(1) LF_INNER_CASE(2) LF_INNER_CASE(4)
@@ -600,6 +658,39 @@ int lf_ks_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_
     if (int e = lf_set_device(device)) return e;
     return ks_tail(1, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh, kl,
                    kh, (hipStream_t)stream);
+}
+
+/* Relinearisation inside cc_mult (see RelinFold): lf_ks_core_batch / lf_ks_tail whose sums additionally receive
+ * P * (x0 y0) and P * (x0 y1 + x1 y0) on the `ell` ordinary rows, from the stack x = [nct][4][ell][N]. */
+int lf_relin_core_batch(const int64_t *state, int64_t state_stride, int nct, int nparts, int rows, int logN, const int64_t *desc,
+                        const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
+                        int64_t row_off, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
+                        const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *x, int64_t x_ct_stride,
+                        const int64_t *PR, int ell, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+                        const int64_t *kh, int device, void *stream) {
+    if (nparts < 1 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
+        !q_host || !psi_dp || !ipsi_dp || !Ed || (nct != 1 && nct != 2 && nct != 4) || !x || !PR || ell < 0 || ell > rows)
+        return LF_ERR_ARG;
+    if (int e = lf_set_device(device)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    if (int e = ks_forward(state, state_stride, nct, nparts, rows, logN, desc, E, Ed, tmp, psi_br, psi_dp, q_host, ql, qh, kl, kh, st))
+        return e;
+    const RelinFold fold{(const i64 *)x, (i64)x_ct_stride, (const i64 *)PR, ell};
+    return ks_tail(nct, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh,
+                   kl, kh, st, &fold);
+}
+
+int lf_relin_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
+                  const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
+                  const int64_t *x, const int64_t *PR, int ell, const int64_t *q_host, const int64_t *ql, const int64_t *qh,
+                  const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (nparts < 1 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
+        !q_host || !ipsi_dp || !x || !PR || ell < 0 || ell > rows)
+        return LF_ERR_ARG;
+    if (int e = lf_set_device(device)) return e;
+    const RelinFold fold{(const i64 *)x, 0, (const i64 *)PR, ell};
+    return ks_tail(1, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh, kl,
+                   kh, (hipStream_t)stream, &fold);
 }
 
 int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,

@@ -245,15 +245,17 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
 
 extern "C" {
 
-int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, const double *ipsi_dp,
-            const int64_t *q_host, const int64_t *Ninv, int tail, int flags, const int64_t *_2q, const int64_t *ql,
-            const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
-    (void)_2q;
+// inverse transform of a [batch][rows][N] stack in place on `a`; ms (relaxed, logN >= 13 only): the transform of the
+// element-wise product of two stacks, read from `src` / ms->b by the first pass and written to `a`
+static int intt_impl(int64_t *a, const int64_t *src, const MulSrc *ms, int batch, int rows, int logN, const int64_t *ipsi_br,
+                     const double *ipsi_dp, const int64_t *q_host, const int64_t *Ninv, int tail, int flags, const int64_t *ql,
+                     const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
     if (batch < 0 || rows < 0 || rows > MAX_LIST_ROWS || logN < 1 || logN > 2 * NTT_TILE_LOG_MAX || tail < 0 || tail > 3)
         return LF_ERR_ARG;
     const int relaxed = flags & LF_NTT_RELAXED;
     if (relaxed && tail < 2) return LF_ERR_ARG;   // relaxed results are canonical residues only
     if (relaxed && (!ipsi_dp || !q_host)) return LF_ERR_ARG;   // see ntt_forward
+    if (ms && (!relaxed || logN <= NTT_TILE_LOG_MAX || !ms->b || !src)) return LF_ERR_ARG;
     if (batch == 0 || rows == 0) return 0;
     if (int e = lf_set_device(device)) return e;
     const int tl = logN < NTT_TILE_LOG_MAX ? logN : NTT_TILE_LOG_MAX;
@@ -287,8 +289,8 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
             continue;
         }
         if (pass == 0 && SB > 0 && tl == NTT_TILE_LOG_MAX) {
-            launch_pass16(true, relaxed, nb, st, (const i64 *)base, base, g, in, dp, (const i64 *)ipsi_br, ipsi_dp,
-                          (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+            launch_pass16(true, relaxed, nb, st, ms ? (const i64 *)src : (const i64 *)base, base, g, in, dp, (const i64 *)ipsi_br,
+                          ipsi_dp, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh, ms);
             continue;
         }
         if (mixed) {
@@ -308,6 +310,21 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
                                (const i64 *)kl, (const i64 *)kh);
     }
     return (int)hipGetLastError();
+}
+
+int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, const double *ipsi_dp,
+            const int64_t *q_host, const int64_t *Ninv, int tail, int flags, const int64_t *_2q, const int64_t *ql,
+            const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    (void)_2q;
+    return intt_impl(a, nullptr, nullptr, batch, rows, logN, ipsi_br, ipsi_dp, q_host, Ninv, tail, flags, ql, qh, kl, kh, device, stream);
+}
+
+int lf_intt_mul(int64_t *dst, const int64_t *a, int64_t a_stride, const int64_t *b, int64_t b_stride, int batch, int rows, int logN,
+                const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *q_host, const int64_t *Ninv, int tail, int flags,
+                const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (!a || !b || !dst) return LF_ERR_ARG;
+    const MulSrc ms{(const i64 *)b, (i64)a_stride, (i64)b_stride};
+    return intt_impl(dst, a, &ms, batch, rows, logN, ipsi_br, ipsi_dp, q_host, Ninv, tail, flags, ql, qh, kl, kh, device, stream);
 }
 
 }  // extern "C"

@@ -367,8 +367,13 @@ __device__ __forceinline__ bool inv_tile16_steps(typename A::T *smt, const i64 *
     return true;
 }
 
-template <bool DP, bool RLX>
-__device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst_row, int tile, const PassGeom &g, const Ctx &c) {
+// MUL (relaxed only): the tile is the element-wise product src_row * mul_row, formed as the words come in — cc_mult's
+// x1 * y1 never exists in HBM.  fp64 class: plain canonical residues in, canonical product (held as doubles from here
+// on); integer class: Montgomery-form words below 2q in, the lazy REDC62 product.
+template <bool DP, bool RLX, bool MUL = false>
+__device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst_row, int tile, const PassGeom &g, const Ctx &c,
+                                           const i64 *mul_row = nullptr) {
+    static_assert(!MUL || RLX, "product-on-load exists for the relaxed inverse transform only");
     const int w = lf_tid();
     const int base = tile << 12, logN = g.logN, s = g.s0;
     constexpr bool CHECK = !RLX;   // relaxed inverse transforms take lazy words in [0, 2q) (include/ckks_hip.h)
@@ -377,6 +382,21 @@ __device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst
         longlong2 in[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) in[i] = *reinterpret_cast<const longlong2 *>(src_row + base + L0 + (i << 7));
+        if (MUL) {
+            longlong2 mb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) mb[i] = *reinterpret_cast<const longlong2 *>(mul_row + base + L0 + (i << 7));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (DP) {
+                    in[i].x = __double_as_longlong(dp_mulmod(dp_from_word(in[i].x), dp_from_word(mb[i].x), c.d));
+                    in[i].y = __double_as_longlong(dp_mulmod(dp_from_word(in[i].y), dp_from_word(mb[i].y), c.d));
+                } else {
+                    in[i].x = mm62u((u64)in[i].x, (u64)mb[i].x, c.m.q, c.m.k);
+                    in[i].y = mm62u((u64)in[i].y, (u64)mb[i].y, c.m.q, c.m.k);
+                }
+            }
+        }
         int odd = 0;
         i64 *sp = sm + PAD16(L0);
 #pragma unroll
@@ -402,7 +422,7 @@ __device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst
         typedef typename DpArith<RLX>::type AD;
         double x[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) x[e] = dp_from_word(raw[e]);
+        for (int e = 0; e < 16; ++e) x[e] = MUL ? __longlong_as_double(raw[e]) : dp_from_word(raw[e]);
         ok = inv_tile16_steps<AD, true, RLX>(reinterpret_cast<double *>(sm), sm, x, w, base, logN, s, cc, CHECK);
         if (ok) {   // exact: the lazy word in [0, 2q); relaxed: balanced residue -> canonical
 #pragma unroll
@@ -426,11 +446,18 @@ __device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst
 }
 
 // ---- kernels: both arithmetic classes in one launch (integer-class blocks first), see ntt_fwd_pass_mixed -----------
-template <bool DP, bool RLX, bool INV>
+// second factor of a product-on-load inverse pass (MUL): polynomial `poly` of the pass reads a + poly * a_stride and
+// multiplies by b + poly * b_stride (strides in words; the factors may sit anywhere, e.g. x1 and y1 of cc_mult's stack)
+struct MulSrc {
+    const i64 *b;
+    i64 a_stride, b_stride;
+};
+
+template <bool DP, bool RLX, bool INV, bool MUL = false>
 __device__ __forceinline__ void pass16_body(i64 *sm, int b, const i64 *src, i64 *dst, const PassGeom &g, const RowList &rl,
                                             const i64 *__restrict__ tw_br, const double *__restrict__ tw_dp,
                                             const i64 *__restrict__ ql, const i64 *__restrict__ qh,
-                                            const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+                                            const i64 *__restrict__ kl, const i64 *__restrict__ kh, const MulSrc *ms = nullptr) {
     int poly, crow, tile;
     block_coords(g, rl, b, poly, crow, tile);
     // (integer divisions run on the VALU: pin the wave-uniform coordinates back into SGPRs)
@@ -444,8 +471,15 @@ __device__ __forceinline__ void pass16_body(i64 *sm, int b, const i64 *src, i64 
     c.relaxed = RLX ? 1 : 0;
     c.inv_reduce = 0;
     const i64 off = (i64)(poly * g.rows + crow) << g.logN;
-    if (INV) inv_tile16<DP, RLX>(sm, src + off, dst + off, tile, g, c);
-    else fwd_tile16<DP, RLX>(sm, dst + off, tile, g, c);
+    if constexpr (INV && MUL) {
+        const i64 roff = (i64)crow << g.logN;
+        inv_tile16<DP, RLX, true>(sm, src + (i64)poly * ms->a_stride + roff, dst + off, tile, g, c,
+                                  ms->b + (i64)poly * ms->b_stride + roff);
+    } else if constexpr (INV) {
+        inv_tile16<DP, RLX>(sm, src + off, dst + off, tile, g, c);
+    } else {
+        fwd_tile16<DP, RLX>(sm, dst + off, tile, g, c);
+    }
 }
 
 template <bool RLX, bool INV>
@@ -463,6 +497,21 @@ __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_mixed(const i64 *
     }
 }
 
+// relaxed inverse pass of a product (MulSrc), both classes
+__global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_mul_mixed(const i64 *src, i64 *dst, PassGeom g, ClassLists cl, MulSrc ms,
+                                                                           const i64 *__restrict__ tw_br,
+                                                                           const double *__restrict__ tw_dp,
+                                                                           const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                           const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT16_LDS_WORDS + 1];
+    const int b = blockIdx.x;
+    if (b < cl.in_blocks) {
+        if (b < cl.in_real) pass16_body<false, true, true, true>(sm, b, src, dst, g, cl.in, tw_br, tw_dp, ql, qh, kl, kh, &ms);
+    } else {
+        pass16_body<true, true, true, true>(sm, b - cl.in_blocks, src, dst, g, cl.dp, tw_br, tw_dp, ql, qh, kl, kh, &ms);
+    }
+}
+
 // one arithmetic class per launch (used when a transform has a single class)
 template <bool DP, bool RLX, bool INV>
 __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16(const i64 *src, i64 *dst, PassGeom g, RowList rl,
@@ -474,11 +523,22 @@ __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16(const i64 *src, i
 }
 
 template <bool DP>
+__global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_mul(const i64 *src, i64 *dst, PassGeom g, RowList rl, MulSrc ms,
+                                                                    const i64 *__restrict__ tw_br, const double *__restrict__ tw_dp,
+                                                                    const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                    const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT16_LDS_WORDS + 1];
+    pass16_body<DP, true, true, true>(sm, blockIdx.x, src, dst, g, rl, tw_br, tw_dp, ql, qh, kl, kh, &ms);
+}
+
+template <bool DP>
 inline void launch_pass16_class(bool inverse, int relaxed, unsigned blocks, hipStream_t st, const i64 *src, i64 *dst,
                                 const PassGeom &g, const RowList &rl, const i64 *tw_br, const double *tw_dp, const i64 *ql,
-                                const i64 *qh, const i64 *kl, const i64 *kh) {
+                                const i64 *qh, const i64 *kl, const i64 *kh, const MulSrc *ms) {
     const dim3 grid(blocks), block(NTT16_THREADS);
-    if (inverse) {
+    if (ms) {
+        hipLaunchKernelGGL((ntt_pass16_mul<DP>), grid, block, 0, st, src, dst, g, rl, *ms, tw_br, tw_dp, ql, qh, kl, kh);
+    } else if (inverse) {
         if (relaxed) hipLaunchKernelGGL((ntt_pass16<DP, true, true>), grid, block, 0, st, src, dst, g, rl, tw_br, tw_dp, ql, qh, kl, kh);
         else hipLaunchKernelGGL((ntt_pass16<DP, false, true>), grid, block, 0, st, src, dst, g, rl, tw_br, tw_dp, ql, qh, kl, kh);
     } else {
@@ -487,20 +547,23 @@ inline void launch_pass16_class(bool inverse, int relaxed, unsigned blocks, hipS
     }
 }
 
-// host: the contiguous 12-stage pass of `polys` polynomials (forward: in place on dst; inverse: src -> dst, no tail)
+// host: the contiguous 12-stage pass of `polys` polynomials (forward: in place on dst; inverse: src -> dst, no tail).
+// ms (relaxed inverse only): the pass transforms the product of two stacks, see MulSrc.
 inline void launch_pass16(bool inverse, int relaxed, int polys, hipStream_t st, const i64 *src, i64 *dst, const PassGeom &g,
                           const RowList &in, const RowList &dp, const i64 *tw_br, const double *tw_dp, const i64 *ql,
-                          const i64 *qh, const i64 *kl, const i64 *kh) {
+                          const i64 *qh, const i64 *kl, const i64 *kh, const MulSrc *ms = nullptr) {
     const unsigned per_row = (unsigned)polys << (g.logN - 12);
     const bool split = !(in.n && dp.n);   // a single class: its own instantiation (no register cost of the other)
     if (split) {   // integer class first: its few, long blocks should not be the tail
-        if (in.n) launch_pass16_class<false>(inverse, relaxed, per_row * (unsigned)in.n, st, src, dst, g, in, tw_br, tw_dp, ql, qh, kl, kh);
-        if (dp.n) launch_pass16_class<true>(inverse, relaxed, per_row * (unsigned)dp.n, st, src, dst, g, dp, tw_br, tw_dp, ql, qh, kl, kh);
+        if (in.n) launch_pass16_class<false>(inverse, relaxed, per_row * (unsigned)in.n, st, src, dst, g, in, tw_br, tw_dp, ql, qh, kl, kh, ms);
+        if (dp.n) launch_pass16_class<true>(inverse, relaxed, per_row * (unsigned)dp.n, st, src, dst, g, dp, tw_br, tw_dp, ql, qh, kl, kh, ms);
         return;
     }
     const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
     const dim3 grid((unsigned)cl.in_blocks + per_row * (unsigned)dp.n), block(NTT16_THREADS);
-    if (inverse) {
+    if (ms) {
+        hipLaunchKernelGGL(ntt_pass16_mul_mixed, grid, block, 0, st, src, dst, g, cl, *ms, tw_br, tw_dp, ql, qh, kl, kh);
+    } else if (inverse) {
         if (relaxed) hipLaunchKernelGGL((ntt_pass16_mixed<true, true>), grid, block, 0, st, src, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
         else hipLaunchKernelGGL((ntt_pass16_mixed<false, true>), grid, block, 0, st, src, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
     } else {

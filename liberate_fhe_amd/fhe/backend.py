@@ -112,6 +112,16 @@ class HipBackend:
         check(lib.lf_intt(_p(buf), batch, rows, logN, _p(ipsi), dp, c.qptr(relaxed and tail >= 2), _p(Ninv), tail,
                           (3 if plain else 1) if relaxed and tail >= 2 else 0, _p(c._2q), *c.mont(), dev, st), "lf_intt")
 
+    def intt_mul(self, dst, a, b, batch, rows, logN, ipsi, Ninv, c: Consts, a_stride=None, b_stride=None, plain=True):
+        """dst[p] = intt(a[p] * b[p]) to canonical coefficients (relaxed, tail 2): the product is formed as the first pass
+        loads its tiles.  a, b: first polynomial of each factor; *_stride = words between a factor's polynomials."""
+        dev, st = _ds(dst)
+        N = dst.size(-1)
+        dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
+        check(lib.lf_intt_mul(_p(dst), _p(a), rows * N if a_stride is None else a_stride, _p(b),
+                              rows * N if b_stride is None else b_stride, batch, rows, logN, _p(ipsi), dp, c.qptr(True), _p(Ninv), 2,
+                              3 if plain else 1, *c.mont(), dev, st), "lf_intt_mul")
+
     def galois(self, a, dst, rows, logN, p, _2q):
         dev, st = _ds(a)
         check(lib.lf_galois(_p(a), _p(dst), rows, logN, p, _p(_2q), dev, st), "lf_galois")
@@ -190,15 +200,23 @@ class HipBackend:
                               *c.mont(), dev, st), "lf_ks_inner")
 
     fused_ks_min_logN = 13   # lf_ks_core needs a two-pass ring degree
+    relin_fold = True        # cc_mult's d0 / d1 folded into the key-switch sums (lf_intt_mul, lf_relin_*)
 
     def ks_core(self, state, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv,
-                c: Consts):
-        """extend + NTT + key inner product + inverse NTT in three fused launches per arithmetic class."""
+                c: Consts, fold=None):
+        """extend + NTT + key inner product + inverse NTT in three fused launches per arithmetic class.
+        fold = (x stack [4, ell, N], PR [ell]): cc_mult's d0 / d1 enter the sums in the NTT domain (lf_relin_core_batch)."""
         dev, st = _ds(s)
         part_stride, comp_stride = key.stride(0), key.stride(1)
         base = key.data_ptr() + first_part * part_stride * 8
         psi_dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
         ipsi_dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
+        if fold is not None:
+            x, PR = fold
+            check(lib.lf_relin_core_batch(_p(state), 0, 1, nparts, rows, logN, _p(desc), _p(E), _pd(Ed), base, part_stride,
+                                          comp_stride, row_off, _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
+                                          _p(x), 0, _p(PR), x.size(1), c.qptr(), *c.mont(), dev, st), "lf_relin_core_batch")
+            return
         check(lib.lf_ks_core(_p(state), nparts, rows, logN, _p(desc), _p(E), _pd(Ed), base, part_stride, comp_stride,
                              row_off, _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
                              c.qptr(), *c.mont(), dev, st), "lf_ks_core")
@@ -211,26 +229,38 @@ class HipBackend:
         check(lib.lf_ks_fwd(_p(state), count, rows, logN, _p(desc) + first * 3 * 8, _p(E), _pd(Ed),
                             _p(tmp) + first * rows * N * 8, _p(psi), psi_dp, c.qptr(), *c.mont(), dev, st), "lf_ks_fwd")
 
-    def ks_tail(self, nparts, rows, logN, key, first_part, row_off, tmp, s, ipsi, Ninv, c: Consts):
-        """Inner product of all extended digits with the key + inverse NTT (lf_ks_tail)."""
+    def ks_tail(self, nparts, rows, logN, key, first_part, row_off, tmp, s, ipsi, Ninv, c: Consts, fold=None):
+        """Inner product of all extended digits with the key + inverse NTT (lf_ks_tail; fold: lf_relin_tail, see ks_core)."""
         dev, st = _ds(s)
         part_stride, comp_stride = key.stride(0), key.stride(1)
         base = key.data_ptr() + first_part * part_stride * 8
         ipsi_dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
+        if fold is not None:
+            x, PR = fold
+            check(lib.lf_relin_tail(nparts, rows, logN, base, part_stride, comp_stride, row_off, _p(tmp), _p(s), _p(ipsi), ipsi_dp,
+                                    _p(Ninv), _p(x), _p(PR), x.size(1), c.qptr(), *c.mont(), dev, st), "lf_relin_tail")
+            return
         check(lib.lf_ks_tail(nparts, rows, logN, base, part_stride, comp_stride, row_off, _p(tmp), _p(s), _p(ipsi), ipsi_dp,
                              _p(Ninv), c.qptr(), *c.mont(), dev, st), "lf_ks_tail")
 
     ks_batch_sizes = (4, 2)   # ciphertexts per lf_ks_core_batch call (largest first)
 
     def ks_core_batch(self, states, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv,
-                      c: Consts):
+                      c: Consts, fold=None):
         """ks_core for len(states) in (2, 4) ciphertexts under one key: states = [nct, state_rows, N] tensor,
-        tmp [nct, nparts, rows, N], s [nct, 2, rows, N]."""
+        tmp [nct, nparts, rows, N], s [nct, 2, rows, N].  fold = (x [nct, 4, ell, N], PR [ell]), see ks_core."""
         dev, st = _ds(s)
         part_stride, comp_stride = key.stride(0), key.stride(1)
         base = key.data_ptr() + first_part * part_stride * 8
         psi_dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
         ipsi_dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
+        if fold is not None:
+            x, PR = fold
+            check(lib.lf_relin_core_batch(_p(states), states.stride(0), states.size(0), nparts, rows, logN, _p(desc), _p(E),
+                                          _pd(Ed), base, part_stride, comp_stride, row_off, _p(tmp), _p(s), _p(psi), psi_dp,
+                                          _p(ipsi), ipsi_dp, _p(Ninv), _p(x), x.stride(0), _p(PR), x.size(2), c.qptr(),
+                                          *c.mont(), dev, st), "lf_relin_core_batch")
+            return
         check(lib.lf_ks_core_batch(_p(states), states.stride(0), states.size(0), nparts, rows, logN, _p(desc), _p(E),
                                    _pd(Ed), base, part_stride, comp_stride, row_off, _p(tmp), _p(s), _p(psi), psi_dp,
                                    _p(ipsi), ipsi_dp, _p(Ninv), c.qptr(), *c.mont(), dev, st), "lf_ks_core_batch")

@@ -727,6 +727,7 @@ class ckks_engine(EvaluatorOps):
         # triplet never leaves this method: only residues matter, so the 40-bit limbs take the relaxed
         # plain-domain transforms (one fp64 product per tensor term)
         per_dev, round_at = self._rescale_operands([a, b])
+        fold = relin and logN >= self.backend.fused_ks_min_logN and getattr(self.backend, "relin_fold", False)
         for d in loc:
             rows = self._rows(d, level, False)
             c = self._consts(d, level, False)
@@ -735,11 +736,32 @@ class ckks_engine(EvaluatorOps):
             self.backend.rescale_ntt(srcs, r0s, x, rows, logN, self.rescale_scales[a.level][d], round_at,
                                      self._tw(d, level, False), self._vec("Rs", d, level, False), c,
                                      relaxed=relin, plain=relin)
+            if fold:
+                # d2 = x1 * y1 goes straight into its inverse transform (the product is formed as the first pass reads
+                # its tiles); d0 and d1 are never formed: the key switch adds P * d0 and P * d1 to its sums in the NTT
+                # domain (dividing by P is linear and P * d vanishes modulo the special primes), so the triplet costs ONE
+                # inverse transform instead of three, no tensor launch and no addend pass
+                t = self._ws("mult_d2", (rows, N), d)
+                self.backend.intt_mul(t, x[1], x[3], 1, rows, logN, self._tw(d, level, False, True),
+                                      self._vec("Ninv", d, level, False), c)
+                d2.append(t)
+                continue
             out = torch.empty((3, rows, N), dtype=torch.int64, device=self.ntt.devices[d])
             self.backend.tensor(x[0], x[1], x[2], x[3], out[0], out[1], out[2], rows, c, plain=relin)
             d0.append(out[0]); d1.append(out[1]); d2.append(out[2])
+        if fold:
+            c0, c1 = self.create_switcher(d2, evk, level, fold={d: (stacks[d], self._PR(d, level)) for d in loc})
+            return self._new((c0, c1), types.origins["ct"], level=level)
         ct_mult = self._new((d0, d1, d2), types.origins["ctt"], level=level, ntt_state=True, montgomery_state=True)
         return self._relinearize(ct_mult, evk, plain=True) if relin else ct_mult
+
+    def _PR(self, dev, level):
+        """P * R mod q over device `dev`'s ordinary rows at `level` (make_mont_PR, eng.py:252-263)."""
+        key = ("PR", dev, level)
+        t = self._tables.get(key)
+        if t is None:
+            t = self._tables[key] = self.mont_PR[dev][self.ntt.starts[level][dev]:]
+        return t
 
     def relinearize(self, ct_triplet: data_struct, evk: data_struct) -> data_struct:
         if ct_triplet.origin != types.origins["ctt"]:
@@ -898,12 +920,14 @@ class ckks_engine(EvaluatorOps):
         return out
 
     def create_switcher(self, a: list[torch.Tensor], ksk: data_struct, level, exit_ntt=False, addends=None,
-                        galois=None) -> tuple:
+                        galois=None, fold=None) -> tuple:
         """Key-switch the coefficient-domain polynomial `a` (one tensor per local device) under `ksk`.
         Returns (c0, c1) lists of canonical [rows, N] tensors.  `addends` = optional (list, list) added
         to (c0, c1) inside the last kernel (relinearize's d0/d1, switch_key's rotated c0).
         `galois` = (p^-1 mod 2N, canonical): switch a(X^p) and add addends(X^p) instead — the permutation is applied
-        where the digits kernel and the mod-down kernel read their input (coefficient-domain `a` only)."""
+        where the digits kernel and the mod-down kernel read their input (coefficient-domain `a` only).
+        `fold` = {device: (x stack [4, ell, N], PR)}: cc_mult's relinearisation — P * (x0 y0) and P * (x0 y1 + x1 y0) are
+        added to the sums in the NTT domain (fused key switch only), see cc_mult."""
         tabs = self._ks_tables(level)
         loc = self._loc(level)
         N, logN, K = self.ctx.N, self.ctx.logN, self.ntt.num_special_primes
@@ -946,8 +970,9 @@ class ckks_engine(EvaluatorOps):
                     if handle is not None:
                         handle.wait()
                     self.backend.ks_fwd(dig, first, count, rows, logN, desc, E, Ed, ext, tw, cs)
+                fkw = {} if fold is None else {"fold": fold[d]}
                 self.backend.ks_tail(nparts, rows, logN, key, tabs["first_part"], self.ntt.starts[level][d], ext, s, itw,
-                                     ninv, cs)
+                                     ninv, cs, **fkw)
                 ready = []
             for handle, _, _ in ready:
                 if handle is not None:
@@ -955,9 +980,11 @@ class ckks_engine(EvaluatorOps):
             if fused and ready:
                 # 3+4. fused core: extend + NTT + key inner product + inverse NTT, the extended digits never
                 # leave the chip in coefficient form
+                fkw = {} if fold is None else {"fold": fold[d]}
                 self.backend.ks_core(dig, nparts, rows, logN, desc, E, Ed, key, tabs["first_part"],
-                                     self.ntt.starts[level][d], ext, s, tw, itw, ninv, cs)
+                                     self.ntt.starts[level][d], ext, s, tw, itw, ninv, cs, **fkw)
             elif not fused:
+                assert fold is None
                 # 3. extend every digit to this device's rows, forward NTT
                 self.backend.ks_extend(dig, ext, nparts, rows, desc, E, cs)
                 self.backend.ntt(ext, nparts, rows, logN, tw, None, cs, relaxed=True)
@@ -1130,9 +1157,10 @@ class ckks_engine(EvaluatorOps):
                             montgomery_state=ct.montgomery_state, origin=types.origins["ct"], level=level, hash=self.hash)
                 for b, ct in enumerate(cts)]
 
-    def _ks_batch(self, srcs, addends, key, level, gal=None):
+    def _ks_batch(self, srcs, addends, key, level, gal=None, fold=None):
         """Key switch of len(srcs) in (2, 4) coefficient-domain polynomials ([ell, N] tensors on the single local
-        device of `level`) under one key; addends[b] = (add to c0, add to c1) or Nones.  Returns [nct, 2, ell, N]."""
+        device of `level`) under one key; addends[b] = (add to c0, add to c1) or Nones.  Returns [nct, 2, ell, N].
+        fold = (x [nct, 4, ell, N], PR): see create_switcher."""
         tabs = self._ks_tables(level)
         d = self._loc(level)[0]
         N, logN, K = self.ctx.N, self.ctx.logN, self.ntt.num_special_primes
@@ -1151,9 +1179,10 @@ class ckks_engine(EvaluatorOps):
         desc, E, Ed = tabs[("extend", d)]
         packs = self._key_pack(key)
         kpack = packs[self._loc(0, special=True).index(d)]
+        fkw = {} if fold is None else {"fold": fold}
         self.backend.ks_core_batch(states, nparts, rows, logN, desc, E, Ed, kpack, tabs["first_part"],
                                    self.ntt.starts[level][d], ext, s, self._tw(d, level, True),
-                                   self._tw(d, level, True, True), self._vec("Ninv", d, level, True), cs)
+                                   self._tw(d, level, True, True), self._vec("Ninv", d, level, True), cs, **fkw)
         # 3. divide by P (+ addends, in gather form under a Galois map): one launch pair for the 2 * nct polynomials
         out = torch.empty((nct, 2, ell, N), dtype=torch.int64, device=self.ntt.devices[d])
         ss = [s[b][comp] for b in range(nct) for comp in range(2)]
@@ -1209,19 +1238,30 @@ class ckks_engine(EvaluatorOps):
         nct = len(pairs)
         rows = self._rows(d, level, False)
         c = self._consts(d, level, False)
-        trip = torch.empty((nct, 3, rows, N), dtype=torch.int64, device=self.ntt.devices[d])
+        fold = getattr(self.backend, "relin_fold", False)
         # rescale + forward transform of the operands, two pairs (8 polynomials) per launch
-        x = self._ws("mult8", (8, rows, N), d)
+        x = self._ws("multx", (nct, 4, rows, N), d) if fold else self._ws("mult8", (8, rows, N), d)
+        trip = None if fold else torch.empty((nct, 3, rows, N), dtype=torch.int64, device=self.ntt.devices[d])
         for t0 in range(0, nct, 2):
             chunk = pairs[t0:t0 + 2]
             per_dev, round_at = self._rescale_operands([ct for pair in chunk for ct in pair])
             srcs, r0s = per_dev[d]
-            self.backend.rescale_ntt(srcs, r0s, x[:4 * len(chunk)], rows, logN, self.rescale_scales[level - 1][d], round_at,
+            xs = x[t0:t0 + len(chunk)].view(4 * len(chunk), rows, N) if fold else x[:4 * len(chunk)]
+            self.backend.rescale_ntt(srcs, r0s, xs, rows, logN, self.rescale_scales[level - 1][d], round_at,
                                      self._tw(d, level, False), self._vec("Rs", d, level, False), c, relaxed=True, plain=True)
+            if fold:
+                continue
             for k in range(len(chunk)):
                 t = t0 + k
                 self.backend.tensor(x[4 * k], x[4 * k + 1], x[4 * k + 2], x[4 * k + 3], trip[t][0], trip[t][1], trip[t][2],
                                     rows, c, plain=True)
+        if fold:
+            # the nct products x1 * y1 through one inverse transform (product on load); d0 / d1 folded into the key switch
+            d2 = self._ws("multx_d2", (nct, rows, N), d)
+            self.backend.intt_mul(d2, x[0][1], x[0][3], nct, rows, logN, self._tw(d, level, False, True),
+                                  self._vec("Ninv", d, level, False), c, a_stride=4 * rows * N, b_stride=4 * rows * N)
+            out = self._ks_batch([d2[t] for t in range(nct)], [(None, None)] * nct, evk, level, fold=(x, self._PR(d, level)))
+            return [self._new(([out[t][0]], [out[t][1]]), types.origins["ct"], level=level) for t in range(nct)]
         # the 3 * nct inverse transforms of the triplets: one launch
         self.backend.intt(trip.view(3 * nct, rows, N), 3 * nct, rows, logN, self._tw(d, level, False, True),
                           self._vec("Ninv", d, level, False), 2, c, relaxed=True, plain=True)

@@ -178,6 +178,43 @@ class OracleBackend:
             if tail >= 3:
                 orc.make_signed(x, rows, _np(c._2q))
 
+    relin_fold = True
+
+    def intt_mul(self, dst, a, b, batch, rows, logN, ipsi, Ninv, c, a_stride=None, b_stride=None, plain=True):
+        """Checker form of lf_intt_mul: mont_mult then intt_exit_reduce, polynomial by polynomial."""
+        N = dst.size(-1)
+        D = _np(dst).reshape(batch, -1, N)
+        fa, fb = a.reshape(-1), b.reshape(-1)
+        sa, sb = (rows * N if a_stride is None else a_stride), (rows * N if b_stride is None else b_stride)
+        for p in range(batch):
+            A = np.ascontiguousarray(_np(torch.as_strided(fa, (rows, N), (N, 1), fa.storage_offset() + p * sa)))
+            B = np.ascontiguousarray(_np(torch.as_strided(fb, (rows, N), (N, 1), fb.storage_offset() + p * sb)))
+            prod = np.empty_like(A)
+            orc.mont_mult(A, B, prod, rows, *self._m(c))
+            D[p][:rows] = prod
+        self.intt(dst, batch, rows, logN, ipsi, Ninv, 2, c)
+
+    def _fold(self, s, fold, c):
+        """s[0] += P * x0 y0, s[1] += P * (x0 y1 + x1 y0) on the ordinary rows, NTT domain, Montgomery form (RelinFold)."""
+        x, PR = fold
+        ell = x.size(1)
+        cut = lambda v: np.ascontiguousarray(_np(v)[:ell])
+        ql, qh, kl, kh = (cut(v) for v in (c.ql, c.qh, c.kl, c.kh))
+        q2 = cut(c._2q)
+        x0, x1, y0, y1 = (np.ascontiguousarray(_np(x[i])) for i in range(4))
+        d0, t0, t1, d1 = (np.empty_like(x0) for _ in range(4))
+        orc.mont_mult(x0, y0, d0, ell, ql, qh, kl, kh)
+        orc.mont_mult(x0, y1, t0, ell, ql, qh, kl, kh)
+        orc.mont_mult(x1, y0, t1, ell, ql, qh, kl, kh)
+        orc.mont_add(t0, t1, d1, ell, q2)
+        pr = np.ascontiguousarray(_np(PR)[:ell])
+        for comp, dd in ((0, d0), (1, d1)):
+            orc.mont_enter(dd, pr, ell, ql, qh, kl, kh)               # REDC(d R * P R) = d P R
+            cur = np.ascontiguousarray(_np(s[comp])[:ell])
+            nxt = np.empty_like(cur)
+            orc.mont_add(cur, dd, nxt, ell, q2)
+            _np(s[comp])[:ell] = nxt
+
     def galois(self, a, dst, rows, logN, p, _2q):
         # encdec.rotate (+ make_unsigned, reduce_2q when _2q is given: ckks_engine.py:1194-1200)
         orc.galois(_np(a)[:rows], _np(dst)[:rows], rows, p)
@@ -303,11 +340,13 @@ class OracleBackend:
 
     fused_ks_min_logN = 13
 
-    def ks_core(self, state, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv, c):
+    def ks_core(self, state, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv, c, fold=None):
         """The fused core as the sequence it replaces: extend, NTT, inner product + sum, inverse NTT chain."""
         self.ks_extend(state, tmp, nparts, rows, desc, E, c)
         self.ntt(tmp, nparts, rows, logN, psi, None, c)
         self.ks_inner(tmp, key, first_part, row_off, s[0], s[1], nparts, rows, c)
+        if fold is not None:
+            self._fold(s, fold, c)
         self.intt(s, 2, rows, logN, ipsi, Ninv, 2, c)
 
     def ks_fwd(self, state, first, count, rows, logN, desc, E, Ed, tmp, psi, c):
@@ -317,8 +356,10 @@ class OracleBackend:
         self.ks_extend(state, sub, count, rows, D, E, c)
         self.ntt(sub, count, rows, logN, psi, None, c)
 
-    def ks_tail(self, nparts, rows, logN, key, first_part, row_off, tmp, s, ipsi, Ninv, c):
+    def ks_tail(self, nparts, rows, logN, key, first_part, row_off, tmp, s, ipsi, Ninv, c, fold=None):
         self.ks_inner(tmp, key, first_part, row_off, s[0], s[1], nparts, rows, c)
+        if fold is not None:
+            self._fold(s, fold, c)
         self.intt(s, 2, rows, logN, ipsi, Ninv, 2, c)
 
     ks_batch_sizes = (4, 2)
@@ -327,9 +368,11 @@ class OracleBackend:
         for src, st in zip(srcs, states):
             self.ks_digits(src, st, nparts, desc, tab, c, galois=galois)
 
-    def ks_core_batch(self, states, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv, c):
+    def ks_core_batch(self, states, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv, c, fold=None):
         for b in range(states.size(0)):
-            self.ks_core(states[b], nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp[b], s[b], psi, ipsi, Ninv, c)
+            f = None if fold is None else (fold[0][b], fold[1])
+            self.ks_core(states[b], nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp[b], s[b], psi, ipsi, Ninv, c,
+                         fold=f)
 
     # ---- divide by P: ckks_engine.py:850-901 (+ relinearize 1135-1140 / switch_key 952-953) ----
     def ks_moddown(self, s, out, addend, ell, K, PiR, Rs, c, PiP=None):
