@@ -254,12 +254,21 @@ int lf_relin_core_batch(const int64_t *state, int64_t state_stride, int nct, int
                         const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
                         int64_t row_off, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
                         const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *x, int64_t x_ct_stride,
-                        const int64_t *PR, int ell, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
-                        const int64_t *kh, int device, void *stream);
+                        const int64_t *PR, int ell, const uint8_t *own, const int64_t *q_host, const int64_t *ql, const int64_t *qh,
+                        const int64_t *kl, const int64_t *kh, int device, void *stream);
+/* own (optional DEVICE table of `rows` bytes, may be NULL): own[r] = the digit (storage order) whose primes include limb
+ * r, 255 for the special limbs.  The extension of a digit's mixed-radix form to one of its own primes is the residue it
+ * was built from, i.e. the switched polynomial x1 * y1 itself: those (digit, limb) pairs are neither extended nor
+ * transformed, and the inner product forms x1 * y1 from the stack in their place (35 of gold's 390 limb transforms).
+ * lf_relin_fwd = lf_ks_fwd of digits first .. first + nparts - 1 with that table (desc / tmp are NOT offset by the caller). */
+int lf_relin_fwd(const int64_t *state, int first, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,
+                 const double *Ed, int64_t *tmp, const int64_t *psi_br, const double *psi_dp, const uint8_t *own,
+                 const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+                 void *stream);
 int lf_relin_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
                   const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
-                  const int64_t *x, const int64_t *PR, int ell, const int64_t *q_host, const int64_t *ql, const int64_t *qh,
-                  const int64_t *kl, const int64_t *kh, int device, void *stream);
+                  const int64_t *x, const int64_t *PR, int ell, const uint8_t *own, const int64_t *q_host, const int64_t *ql,
+                  const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 
 /* Batched forms: `count` (<= 8) independent operand sets in ONE launch — the two components of a ciphertext, the
  * four polynomials cc_mult rescales.  The arrays of pointers are HOST arrays of device pointers; constants are

@@ -41,6 +41,11 @@ struct KsGeom {
     i64 N;
     int nct;         // ciphertexts switched under the same key in this call (lf_ks_core_batch)
     i64 state_stride;   // words between their digit states
+    // relinearisation inside cc_mult: the limbs a digit is made of are not extended (the inner product takes them from
+    // the NTT-domain operands, RelinFold); own[r] = digit (numbered from the first digit of the key switch, this call
+    // starting at p0) that limb r belongs to, 255 for the special limbs; nullptr: every (digit, limb) pair is extended
+    const unsigned char *own;
+    int p0;
 };
 
 // ---- K2: extend + strided NTT pass -----------------------------------------------------------------
@@ -74,7 +79,8 @@ __device__ __forceinline__ void ks_ext_body(i64 *sm, int b, const i64 *__restric
     }
     const int tile = pt % tiles, p = pt / tiles;
     const int crow = rl.id[ri];
-    const PassGeom g{kg.logN, kg.tl, 1, kg.S1, 0, kg.tl - kg.S1, kg.rows, kg.nparts, 1, 0, 0};
+    if (kg.own != nullptr && (int)kg.own[crow] == kg.p0 + p) return;   // the digit's own limb: nothing to extend
+    const PassGeom g{kg.logN, kg.tl, 1, kg.S1, 0, kg.tl - kg.S1, kg.rows, kg.nparts, 1, 0, 0, nullptr, 0, 0};
 
     Ctx c;
     c.m = load_mod(ql, qh, kl, kh, crow);
@@ -239,6 +245,7 @@ __device__ __forceinline__ void ks_ext_cols_body(int b, const i64 *__restrict__ 
     const int chunk = __builtin_amdgcn_readfirstlane(pc % chunks), p = __builtin_amdgcn_readfirstlane(pc / chunks);
     const int crow = __builtin_amdgcn_readfirstlane((int)rl.id[ri]);
     const int ctu = __builtin_amdgcn_readfirstlane(ct);
+    if (kg.own != nullptr && (int)kg.own[crow] == kg.p0 + p) return;   // the digit's own limb: nothing to extend
 
     Ctx c;
     c.m = load_mod(ql, qh, kl, kh, crow);
@@ -363,6 +370,10 @@ struct RelinFold {
     i64 ct_stride;      // words between the stacks of consecutive pairs
     const i64 *PR;      // [ell]  P * R mod q_r
     int ell;            // ordinary rows: the first `ell` of the `rows` limbs
+    // own[r] = the digit limb r belongs to (nullptr: none skipped): that digit's extension to limb r IS the third tensor
+    // component x1 * y1 in the NTT domain — the extension (mod q_r) of a digit's mixed-radix form to one of its own primes
+    // is the residue it was built from — so it is formed here from the operands instead of being read from `ext`
+    const unsigned char *own;
 };
 
 template <int NCT, bool FOLD>
@@ -387,11 +398,23 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
         double acc[NCT][2][2];
 #pragma unroll
         for (int t = 0; t < NCT; ++t) acc[t][0][0] = acc[t][0][1] = acc[t][1][0] = acc[t][1][1] = 0.0;
+        const int p_own = (FOLD && fold.own != nullptr && r < fold.ell) ? (int)fold.own[r] : -1;
+        longlong2 xo[NCT];   // the own digit's words: x1 * y1, plain canonical
+        if (p_own >= 0) {
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) {
+                const i64 *xs = fold.x + t * fold.ct_stride + (i64)r * N + j0 + (i64)fold.ell * N;
+                const longlong2 X1 = *reinterpret_cast<const longlong2 *>(xs), Y1 = *reinterpret_cast<const longlong2 *>(xs + 2 * (i64)fold.ell * N);
+                xo[t].x = dp_to_word(dp_mulmod(dp_from_word(X1.x), dp_from_word(Y1.x), d));
+                xo[t].y = dp_to_word(dp_mulmod(dp_from_word(X1.y), dp_from_word(Y1.y), d));
+            }
+        }
 #pragma unroll 2
         for (int p = 0; p < nparts; ++p) {
             longlong2 x[NCT];
 #pragma unroll
-            for (int t = 0; t < NCT; ++t) x[t] = *reinterpret_cast<const longlong2 *>(e + t * ct_ext + (i64)p * rows * N);
+            for (int t = 0; t < NCT; ++t)
+                x[t] = p == p_own ? xo[t] : *reinterpret_cast<const longlong2 *>(e + t * ct_ext + (i64)p * rows * N);
             const longlong2 k0 = ld_nt(k + (i64)p * part_stride);
             const longlong2 k1 = ld_nt(k + (i64)p * part_stride + comp_stride);
             const double k0x = dp_from_word(k0.x), k0y = dp_from_word(k0.y), k1x = dp_from_word(k1.x), k1y = dp_from_word(k1.y);
@@ -436,12 +459,23 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
         i64 acc[NCT][2][2];
 #pragma unroll
         for (int t = 0; t < NCT; ++t) acc[t][0][0] = acc[t][0][1] = acc[t][1][0] = acc[t][1][1] = 0;
+        const int p_own = (FOLD && fold.own != nullptr && r < fold.ell) ? (int)fold.own[r] : -1;
+        longlong2 xo[NCT];   // the own digit's words: REDC62(x1 * y1), Montgomery form below 2q
+        if (p_own >= 0) {
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) {
+                const i64 *xs = fold.x + t * fold.ct_stride + (i64)r * N + j0 + (i64)fold.ell * N;
+                const longlong2 X1 = *reinterpret_cast<const longlong2 *>(xs), Y1 = *reinterpret_cast<const longlong2 *>(xs + 2 * (i64)fold.ell * N);
+                xo[t].x = mm62u((u64)X1.x, (u64)Y1.x, m.q, m.k);
+                xo[t].y = mm62u((u64)X1.y, (u64)Y1.y, m.q, m.k);
+            }
+        }
         for (int p = 0; p < nparts; ++p) {
             const longlong2 k0 = ld_nt(k + (i64)p * part_stride);
             const longlong2 k1 = ld_nt(k + (i64)p * part_stride + comp_stride);
 #pragma unroll
             for (int t = 0; t < NCT; ++t) {
-                const longlong2 x = *reinterpret_cast<const longlong2 *>(e + t * ct_ext + (i64)p * rows * N);
+                const longlong2 x = p == p_own ? xo[t] : *reinterpret_cast<const longlong2 *>(e + t * ct_ext + (i64)p * rows * N);
                 acc[t][0][0] = csub(acc[t][0][0] + mm62u((u64)x.x, (u64)k0.x, m.q, m.k), m.q2);
                 acc[t][0][1] = csub(acc[t][0][1] + mm62u((u64)x.y, (u64)k0.y, m.q, m.k), m.q2);
                 acc[t][1][0] = csub(acc[t][1][0] + mm62u((u64)x.x, (u64)k1.x, m.q, m.k), m.q2);
@@ -491,10 +525,10 @@ void classify_rows(int rows, const int64_t *q_host, RowList &dp, RowList &in) {
 int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, int rows, int logN, const int64_t *desc,
                const int64_t *E, const double *Ed, int64_t *tmp, const int64_t *psi_br, const double *psi_dp,
                const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh,
-               hipStream_t st) {
+               hipStream_t st, const unsigned char *own = nullptr, int p0 = 0) {
     if (!psi_dp) return LF_ERR_ARG;   // the relaxed arithmetic of both classes lives in the auxiliary table
     const int tl = NTT_TILE_LOG_MAX, S1 = logN - tl;
-    const KsGeom kg{logN, tl, S1, rows, nparts, (i64)1 << logN, nct, (i64)state_stride};
+    const KsGeom kg{logN, tl, S1, rows, nparts, (i64)1 << logN, nct, (i64)state_stride, own, p0};
     RowList dp, in;
     classify_rows(rows, q_host, dp, in);
     const unsigned tiles = 1u << (logN - tl);
@@ -530,7 +564,7 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
                            (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     // contiguous forward pass, in place on tmp (relaxed)
     {
-        const PassGeom g{logN, tl, 0, tl, S1, 0, rows, (int)polys, 1, 1, 0};
+        const PassGeom g{logN, tl, 0, tl, S1, 0, rows, (int)polys, 1, 1, 0, own, nparts, p0};
         launch_pass16(false, 1, (int)polys, st, (const i64 *)tmp, (i64 *)tmp, g, in, dp, (const i64 *)psi_br, psi_dp,
                       (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     }
@@ -551,7 +585,7 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
     {
         const i64 N = (i64)1 << logN;
         dim3 grid((unsigned)((N + 512 * KI_COLS - 1) / (512 * KI_COLS)), (unsigned)rows);
-        const RelinFold nofold{nullptr, 0, nullptr, 0};
+        const RelinFold nofold{nullptr, 0, nullptr, 0, nullptr};
 #define LF_INNER_CASE(NCT)                                                                                             \
     case NCT:                                                                                                          \
         if (fold)                                                                                                      \
@@ -660,35 +694,50 @@ int lf_ks_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_
                    kh, (hipStream_t)stream);
 }
 
-/* Relinearisation inside cc_mult (see RelinFold): lf_ks_core_batch / lf_ks_tail whose sums additionally receive
- * P * (x0 y0) and P * (x0 y1 + x1 y0) on the `ell` ordinary rows, from the stack x = [nct][4][ell][N]. */
+/* Relinearisation inside cc_mult (see RelinFold): lf_ks_core_batch / lf_ks_fwd / lf_ks_tail whose sums additionally
+ * receive P * (x0 y0) and P * (x0 y1 + x1 y0) on the `ell` ordinary rows, from the stack x = [nct][4][ell][N]; with `own`
+ * the (digit, own limb) pairs are neither extended nor transformed: the inner product forms x1 y1 for them. */
 int lf_relin_core_batch(const int64_t *state, int64_t state_stride, int nct, int nparts, int rows, int logN, const int64_t *desc,
                         const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
                         int64_t row_off, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
                         const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *x, int64_t x_ct_stride,
-                        const int64_t *PR, int ell, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
-                        const int64_t *kh, int device, void *stream) {
-    if (nparts < 1 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
+                        const int64_t *PR, int ell, const uint8_t *own, const int64_t *q_host, const int64_t *ql, const int64_t *qh,
+                        const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (nparts < 1 || nparts > 254 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
         !q_host || !psi_dp || !ipsi_dp || !Ed || (nct != 1 && nct != 2 && nct != 4) || !x || !PR || ell < 0 || ell > rows)
         return LF_ERR_ARG;
     if (int e = lf_set_device(device)) return e;
     hipStream_t st = (hipStream_t)stream;
-    if (int e = ks_forward(state, state_stride, nct, nparts, rows, logN, desc, E, Ed, tmp, psi_br, psi_dp, q_host, ql, qh, kl, kh, st))
+    if (int e = ks_forward(state, state_stride, nct, nparts, rows, logN, desc, E, Ed, tmp, psi_br, psi_dp, q_host, ql, qh, kl, kh, st,
+                           (const unsigned char *)own, 0))
         return e;
-    const RelinFold fold{(const i64 *)x, (i64)x_ct_stride, (const i64 *)PR, ell};
+    const RelinFold fold{(const i64 *)x, (i64)x_ct_stride, (const i64 *)PR, ell, (const unsigned char *)own};
     return ks_tail(nct, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh,
                    kl, kh, st, &fold);
 }
 
+int lf_relin_fwd(const int64_t *state, int first, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,
+                 const double *Ed, int64_t *tmp, const int64_t *psi_br, const double *psi_dp, const uint8_t *own,
+                 const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+                 void *stream) {
+    if (first < 0 || nparts < 0 || first + nparts > 254 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX ||
+        logN > 2 * NTT_TILE_LOG_MAX || !q_host || !psi_dp || !Ed)
+        return LF_ERR_ARG;
+    if (nparts == 0) return 0;
+    if (int e = lf_set_device(device)) return e;
+    return ks_forward(state, 0, 1, nparts, rows, logN, desc + 3 * (int64_t)first, E, Ed, tmp + (((int64_t)first * rows) << logN), psi_br,
+                      psi_dp, q_host, ql, qh, kl, kh, (hipStream_t)stream, (const unsigned char *)own, first);
+}
+
 int lf_relin_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
                   const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
-                  const int64_t *x, const int64_t *PR, int ell, const int64_t *q_host, const int64_t *ql, const int64_t *qh,
-                  const int64_t *kl, const int64_t *kh, int device, void *stream) {
-    if (nparts < 1 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
+                  const int64_t *x, const int64_t *PR, int ell, const uint8_t *own, const int64_t *q_host, const int64_t *ql,
+                  const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (nparts < 1 || nparts > 254 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
         !q_host || !ipsi_dp || !x || !PR || ell < 0 || ell > rows)
         return LF_ERR_ARG;
     if (int e = lf_set_device(device)) return e;
-    const RelinFold fold{(const i64 *)x, 0, (const i64 *)PR, ell};
+    const RelinFold fold{(const i64 *)x, 0, (const i64 *)PR, ell, (const unsigned char *)own};
     return ks_tail(1, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh, kl,
                    kh, (hipStream_t)stream, &fold);
 }

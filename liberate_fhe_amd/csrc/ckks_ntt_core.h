@@ -68,6 +68,10 @@ struct PassGeom {
     int last;      // 1: last pass of the transform
     int plain;     // relaxed only: fp64-class limbs work in the PLAIN domain — no Montgomery entry on the way in
                    // (Rs applies to integer-class limbs only), inverse tail multiplies by N^-1 instead of N^-1 R^-1
+    // key switch inside cc_mult (lf_relin_*): polynomial `poly` of the stack is digit skip_off + poly % skip_mod; the limbs
+    // a digit is made of need no extension and no transform (the caller has them in the NTT domain already): their blocks exit
+    const unsigned char *skip_own;   // device, [rows]: digit that owns the limb (255: none); nullptr: nothing is skipped
+    int skip_mod, skip_off;
 };
 
 // tile-local index -> coefficient index of the row

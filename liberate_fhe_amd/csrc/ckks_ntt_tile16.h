@@ -463,6 +463,7 @@ __device__ __forceinline__ void pass16_body(i64 *sm, int b, const i64 *src, i64 
     // (integer divisions run on the VALU: pin the wave-uniform coordinates back into SGPRs)
     poly = __builtin_amdgcn_readfirstlane(poly), crow = __builtin_amdgcn_readfirstlane(crow);
     tile = __builtin_amdgcn_readfirstlane(tile);
+    if (!INV && RLX && g.skip_own != nullptr && (int)g.skip_own[crow] == g.skip_off + poly % g.skip_mod) return;   // see PassGeom
     Ctx c;
     c.m = load_mod(ql, qh, kl, kh, crow);
     c.tw_mont = tw_br + ((i64)crow << g.logN);

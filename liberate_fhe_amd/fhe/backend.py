@@ -37,6 +37,15 @@ def _p(t):
     return t.data_ptr()
 
 
+def _pb(t):
+    """Device pointer of a uint8 table (None -> NULL)."""
+    if t is None:
+        return 0
+    if t.dtype != torch.uint8 or not t.is_contiguous():
+        raise TypeError("HipBackend: contiguous uint8 tensor required")
+    return t.data_ptr()
+
+
 def _pd(t):
     """Device pointer of a float64 table (None -> NULL)."""
     if t is None:
@@ -205,27 +214,34 @@ class HipBackend:
     def ks_core(self, state, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv,
                 c: Consts, fold=None):
         """extend + NTT + key inner product + inverse NTT in three fused launches per arithmetic class.
-        fold = (x stack [4, ell, N], PR [ell]): cc_mult's d0 / d1 enter the sums in the NTT domain (lf_relin_core_batch)."""
+        fold = (x stack [4, ell, N], PR [ell], own [rows] uint8 or None): cc_mult's d0 / d1 enter the sums in the NTT domain and
+        the digits' own limbs come from x1 * y1 instead of an extension (lf_relin_core_batch)."""
         dev, st = _ds(s)
         part_stride, comp_stride = key.stride(0), key.stride(1)
         base = key.data_ptr() + first_part * part_stride * 8
         psi_dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
         ipsi_dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
         if fold is not None:
-            x, PR = fold
+            x, PR, own = fold
             check(lib.lf_relin_core_batch(_p(state), 0, 1, nparts, rows, logN, _p(desc), _p(E), _pd(Ed), base, part_stride,
                                           comp_stride, row_off, _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
-                                          _p(x), 0, _p(PR), x.size(1), c.qptr(), *c.mont(), dev, st), "lf_relin_core_batch")
+                                          _p(x), 0, _p(PR), x.size(1), _pb(own), c.qptr(), *c.mont(), dev, st),
+                  "lf_relin_core_batch")
             return
         check(lib.lf_ks_core(_p(state), nparts, rows, logN, _p(desc), _p(E), _pd(Ed), base, part_stride, comp_stride,
                              row_off, _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
                              c.qptr(), *c.mont(), dev, st), "lf_ks_core")
 
-    def ks_fwd(self, state, first, count, rows, logN, desc, E, Ed, tmp, psi, c: Consts):
-        """Extension + forward NTT of digits first .. first + count - 1 into tmp[first:first + count] (lf_ks_fwd)."""
+    def ks_fwd(self, state, first, count, rows, logN, desc, E, Ed, tmp, psi, c: Consts, own=None):
+        """Extension + forward NTT of digits first .. first + count - 1 into tmp[first:first + count] (lf_ks_fwd; with
+        `own`, lf_relin_fwd: the digits' own limbs are left out, see ks_core's fold)."""
         dev, st = _ds(tmp)
         psi_dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
         N = tmp.size(-1)
+        if own is not None:
+            check(lib.lf_relin_fwd(_p(state), first, count, rows, logN, _p(desc), _p(E), _pd(Ed), _p(tmp), _p(psi), psi_dp,
+                                   _pb(own), c.qptr(), *c.mont(), dev, st), "lf_relin_fwd")
+            return
         check(lib.lf_ks_fwd(_p(state), count, rows, logN, _p(desc) + first * 3 * 8, _p(E), _pd(Ed),
                             _p(tmp) + first * rows * N * 8, _p(psi), psi_dp, c.qptr(), *c.mont(), dev, st), "lf_ks_fwd")
 
@@ -236,9 +252,9 @@ class HipBackend:
         base = key.data_ptr() + first_part * part_stride * 8
         ipsi_dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
         if fold is not None:
-            x, PR = fold
+            x, PR, own = fold
             check(lib.lf_relin_tail(nparts, rows, logN, base, part_stride, comp_stride, row_off, _p(tmp), _p(s), _p(ipsi), ipsi_dp,
-                                    _p(Ninv), _p(x), _p(PR), x.size(1), c.qptr(), *c.mont(), dev, st), "lf_relin_tail")
+                                    _p(Ninv), _p(x), _p(PR), x.size(1), _pb(own), c.qptr(), *c.mont(), dev, st), "lf_relin_tail")
             return
         check(lib.lf_ks_tail(nparts, rows, logN, base, part_stride, comp_stride, row_off, _p(tmp), _p(s), _p(ipsi), ipsi_dp,
                              _p(Ninv), c.qptr(), *c.mont(), dev, st), "lf_ks_tail")
@@ -255,10 +271,10 @@ class HipBackend:
         psi_dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
         ipsi_dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
         if fold is not None:
-            x, PR = fold
+            x, PR, own = fold
             check(lib.lf_relin_core_batch(_p(states), states.stride(0), states.size(0), nparts, rows, logN, _p(desc), _p(E),
                                           _pd(Ed), base, part_stride, comp_stride, row_off, _p(tmp), _p(s), _p(psi), psi_dp,
-                                          _p(ipsi), ipsi_dp, _p(Ninv), _p(x), x.stride(0), _p(PR), x.size(2), c.qptr(),
+                                          _p(ipsi), ipsi_dp, _p(Ninv), _p(x), x.stride(0), _p(PR), x.size(2), _pb(own), c.qptr(),
                                           *c.mont(), dev, st), "lf_relin_core_batch")
             return
         check(lib.lf_ks_core_batch(_p(states), states.stride(0), states.size(0), nparts, rows, logN, _p(desc), _p(E),

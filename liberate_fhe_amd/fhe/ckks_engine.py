@@ -750,7 +750,8 @@ class ckks_engine(EvaluatorOps):
             self.backend.tensor(x[0], x[1], x[2], x[3], out[0], out[1], out[2], rows, c, plain=relin)
             d0.append(out[0]); d1.append(out[1]); d2.append(out[2])
         if fold:
-            c0, c1 = self.create_switcher(d2, evk, level, fold={d: (stacks[d], self._PR(d, level)) for d in loc})
+            tabs = self._ks_tables(level)
+            c0, c1 = self.create_switcher(d2, evk, level, fold={d: (stacks[d], self._PR(d, level), tabs[("own", d)]) for d in loc})
             return self._new((c0, c1), types.origins["ct"], level=level)
         ct_mult = self._new((d0, d1, d2), types.origins["ctt"], level=level, ntt_state=True, montgomery_state=True)
         return self._relinearize(ct_mult, evk, plain=True) if relin else ct_mult
@@ -859,6 +860,13 @@ class ckks_engine(EvaluatorOps):
             tabs[("pir", d)] = pir
             # plain P_j^-1 mod q_row as doubles (fp64 class of the mod-down kernel)
             specials = ctx.q[-K:][::-1]
+            # (5) the digit each local limb belongs to (255: special limbs) — cc_mult's key switch leaves those pairs out
+            own = [255] * nrows
+            for s_, (_, _, primes) in enumerate(order):
+                for i, r in enumerate(dest):
+                    if r in primes:
+                        own[i] = s_
+            tabs[("own", d)] = torch.tensor(own, dtype=torch.uint8, device=self.ntt.devices[d])
             tabs[("pip", d)] = torch.tensor(
                 [[float(pow(specials[P_ind], -1, ctx.q[r])) if i < nrows - P_ind - 1 else 0.0 for i, r in enumerate(dest)]
                  for P_ind in range(K)], dtype=torch.float64, device=self.ntt.devices[d])
@@ -926,7 +934,7 @@ class ckks_engine(EvaluatorOps):
         to (c0, c1) inside the last kernel (relinearize's d0/d1, switch_key's rotated c0).
         `galois` = (p^-1 mod 2N, canonical): switch a(X^p) and add addends(X^p) instead — the permutation is applied
         where the digits kernel and the mod-down kernel read their input (coefficient-domain `a` only).
-        `fold` = {device: (x stack [4, ell, N], PR)}: cc_mult's relinearisation — P * (x0 y0) and P * (x0 y1 + x1 y0) are
+        `fold` = {device: (x stack [4, ell, N], PR, own table)}: cc_mult's relinearisation — P * (x0 y0) and P * (x0 y1 + x1 y0) are
         added to the sums in the NTT domain (fused key switch only), see cc_mult."""
         tabs = self._ks_tables(level)
         loc = self._loc(level)
@@ -969,7 +977,8 @@ class ckks_engine(EvaluatorOps):
                 for handle, first, count in ready:
                     if handle is not None:
                         handle.wait()
-                    self.backend.ks_fwd(dig, first, count, rows, logN, desc, E, Ed, ext, tw, cs)
+                    okw = {} if fold is None else {"own": fold[d][2]}
+                    self.backend.ks_fwd(dig, first, count, rows, logN, desc, E, Ed, ext, tw, cs, **okw)
                 fkw = {} if fold is None else {"fold": fold[d]}
                 self.backend.ks_tail(nparts, rows, logN, key, tabs["first_part"], self.ntt.starts[level][d], ext, s, itw,
                                      ninv, cs, **fkw)
@@ -1160,7 +1169,7 @@ class ckks_engine(EvaluatorOps):
     def _ks_batch(self, srcs, addends, key, level, gal=None, fold=None):
         """Key switch of len(srcs) in (2, 4) coefficient-domain polynomials ([ell, N] tensors on the single local
         device of `level`) under one key; addends[b] = (add to c0, add to c1) or Nones.  Returns [nct, 2, ell, N].
-        fold = (x [nct, 4, ell, N], PR): see create_switcher."""
+        fold = (x [nct, 4, ell, N], PR, own): see create_switcher."""
         tabs = self._ks_tables(level)
         d = self._loc(level)[0]
         N, logN, K = self.ctx.N, self.ctx.logN, self.ntt.num_special_primes
@@ -1260,7 +1269,8 @@ class ckks_engine(EvaluatorOps):
             d2 = self._ws("multx_d2", (nct, rows, N), d)
             self.backend.intt_mul(d2, x[0][1], x[0][3], nct, rows, logN, self._tw(d, level, False, True),
                                   self._vec("Ninv", d, level, False), c, a_stride=4 * rows * N, b_stride=4 * rows * N)
-            out = self._ks_batch([d2[t] for t in range(nct)], [(None, None)] * nct, evk, level, fold=(x, self._PR(d, level)))
+            out = self._ks_batch([d2[t] for t in range(nct)], [(None, None)] * nct, evk, level,
+                                 fold=(x, self._PR(d, level), self._ks_tables(level)[("own", d)]))
             return [self._new(([out[t][0]], [out[t][1]]), types.origins["ct"], level=level) for t in range(nct)]
         # the 3 * nct inverse transforms of the triplets: one launch
         self.backend.intt(trip.view(3 * nct, rows, N), 3 * nct, rows, logN, self._tw(d, level, False, True),

@@ -196,7 +196,7 @@ class OracleBackend:
 
     def _fold(self, s, fold, c):
         """s[0] += P * x0 y0, s[1] += P * (x0 y1 + x1 y0) on the ordinary rows, NTT domain, Montgomery form (RelinFold)."""
-        x, PR = fold
+        x, PR = fold[0], fold[1]
         ell = x.size(1)
         cut = lambda v: np.ascontiguousarray(_np(v)[:ell])
         ql, qh, kl, kh = (cut(v) for v in (c.ql, c.qh, c.kl, c.kh))
@@ -349,7 +349,7 @@ class OracleBackend:
             self._fold(s, fold, c)
         self.intt(s, 2, rows, logN, ipsi, Ninv, 2, c)
 
-    def ks_fwd(self, state, first, count, rows, logN, desc, E, Ed, tmp, psi, c):
+    def ks_fwd(self, state, first, count, rows, logN, desc, E, Ed, tmp, psi, c, own=None):
         """Digits first .. first + count - 1 only: extend + NTT into tmp[first:first + count]."""
         D = desc.reshape(-1, 3)[first:first + count].contiguous()
         sub = tmp[first:first + count]
@@ -370,7 +370,7 @@ class OracleBackend:
 
     def ks_core_batch(self, states, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv, c, fold=None):
         for b in range(states.size(0)):
-            f = None if fold is None else (fold[0][b], fold[1])
+            f = None if fold is None else (fold[0][b], fold[1], fold[2])
             self.ks_core(states[b], nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp[b], s[b], psi, ipsi, Ninv, c,
                          fold=f)
 
