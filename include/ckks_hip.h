@@ -312,6 +312,48 @@ int lf_rescale_ntt(const int64_t *const *in, const int64_t *const *row0, int cou
                    const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Whole engine ops behind one entry each (csrc/ckks_ops.hip).  The reference's Python engine issues ~250 extension calls
+ * per cc_mult + relinearize (ckks_engine.py:1072-1151 over 654-961); a binding that wants the host side of an op to be ONE
+ * native call fills an lf_ks_plan once per (device, level) — everything that does not change from call to call — and
+ * hands the operands and the key per call.  The entries enqueue exactly the steps above (lf_rescale_ntt, lf_intt_mul,
+ * lf_ks_digits(_galois), lf_relin_core_batch / lf_ks_core, lf_ks_moddown_ws) on `stream` and return the first failure.
+ * They apply when every limb of the level lives on this device (no exchange between the digits and their extension).
+ * `rows` = ell + K limbs, ordinary first: the per-row vectors and twiddle tables are those of lf_ks_core.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct lf_ks_plan {
+    int32_t logN, ell, K, nparts;        /* ring degree, ordinary limbs at the op's level, special primes, digits */
+    int32_t dig_nparts, device;          /* digits lf_ks_digits builds here (= nparts on one device) */
+    int64_t round_at;                    /* cc_mult: rescale rounding threshold q_l / 2 (lf_rescale) */
+    int64_t md_ws_words;
+    const int64_t *ql, *qh, *kl, *kh, *_2q, *Rs, *Ninv;      /* device, [rows] */
+    const int64_t *q_host;                                    /* HOST, [rows] */
+    const int64_t *psi, *ipsi;                                /* compact twiddle tables of the rows */
+    const double *psi_dp, *ipsi_dp;                           /* their auxiliary tables (lf_twiddle_dp) */
+    const int64_t *dig_desc, *dig_tab;                        /* lf_ks_digits */
+    const int64_t *ext_desc, *E;                              /* lf_ks_core */
+    const double *Ed;
+    const int64_t *PiR;                                       /* lf_ks_moddown */
+    const double *PiP;
+    const uint8_t *own;                                       /* lf_relin_*: may be NULL */
+    const int64_t *rescale_scales, *PR;                       /* cc_mult only: [ell] q_l^-1 R and P R mod q_r */
+    int64_t *state, *ext, *sum, *md_ws;                       /* scratch: [ell][N], [nparts][rows][N], [2][rows][N], md_ws_words */
+    int64_t *x4, *d2;                                         /* cc_mult only: [4][ell][N], [ell][N] */
+} lf_ks_plan;
+
+/* ckks_engine.cc_mult(a, b, evk) with relinearisation, level l -> l + 1 (ckks_engine.py:1072-1151): in[0..3] = first
+ * SURVIVING row of a.c0, a.c1, b.c0, b.c1 (HOST array of device pointers, as lf_rescale_batch), row0[0..3] their dropped
+ * rows; the plan describes level l + 1; key addressed as in lf_ks_inner; out0 / out1 [ell][N] canonical. */
+int lf_cc_mult_evk(const lf_ks_plan *plan, const int64_t *const *in, const int64_t *const *row0, const int64_t *ksk,
+                   int64_t part_stride, int64_t comp_stride, int64_t row_off, int64_t *out0, int64_t *out1, void *stream);
+
+/* ckks_engine.switch_key / rotate_single / conjugate of a coefficient-domain ciphertext (c0, c1), [ell][N] each
+ * (ckks_engine.py:939-961, 1180-1206, 1718-1734): out = (c0(X^p) + ks_0, ks_1) with ks = key switch of c1(X^p);
+ * gal_pinv = p^-1 mod 2N (0: no automorphism), gal_canonical != 0: rotate_single's make_unsigned + reduce_2q. */
+int lf_switch_key(const lf_ks_plan *plan, const int64_t *c0, const int64_t *c1, int64_t gal_pinv, int gal_canonical,
+                  const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off, int64_t *out0, int64_t *out1,
+                  void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Samplers: the reference's csprng extensions, src/liberate/csprng/.
  * A ChaCha20 state is 16 int64 words holding 32-bit values (csprng.py:124-160); words 12/13 are
  * the 64-bit block counter, advanced by `step` after every draw.  All tables below are DEVICE

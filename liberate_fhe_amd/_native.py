@@ -72,6 +72,20 @@ _SIGNATURES = {
     "lf_ks_core": [_P, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
 }
 
+
+
+class KsPlan(ctypes.Structure):
+    """lf_ks_plan (include/ckks_hip.h), field for field."""
+    _fields_ = ([(n, ctypes.c_int32) for n in ("logN", "ell", "K", "nparts", "dig_nparts", "device")]
+                + [("round_at", _L), ("md_ws_words", _L)]
+                + [(n, _P) for n in ("ql", "qh", "kl", "kh", "_2q", "Rs", "Ninv", "q_host", "psi", "ipsi", "psi_dp", "ipsi_dp",
+                                     "dig_desc", "dig_tab", "ext_desc", "E", "Ed", "PiR", "PiP", "own", "rescale_scales", "PR",
+                                     "state", "ext", "sum", "md_ws", "x4", "d2")])
+
+
+_SIGNATURES["lf_cc_mult_evk"] = [ctypes.POINTER(KsPlan), _P, _P, _P, _L, _L, _L, _P, _P, _P]
+_SIGNATURES["lf_switch_key"] = [ctypes.POINTER(KsPlan), _P, _P, _L, _I, _P, _L, _L, _L, _P, _P, _P]
+
 for _name, _args in _SIGNATURES.items():
     _fn = getattr(lib, _name)
     _fn.argtypes = _args

@@ -555,6 +555,9 @@ inline void launch_pass16(bool inverse, int relaxed, int polys, hipStream_t st, 
                           const i64 *qh, const i64 *kl, const i64 *kh, const MulSrc *ms = nullptr) {
     const unsigned per_row = (unsigned)polys << (g.logN - 12);
     const bool split = !(in.n && dp.n);   // a single class: its own instantiation (no register cost of the other)
+    // (launches that do not fill the chip — silver's 128 .. 1 216 tile blocks — were also tried on the 512-thread /
+    // 8-words-per-thread pass, two waves per SIMD from one block per CU: silver cc_mult 163-165 us against 165-169,
+    // inside the run-to-run spread; dropped)
     if (split) {   // integer class first: its few, long blocks should not be the tail
         if (in.n) launch_pass16_class<false>(inverse, relaxed, per_row * (unsigned)in.n, st, src, dst, g, in, tw_br, tw_dp, ql, qh, kl, kh, ms);
         if (dp.n) launch_pass16_class<true>(inverse, relaxed, per_row * (unsigned)dp.n, st, src, dst, g, dp, tw_br, tw_dp, ql, qh, kl, kh, ms);

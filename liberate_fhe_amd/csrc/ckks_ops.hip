@@ -1,0 +1,69 @@
+// ckks_ops.hip — whole engine ops behind ONE C entry each: lf_cc_mult_evk, lf_switch_key.
+//
+// The reference issues a cc_mult + relinearize as ~250 Python-level calls into its extension (ckks_engine.py:1072-1151,
+// 746-961); this library's engine brought that down to a dozen fused launches, but each still cost a Python -> ctypes
+// round trip with twenty-odd marshalled arguments (117 us of host time per silver cc_mult, more than the device time of
+// a rank of the limb-sharded path).  Here the launches of an op are enqueued by one native call: everything that does
+// not change between calls — constants, twiddle tables, key-switch descriptors, scratch — sits in an `lf_ks_plan` the
+// caller fills once per (device, level).  The entries only compose the library's own exported steps (same kernels, same
+// results); they apply when every limb of the level lives on this device (no exchange step in the middle).
+#include "../../include/ckks_hip.h"
+#include "ckks_common.h"
+
+extern "C" {
+
+static int plan_ok(const lf_ks_plan *p) {
+    return p && p->logN > NTT_TILE_LOG_MAX && p->logN <= 2 * NTT_TILE_LOG_MAX && p->ell >= 1 && p->K >= 1 && p->K <= KS_MAX_K &&
+           p->nparts >= 1 && p->dig_nparts >= 1 && p->ql && p->qh && p->kl && p->kh && p->_2q && p->Rs && p->Ninv && p->q_host &&
+           p->psi && p->ipsi && p->psi_dp && p->ipsi_dp && p->dig_desc && p->dig_tab && p->ext_desc && p->E && p->Ed && p->PiR &&
+           p->state && p->ext && p->sum && p->md_ws;
+}
+
+int lf_cc_mult_evk(const lf_ks_plan *p, const int64_t *const *in, const int64_t *const *row0, const int64_t *ksk,
+                   int64_t part_stride, int64_t comp_stride, int64_t row_off, int64_t *out0, int64_t *out1, void *stream) {
+    if (!plan_ok(p) || !p->rescale_scales || !p->PR || !p->x4 || !p->d2 || !in || !row0 || !ksk || !out0 || !out1) return LF_ERR_ARG;
+    const int ell = p->ell, rows = p->ell + p->K, logN = p->logN, dev = p->device;
+    const int64_t N = (int64_t)1 << logN, poly = (int64_t)ell * N;
+    const int relaxed_plain = LF_NTT_RELAXED | LF_NTT_PLAIN;
+    // x0, x1, y0, y1: both rescales inside the first pass of one batched forward transform (ckks_engine.py:1085-1093)
+    if (int e = lf_rescale_ntt(in, row0, 4, p->x4, ell, logN, p->rescale_scales, p->round_at, p->psi, p->psi_dp, p->q_host, p->Rs,
+                               relaxed_plain, p->_2q, p->ql, p->qh, p->kl, p->kh, dev, stream))
+        return e;
+    // d2 = x1 * y1 straight into its inverse transform (1099-1101, 1129)
+    if (int e = lf_intt_mul(p->d2, p->x4 + poly, poly, p->x4 + 3 * poly, poly, 1, ell, logN, p->ipsi, p->ipsi_dp, p->q_host, p->Ninv, 2,
+                            relaxed_plain, p->ql, p->qh, p->kl, p->kh, dev, stream))
+        return e;
+    // key switch of d2 with d0, d1 folded into its sums (654-961, 1117-1151)
+    if (int e = lf_ks_digits(p->d2, p->state, p->dig_nparts, p->dig_desc, p->dig_tab, N, p->ql, p->qh, p->kl, p->kh, dev, stream))
+        return e;
+    if (int e = lf_relin_core_batch(p->state, 0, 1, p->nparts, rows, logN, p->ext_desc, p->E, p->Ed, ksk, part_stride, comp_stride,
+                                    row_off, p->ext, p->sum, p->psi, p->psi_dp, p->ipsi, p->ipsi_dp, p->Ninv, p->x4, 0, p->PR, ell,
+                                    p->own, p->q_host, p->ql, p->qh, p->kl, p->kh, dev, stream))
+        return e;
+    const int64_t *ss[2] = {p->sum, p->sum + (int64_t)rows * N};
+    int64_t *outs[2] = {out0, out1};
+    return lf_ks_moddown_ws(ss, outs, nullptr, 2, ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, 0, nullptr, p->ql,
+                            p->qh, p->kl, p->kh, dev, stream);
+}
+
+int lf_switch_key(const lf_ks_plan *p, const int64_t *c0, const int64_t *c1, int64_t gal_pinv, int gal_canonical,
+                  const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off, int64_t *out0, int64_t *out1,
+                  void *stream) {
+    if (!plan_ok(p) || !c1 || !ksk || !out0 || !out1) return LF_ERR_ARG;
+    const int ell = p->ell, rows = p->ell + p->K, logN = p->logN, dev = p->device;
+    const int64_t N = (int64_t)1 << logN;
+    const int64_t *g2q = (gal_pinv && gal_canonical) ? p->_2q : nullptr;
+    if (int e = lf_ks_digits_galois(c1, p->state, p->dig_nparts, p->dig_desc, p->dig_tab, N, gal_pinv, g2q, p->ql, p->qh, p->kl, p->kh,
+                                    dev, stream))
+        return e;
+    if (int e = lf_ks_core(p->state, p->nparts, rows, logN, p->ext_desc, p->E, p->Ed, ksk, part_stride, comp_stride, row_off, p->ext,
+                           p->sum, p->psi, p->psi_dp, p->ipsi, p->ipsi_dp, p->Ninv, p->q_host, p->ql, p->qh, p->kl, p->kh, dev, stream))
+        return e;
+    const int64_t *ss[2] = {p->sum, p->sum + (int64_t)rows * N};
+    int64_t *outs[2] = {out0, out1};
+    const int64_t *adds[2] = {c0, nullptr};
+    return lf_ks_moddown_ws(ss, outs, adds, 2, ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, gal_pinv, g2q, p->ql,
+                            p->qh, p->kl, p->kh, dev, stream);
+}
+
+}  // extern "C"

@@ -11,7 +11,7 @@ import ctypes
 
 import torch
 
-from .._native import lib, check
+from .._native import lib, check, KsPlan
 from ..ntt import ntt_cuda, twiddles
 
 
@@ -258,6 +258,52 @@ class HipBackend:
             return
         check(lib.lf_ks_tail(nparts, rows, logN, base, part_stride, comp_stride, row_off, _p(tmp), _p(s), _p(ipsi), ipsi_dp,
                              _p(Ninv), c.qptr(), *c.mont(), dev, st), "lf_ks_tail")
+
+    # ---- whole ops behind one native call (lf_cc_mult_evk / lf_switch_key over an lf_ks_plan) ------------------------
+    native_ops = True
+
+    def make_plan(self, ints, tensors, q_host, psi, ipsi, c: Consts):
+        """lf_ks_plan from the engine's per-level pieces.  ints: {field: int}; tensors: {field: tensor or None} (int64 /
+        float64 / uint8 device tensors); q_host: numpy int64; psi / ipsi: the twiddle views (their auxiliary tables are
+        built here, on the current stream).  Returns (plan, keep-alive list)."""
+        plan = KsPlan()
+        for k, v in ints.items():
+            setattr(plan, k, int(v))
+        keep = [q_host, psi, ipsi, c]
+        for k, t in tensors.items():
+            if t is None:
+                setattr(plan, k, None)
+                continue
+            if not t.is_contiguous():
+                raise ValueError(f"plan tensor {k} must be contiguous")
+            setattr(plan, k, t.data_ptr())
+            keep.append(t)
+        dev, st = _ds(psi)
+        plan.device = dev
+        plan.ql, plan.qh, plan.kl, plan.kh = c.mont()
+        plan._2q = _p(c._2q)
+        plan.q_host = q_host.ctypes.data
+        plan.psi, plan.ipsi = _p(psi), _p(ipsi)
+        plan.psi_dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
+        plan.ipsi_dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
+        return plan, keep
+
+    def cc_mult_evk(self, plan, ins, row0s, key, first_part, row_off, out):
+        """ins / row0s: ctypes arrays of 4 device pointers; out [2, ell, N]."""
+        dev, st = _ds(out)
+        part_stride, comp_stride = key.stride(0), key.stride(1)
+        base = key.data_ptr() + first_part * part_stride * 8
+        plane = out.stride(0) * 8
+        check(lib.lf_cc_mult_evk(ctypes.byref(plan), ins, row0s, base, part_stride, comp_stride, row_off, out.data_ptr(),
+                                 out.data_ptr() + plane, st), "lf_cc_mult_evk")
+
+    def switch_key_native(self, plan, c0, c1, pinv, canonical, key, first_part, row_off, out):
+        dev, st = _ds(out)
+        part_stride, comp_stride = key.stride(0), key.stride(1)
+        base = key.data_ptr() + first_part * part_stride * 8
+        plane = out.stride(0) * 8
+        check(lib.lf_switch_key(ctypes.byref(plan), _p(c0), _p(c1), pinv, 1 if canonical else 0, base, part_stride, comp_stride,
+                                row_off, out.data_ptr(), out.data_ptr() + plane, st), "lf_switch_key")
 
     ks_batch_sizes = (4, 2)   # ciphertexts per lf_ks_core_batch call (largest first)
 

@@ -20,6 +20,7 @@ Data lists (`data_struct.data[i]`) hold one tensor per LOCAL participating devic
 """
 from __future__ import annotations
 
+import ctypes
 import math
 import os
 import weakref
@@ -708,6 +709,69 @@ class ckks_engine(EvaluatorOps):
         return self._new(([outs[0][d] for d in loc], [outs[1][d] for d in loc]), types.origins["ct"], level=nxt)
 
     # =============================================================================================
+    # whole ops behind one native call (include/ckks_hip.h: lf_ks_plan, lf_cc_mult_evk, lf_switch_key)
+    # =============================================================================================
+    def _native_level(self, level):
+        """The device index if every limb of `level` lives on ONE device of this process and the backend has the one-call
+        entries; None otherwise (several devices / ranks: the exchange steps sit between the launches)."""
+        if not getattr(self.backend, "native_ops", False) or self.ctx.logN < self.backend.fused_ks_min_logN:
+            return None
+        if self.len_devices[level] != 1:
+            return None
+        loc = self._loc(level)
+        return loc[0] if len(loc) == 1 else None
+
+    def _op_plan(self, level, d):
+        """lf_ks_plan of (level, device): constants, tables and scratch of a key switch AT `level` and of a cc_mult INTO it,
+        resolved once (per pipeline lane: the scratch tensors are per lane)."""
+        key = ("plan", level, d, self._lane)
+        hit = self._tables.get(key)
+        if hit is not None:
+            return hit
+        N, K = self.ctx.N, self.ntt.num_special_primes
+        rows, ell = self._rows(d, level, True), self._rows(d, level, False)
+        tabs = self._ks_tables(level)
+        cs = self._consts(d, level, True)
+        nparts = len(tabs["order"])
+        dig_nparts, dig_desc, dig_tab = tabs[("digits", d)]
+        desc, E, Ed = tabs[("extend", d)]
+        words = self.backend.moddown_ws_words(2, ell, K, N)
+        ints = {"logN": self.ctx.logN, "ell": ell, "K": K, "nparts": nparts, "dig_nparts": dig_nparts, "md_ws_words": words,
+                "round_at": 0}
+        tensors = {"Rs": self._vec("Rs", d, level, True), "Ninv": self._vec("Ninv", d, level, True), "dig_desc": dig_desc,
+                   "dig_tab": dig_tab, "ext_desc": desc, "E": E, "Ed": Ed, "PiR": tabs[("pir", d)], "PiP": tabs[("pip", d)],
+                   "own": tabs[("own", d)], "rescale_scales": None, "PR": self._PR(d, level),
+                   "state": self._ws("ks_state", (ell, N), d), "ext": self._ws("ks_ext", (nparts, rows, N), d),
+                   "sum": self._ws("ks_sum", (2, rows, N), d), "md_ws": self._ws("ks_moddown", (words,), d),
+                   "x4": self._ws("mult4", (4, ell, N), d), "d2": self._ws("mult_d2", (ell, N), d)}
+        if level >= 1:
+            owner = self.ntt.p.rescaler_loc[level - 1]
+            ints["round_at"] = self.ctx.q[self.ntt.p.destination_arrays[level - 1][owner][0]] // 2
+            tensors["rescale_scales"] = self.rescale_scales[level - 1][d]
+        plan, keep = self.backend.make_plan(ints, tensors, cs.q_host, self._tw(d, level, True), self._tw(d, level, True, True), cs)
+        hit = self._tables[key] = (plan, keep, tabs["first_part"], self.ntt.starts[level][d])
+        return hit
+
+    def _cc_mult_native(self, a, b, evk, level, d):
+        """cc_mult + relinearize as ONE native call (lf_cc_mult_evk); None if an operand is not laid out for it."""
+        N = self.ctx.N
+        ins, row0s = (ctypes.c_void_p * 4)(), (ctypes.c_void_p * 4)()
+        k = 0
+        for ct in (a, b):
+            for comp in range(2):
+                t = ct.data[comp][0]
+                if not t.is_contiguous() or t.dtype != torch.int64:
+                    return None
+                ptr = t.data_ptr()
+                row0s[k], ins[k] = ptr, ptr + N * 8      # the dropped limb is the first row; the survivors follow it
+                k += 1
+        plan, _, first_part, row_off = self._op_plan(level, d)
+        kpack = self._key_pack(evk)[self._loc(0, special=True).index(d)]
+        out = torch.empty((2, plan.ell, N), dtype=torch.int64, device=self.ntt.devices[d])
+        self.backend.cc_mult_evk(plan, ins, row0s, kpack, first_part, row_off, out)
+        return self._new(([out[0]], [out[1]]), types.origins["ct"], level=level)
+
+    # =============================================================================================
     # multiplication (eng.py:1072-1151)
     # =============================================================================================
     def cc_mult(self, a: data_struct, b: data_struct, evk: data_struct, relin=True) -> data_struct:
@@ -720,6 +784,12 @@ class ckks_engine(EvaluatorOps):
             raise errors.MaximumLevelError(level=a.level, level_max=self.num_levels)
         loc = self._loc(level)
         N, logN = self.ctx.N, self.ctx.logN
+        if relin and a.level == b.level and not (a.ntt_state or b.ntt_state or a.include_special or b.include_special):
+            d = self._native_level(level)
+            if d is not None and self._native_level(a.level) == d:
+                out = self._cc_mult_native(a, b, evk, level, d)
+                if out is not None:
+                    return out
         d0, d1, d2 = [], [], []
         stacks = {d: self._ws("mult4", (4, self._rows(d, level, False), N), d) for d in loc}
         # x0, x1, y0, y1: both rescales and the four forward transforms are one backend call per device (for
@@ -1036,6 +1106,15 @@ class ckks_engine(EvaluatorOps):
         level = ct.level
         if not ct.ntt_state and not ct.include_special:
             pinv = pow(exponent, -1, 2 * self.ctx.N)
+            d = self._native_level(level)
+            if d is not None and ct.data[0][0].is_contiguous() and ct.data[1][0].is_contiguous():
+                # the whole rotation as ONE native call (lf_switch_key)
+                plan, _, first_part, row_off = self._op_plan(level, d)
+                kpack = self._key_pack(key)[self._loc(0, special=True).index(d)]
+                out = torch.empty((2, plan.ell, self.ctx.N), dtype=torch.int64, device=self.ntt.devices[d])
+                self.backend.switch_key_native(plan, ct.data[0][0], ct.data[1][0], pinv, canonical, kpack, first_part, row_off, out)
+                return data_struct(data=([out[0]], [out[1]]), include_special=False, ntt_state=False,
+                                   montgomery_state=ct.montgomery_state, origin=types.origins["ct"], level=level, hash=self.hash)
             c0, c1 = self.create_switcher(ct.data[1], key, level, addends=(ct.data[0], None), galois=(pinv, canonical))
             return data_struct(data=(c0, c1), include_special=False, ntt_state=False,
                                montgomery_state=ct.montgomery_state, origin=types.origins["ct"], level=level, hash=self.hash)

@@ -400,3 +400,29 @@ def test_c3_silver_cc_mult_decode_within_2_pow_minus_30_of_the_checker():
     rel = np.abs(dec_hip - dec_chk).max() / np.abs(dec_chk).max()
     assert rel < 2.0 ** -30, rel
     assert np.abs(dec_hip - m1 * m2).max() < 2e-7        # and both are the product, to CKKS accuracy
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["silver", "sb45"])
+def test_hip_native_op_entries_equal_the_step_by_step_engine(name):
+    """lf_cc_mult_evk / lf_switch_key (one native call per op over an lf_ks_plan) against the same engine with the entries
+    switched off, i.e. the Python orchestration of the individual steps — levels 0, 1 and a deep one, rotate and conjugate."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    from liberate_fhe_amd.fhe.backend import HipBackend
+    params = GOLD[name]["params"]
+    outs = []
+    for native in (True, False):
+        be = HipBackend()
+        be.native_ops = native
+        eng = ckks_engine(devices=["cuda:0"], backend=be, **params)
+        assert (eng._native_level(0) is not None) == native
+        evk, rotk = synth.key_switch_key(eng, 5), synth.key_switch_key(eng, 6, origin="rotation key:3")
+        conjk = synth.key_switch_key(eng, 7, origin="conjugation key")
+        res = []
+        for level in (0, 1, eng.num_levels - 2):
+            a, b = synth.ciphertext(eng, 50 + level, level), synth.ciphertext(eng, 60 + level, level)
+            prod = eng.cc_mult(a, b, evk)
+            res += [digest(prod), digest(eng.rotate_single(a, rotk)), digest(eng.conjugate(a, conjk)),
+                    digest(eng.rotate_single(prod, rotk))]
+        outs.append(res)
+    assert outs[0] == outs[1]

@@ -1,5 +1,6 @@
 """Host time per engine op (time to ENQUEUE an op, no synchronisation inside the loop) against its device time:
-the margin the one-process-per-GPU sharded path has before the host, not the GPU, paces it."""
+the margin the one-process-per-GPU sharded path has before the host, not the GPU, paces it.  Short bursts from an idle
+queue (the launch queue must not fill, or the enqueue time tracks the device)."""
 import sys, time, warnings
 import torch
 warnings.filterwarnings("ignore")
@@ -13,17 +14,29 @@ for preset in ("silver", "gold"):
     a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
     evk = synth.key_switch_key(eng, 5)
     rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
-    for name, fn in (("cc_mult", lambda: eng.cc_mult(a, b, evk)), ("rotate", lambda: eng.rotate_single(a, rotk))):
+    pinv = pow(5, -1, 2 * eng.ctx.N)
+    plan, _, fp, ro = eng._op_plan(0, 0)
+    kp = eng._key_pack(rotk)[0]
+    out = torch.empty((2, plan.ell, eng.ctx.N), dtype=torch.int64, device="cuda:0")
+    raw = lambda: eng.backend.switch_key_native(plan, a.data[0][0], a.data[1][0], pinv, True, kp, fp, ro, out)
+    for name, fn in (("cc_mult", lambda: eng.cc_mult(a, b, evk)), ("rotate", lambda: eng.rotate_single(a, rotk)),
+                     ("lf_switch_key alone", raw)):
         for _ in range(40):
             fn()
         torch.cuda.synchronize()
-        n = 200
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        t1 = time.perf_counter()
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        print(f"{preset} {name}: host enqueue {1e6 * (t1 - t0) / n:.1f} us/op, device-paced total {1e6 * (t2 - t0) / n:.1f} us/op")
+        host, total, n = [], [], 8
+        for rep in range(10):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            host.append((t1 - t0) / n)
+            total.append((t2 - t0) / n)
+        host.sort(); total.sort()
+        print(f"{preset} {name}: host enqueue {1e6 * host[len(host) // 2]:.1f} us/op (median of 10 bursts of {n}), "
+              f"device-paced {1e6 * total[len(total) // 2]:.1f} us/op")
     del eng
     torch.cuda.empty_cache()
