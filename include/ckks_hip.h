@@ -48,6 +48,15 @@ int lf_abi_version(void);
 #define LF_LIMIT_LOGN 4
 int lf_limits(int which);
 
+/* Launch-shape thresholds (never results: every setting produces the same words).  Returns the previous value, -1 for an
+ * unknown `which`; value < 0 only reads.  Process-wide; set before launching from several threads.
+ *   LF_TUNE_KS_ONE_MIN_PAIRS  (digit, target limb) pairs from which the key switch of a logN 13..15 ring runs extension +
+ *                             the WHOLE forward transform as one launch, a block per pair (csrc/ckks_ntt_one.h); below it
+ *                             the column kernel + 4096-word tiled pass, 8..16 times the blocks.  Default INT_MAX (off):
+ *                             measured slower on MI355X at every preset size (profiles/r03_one_launch_ab.txt). */
+#define LF_TUNE_KS_ONE_MIN_PAIRS 0
+int lf_tune(int which, int value);
+
 /* ---- elementwise family --------------------------------------------------------------------- */
 
 /* ntt_cuda.mont_mult (ntt.cpp:120-144, K.cu:66-146): c[i][j] = REDC62(a[i][j] * b[i][j]). */

@@ -1,5 +1,5 @@
 """Engine-op rates on this GPU (the figures bench.py reports as `extra`), without the NTT / CPU legs:
-    python tools/eo.py [quick]"""
+    python tools/eo.py [quick] [--ks-one-min PAIRS]"""
 import json
 import os
 import sys
@@ -11,6 +11,9 @@ import bench  # noqa: E402
 import __graft_entry__ as g  # noqa: E402
 
 g.build()
+if "--ks-one-min" in sys.argv:   # launch-shape threshold of the one-launch key-switch transform (lf_tune)
+    from liberate_fhe_amd._native import lib
+    lib.lf_tune(0, int(sys.argv[sys.argv.index("--ks-one-min") + 1]))
 rates, roof = bench.engine_rates("cuda:0", quick=len(sys.argv) > 1 and sys.argv[1] == "quick")
 print(json.dumps({k: round(v, 1) for k, v in rates.items()}))
 print(json.dumps({k: round(v["frac"], 4) for k, v in roof.items()}))
