@@ -1086,6 +1086,66 @@ class ckks_engine(EvaluatorOps):
             c0.append(out[0]); c1.append(out[1])
         return c0, c1
 
+    # ---- the reference's key-switch steps as public methods (eng.py:218-227, 654-743, 906-937) ---------------------------
+    # The reference's own callers are create_switcher and the multiparty helpers; create_switcher above runs fused
+    # kernels instead.  Code written against the step methods still works: each one is the unfused C-ABI step of the
+    # same name (lf_ks_digits / lf_ks_extend, lf_ntt, lf_mont_mult), so every intermediate word is the reference's.
+    def reserve_ksk_buffers(self):
+        """Staging buffers of the reference's digit gather (one pinned [K, N] host tensor per local part, eng.py:218-227).
+        This engine moves digits device to device (comm.py) and never reads them; kept so that callers find the attribute."""
+        K, N = self.ntt.num_special_primes, self.ctx.N
+        self.ksk_buffers = []
+        for d in range(self.ntt.num_devices):
+            n_parts = len(self.ntt.p.p[0][d]) if d in self.local_ids else 0
+            bufs = [torch.empty((K, N), dtype=torch.int64) for _ in range(n_parts)]
+            if torch.cuda.is_available():
+                bufs = [b.pin_memory() for b in bufs]
+            self.ksk_buffers.append(bufs)
+
+    def pre_extend(self, a, device_id, level, part_id, exit_ntt=False):
+        """Mixed-radix (Garner) digits of part `part_id` of the polynomial a[device_id] ([rows, N]): the [alpha, N] state the
+        reference returns, signed-lazy words included (eng.py:654-705)."""
+        tabs = self._ks_tables(level)
+        rows_of_part = self.ntt.p.parts[level][device_id][part_id]
+        lo, alpha = rows_of_part[0], len(rows_of_part)
+        i = self._loc(level).index(device_id) if len(a) != self.ntt.num_devices else device_id
+        src = a[i]
+        if exit_ntt:
+            part = src[lo:lo + alpha]
+            self.ntt.intt_exit_reduce([part], level, device_id, part_id)
+        _, desc, tab = tabs[("digits", device_id)]
+        one = desc[part_id:part_id + 1].clone()
+        state = torch.empty((self._rows(device_id, level, False), self.ctx.N), dtype=torch.int64, device=src.device)
+        self.backend.ks_digits(src.contiguous(), state, 1, one, tab, self._consts(device_id, level, False))
+        return state[lo:lo + alpha]
+
+    def extend(self, state, device_id, level, part_id, target_device_id=None):
+        """Basis extension of a digit state (of part `part_id` of device `device_id`) to every limb, special ones included,
+        of `target_device_id`: [rows, N] in Montgomery form (eng.py:707-743)."""
+        target = device_id if target_device_id is None else target_device_id
+        tabs = self._ks_tables(level)
+        desc, E, _ = tabs[("extend", target)]
+        s_id = self.stor_ids[level][device_id][part_id]
+        one = desc[s_id:s_id + 1].clone()
+        one[0, 0] = 0                                   # the state handed in starts at its own row 0
+        rows = self._rows(target, level, True)
+        st = state.to(self.ntt.devices[target]).contiguous()
+        out = torch.empty((1, rows, self.ctx.N), dtype=torch.int64, device=st.device)
+        self.backend.ks_extend(st, out, 1, rows, one, E, self._consts(target, level, True))
+        return out[0]
+
+    def switcher_later_part(self, state, ksk, src_device_id, dst_device_id, level, part_id):
+        """extend -> NTT -> the two products with the key part (eng.py:906-937); returns (d0, d1) on dst_device_id."""
+        extended = self.extend(state, src_device_id, level, part_id, dst_device_id)
+        self.ntt.ntt([extended], level, dst_device_id, -2)
+        part = ksk.data[self.parts_alloc[level][src_device_id][part_id]].data
+        i = self._loc(0, special=True).index(dst_device_id)
+        start = self.ntt.starts[level][dst_device_id]
+        k0, k1 = part[0][i][start:], part[1][i][start:]
+        d0 = self.ntt.mont_mult([extended], [k0], level, dst_device_id, -2)
+        d1 = self.ntt.mont_mult([extended], [k1], level, dst_device_id, -2)
+        return d0[0], d1[0]
+
     def switch_key(self, ct: data_struct, ksk: data_struct) -> data_struct:
         if ct.origin != types.origins["ct"]:
             raise errors.NotMatchType(origin=ct.origin, to=types.origins["ct"])

@@ -198,3 +198,76 @@ def test_engine_keygen_encrypt_decrypt_with_hip_samplers():
     assert np.abs(me.decrode(c1, sk) - m1).max() < 1e-8
     assert np.abs(me.decrode(me.cc_mult(c1, c2, evk), sk) - m1 * m2).max() < 1e-7
     assert np.abs(me.decrode(me.rotate_single(c1, rotk), sk) - np.roll(m1, 3)).max() < 1e-8
+
+
+# ---- the three post-processing maps against their EXACT-INTEGER definitions at the gold key shape ------------------
+# (they exist in the reference only as CUDA; the oracle restates them, and here the HIP kernels are held directly to the
+# mathematical definitions — Python integers — on the tensor shapes gold key generation draws: 43 channels x N = 65536)
+GOLD_N = 65536
+
+
+def _gold_moduli():
+    from liberate_fhe_amd.fhe.context.ckks_context import ckks_context
+    ctx = ckks_context(logN=16, num_special_primes=4)
+    q = [int(x) for x in ctx.q]
+    return q + q[-4:]            # 39 own channels + 4 repeating ones = the 43 limbs of a gold uniform draw
+
+
+def test_randint_gold_shape_equals_exact_128_bit_product():
+    from liberate_fhe_amd.csprng import randint_cuda, chacha20_cuda
+    q = _gold_moduli()
+    C, L = len(q), GOLD_N // 4
+    s = random_states(C * L, 77).reshape(C, L, 16)
+    qa = np.array(q, dtype=np.uint64)
+    d = dev(s)
+    blocks = chacha20_cuda.chacha20([dev(s).view(-1, 16)], 1)[0].view(C, L, 16).cpu().numpy()   # the words the fused kernel maps
+    got = randint_cuda.randint_fast([d], [qa], -1, 1)[0].cpu().numpy()
+    assert got.shape == (C, GOLD_N)
+    g = np.random.default_rng(5)
+    picks = [(int(c), int(i)) for c, i in zip(g.integers(0, C, 30000), g.integers(0, GOLD_N, 30000))]
+    picks += [(c, i) for c in (0, C - 1) for i in (0, 1, 2, 3, GOLD_N - 1)]
+    for c, i in picks:
+        w = blocks[c, i // 4, 4 * (i % 4):4 * (i % 4) + 4]
+        want = co.scale128_exact(q[c], *w) - 1
+        assert int(got[c, i]) == want, (c, i)
+    assert got.min() >= -1 and all(int(got[c].max()) <= q[c] - 2 for c in range(C))
+
+
+def test_discrete_gaussian_gold_shape_equals_table_inversion():
+    from liberate_fhe_amd.csprng import discrete_gaussian_cuda, chacha20_cuda
+    from liberate_fhe_amd.csprng.discrete_gaussian_sampler import cumulative_table
+    flat, size, depth = tree()
+    table, _ = cumulative_table()
+    n = GOLD_N // 4 * 2                       # two polynomials (encrypt's e0, e1)
+    s = random_states(n, 78)
+    blocks = chacha20_cuda.chacha20([dev(s)], 1)[0].cpu().numpy()
+    got = discrete_gaussian_cuda.discrete_gaussian_fast([dev(s)], flat.__array_interface__["data"][0], size, depth, 1)[0].cpu().numpy()
+    assert got.shape == (4 * n,)
+    idx = np.random.default_rng(6).integers(0, 4 * n, 40000)
+    for i in idx:
+        w = blocks[i // 4, 4 * (i % 4):4 * (i % 4) + 4]
+        assert int(got[i]) == co.cdt_sample_exact(table, *w), int(i)
+    assert abs(float(got.astype(np.float64).std()) - 3.2) < 0.05
+
+
+def test_randround_gold_shape_equals_exact_rule():
+    """sign(c) * (floor|c| + [r < rn(frac|c| * 2^32)]) with exact rational arithmetic on the doubles."""
+    from fractions import Fraction
+    from liberate_fhe_amd.csprng import randround_cuda
+    g = np.random.default_rng(9)
+    c = g.normal(0.0, 2.0 ** 20, GOLD_N) + g.integers(-3, 4, GOLD_N)
+    c[:6] = [0.0, -0.0, 0.5, -0.5, 1.0 - 2.0 ** -33, -(2.0 ** 40 + 0.25)]
+    r = g.integers(0, 1 << 32, size=GOLD_N, dtype=np.int64)
+    d = dev(r)
+    randround_cuda.randround([dev(c)], [d])
+    got = d.cpu().numpy()
+    for i in list(range(64)) + [int(x) for x in g.integers(0, GOLD_N, 20000)]:
+        a = abs(Fraction(float(c[i])))
+        ip = a.numerator // a.denominator
+        scaled = (a - ip) * (1 << 32)                    # exact; round half to even like __double2ll_rn
+        fl = scaled.numerator // scaled.denominator
+        rem = scaled - fl
+        ifrac = fl + (1 if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2 == 1) else 0)
+        mag = ip + (1 if int(r[i]) < ifrac else 0)
+        want = -mag if np.signbit(c[i]) else mag
+        assert int(got[i]) == want, i

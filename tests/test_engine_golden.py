@@ -456,3 +456,52 @@ def test_one_launch_key_switch_equals_two_pass_form(params):
     finally:
         lib.lf_tune(0, old)
     assert outs[0] == outs[1]
+
+
+def _reference_shaped_switcher(eng, a, ksk, level):
+    """create_switcher as the reference composes it from its step methods (eng.py:746-904) on ONE device: digits per part,
+    extension + NTT + key products per part, sums, inverse transform, division by P through the checker's chain."""
+    d, N = 0, eng.ctx.N
+    rows, ell, K = eng._rows(d, level, True), eng._rows(d, level, False), eng.ntt.num_special_primes
+    sums = None
+    for part_id in range(len(eng.ntt.p.p[level][d])):
+        state = eng.pre_extend(a, d, level, part_id)
+        d0, d1 = eng.switcher_later_part(state, ksk, d, d, level, part_id)
+        if sums is None:
+            sums = [d0, d1]
+        else:
+            sums = [eng.ntt.mont_add([sums[0]], [d0], level, d, -2)[0], eng.ntt.mont_add([sums[1]], [d1], level, d, -2)[0]]
+    s = torch.stack(sums).contiguous()
+    eng.ntt.intt_exit_reduce([s[0]], level, d, -2)
+    eng.ntt.intt_exit_reduce([s[1]], level, d, -2)
+    out = torch.empty((2, ell, N), dtype=torch.int64, device=s.device)
+    tabs = eng._ks_tables(level)
+    eng.backend.ks_moddown_batch([s[0], s[1]], [out[0], out[1]], [None, None], ell, K, tabs[("pir", d)], eng._vec("Rs", d, level, True),
+                                 eng._consts(d, level, True), PiP=None)
+    return out
+
+
+def _check_step_methods(eng):
+    ksk = synth.key_switch_key(eng, 21)
+    for level in (0, 2):
+        a = [synth.ciphertext(eng, 70 + level, level).data[1][0]]
+        got = _reference_shaped_switcher(eng, a, ksk, level)
+        c0, c1 = eng.create_switcher(a, ksk, level)
+        assert torch.equal(got[0], c0[0]) and torch.equal(got[1], c1[0])
+    eng.reserve_ksk_buffers()
+    assert len(eng.ksk_buffers[0]) == len(eng.ntt.p.p[0][0]) and tuple(eng.ksk_buffers[0][0].shape) == (eng.ntt.num_special_primes, eng.ctx.N)
+
+
+def test_public_key_switch_step_methods_checker():
+    """pre_extend / extend / switcher_later_part / reserve_ksk_buffers (eng.py:218-227, 654-743, 906-937) composed the
+    reference's way equal create_switcher (checker backend: host logic)."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    from tests.oracle_backend import OracleBackend
+    _check_step_methods(ckks_engine(devices=["cpu"], backend=OracleBackend(), **_rot_params()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("params", [dict(logN=12, num_scales=5, num_special_primes=2, is_secured=False), _rot_params()])
+def test_public_key_switch_step_methods_hip(params):
+    from liberate_fhe_amd.fhe import ckks_engine
+    _check_step_methods(ckks_engine(devices=["cuda:0"], **params))

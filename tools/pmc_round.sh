@@ -1,6 +1,8 @@
 #!/bin/bash
-# PMC passes (separate runs, as the guide prescribes) over the bench step and over gold / silver cc_mult + rotate
+# PMC passes (separate runs, as the guide prescribes) over the bench step and over gold / silver cc_mult:
+#   tools/pmc_round.sh <tag>      (on the GPU box; then tools/summarize_round.py <tag> -> profiles/)
 set -u
+TAG=${1:-r03}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out; mkdir -p $OUT; REPO=$PWD
 run() {  # tag, counters..., then "--", then program args
@@ -18,6 +20,6 @@ for P in gold silver; do
   run ${P}_valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY -- $C
 done
 # kernel stats of the bench command itself (the file the roofline numbers are checked against)
-cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_r02 -o stats -- python3 $REPO/bench.py --no-extra > $OUT/prof_r02.log 2>&1; cd $REPO
-python3 bench.py > $OUT/bench_r02.json 2> $OUT/bench_r02.err; tail -c 400 $OUT/bench_r02.json
+cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o stats -- python3 $REPO/bench.py --no-extra > $OUT/prof_$TAG.log 2>&1; cd $REPO
+python3 bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; tail -c 400 $OUT/bench_$TAG.json
 ls $OUT | grep pmc2 | head -20

@@ -8,7 +8,9 @@ tables, warm-up).  The summary also records how many __amd_rocclr_copyBuffer dis
 import json, os, sqlite3, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+sys.path.insert(0, ROOT)
+import __graft_entry__ as _g   # noqa: E402
 src = os.path.join(ROOT, "gpurun_out")
 N_OPS = 10
 lines, summary = [], {}
@@ -47,5 +49,6 @@ for preset in ("silver", "gold"):
             "dominant_kernel_avg_us": dom[1][1] / dom[1][0],
             "kernels_us_per_op": {k: round(v[1] / N_OPS, 2) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}}
 open(os.path.join(ROOT, "profiles", f"{tag}_engine_ops_kernel_stats.txt"), "w").write("\n".join(lines) + "\n")
+summary["library_digest"] = _g.library_digest()   # bench.py drops these figures when the running build differs
 json.dump(summary, open(os.path.join(ROOT, "profiles", f"{tag}_engine_ops_summary.json"), "w"), indent=1)
 print("\n".join(lines))

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""gpurun_out/ of tools/r02_pmc.sh -> the tracked summaries under profiles/ (tag r02):
+"""gpurun_out/ of tools/pmc_round.sh <tag> -> the tracked summaries under profiles/ (python3 tools/summarize_round.py <tag>):
 
-  r02_bench_kernel_stats.txt   rocprofv3 --kernel-trace --stats of `python3 bench.py --no-extra`
-  r02_bench_pmc.txt            FETCH_SIZE / WRITE_SIZE / SQ passes over the same command (separate runs)
-  traffic_r02.json             what bench.py folds into its roofline block (bytes and VALU figures per launch)
-  r02_engine_ops_pmc.txt       the same counters per kernel of gold / silver cc_mult (+relinearize)
+  <tag>_bench_kernel_stats.txt   rocprofv3 --kernel-trace --stats of `python3 bench.py --no-extra`
+  <tag>_bench_pmc.txt          FETCH_SIZE / WRITE_SIZE / SQ passes over the same command (separate runs)
+  traffic_<tag>.json           what bench.py folds into its roofline block (bytes and VALU figures per launch)
+  <tag>_engine_ops_pmc.txt       the same counters per kernel of gold / silver cc_mult (+relinearize)
 
 Units: rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts a 16 B/lane coalesced read at
 half its bytes (MI355X_MICROARCH.md, HBM section) -> doubled.  SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count in units of
@@ -13,7 +13,10 @@ import collections, json, os, sqlite3, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, out = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-TAG = "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+sys.path.insert(0, ROOT)
+import __graft_entry__ as _g   # noqa: E402
+DIGEST = _g.library_digest()   # the sources these counters were taken at: bench.py drops the figures when the build differs
 
 
 def q(db, sql):
@@ -63,7 +66,7 @@ print("\n".join(lines[:12]))
 f, w, v = counters("bench_fetch"), counters("bench_write"), counters("bench_valu")
 pm = [f"# rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --no-extra --steps 5 --warmup 2   ({TAG}); one run per line group",
       "# kernel/grid | us | FETCH_SIZE KiB (raw) | read MB (x2, gfx950) | WRITE_SIZE KiB | write MB | moved TB/s | VALU wave-instr | VALU busy | CU busy", ""]
-traffic = {"batch_per_gpu": 128}
+traffic = {"batch_per_gpu": 128, "library_digest": DIGEST}
 for key in sorted(f):
     if "ntt_" not in key[0] or "cols_mixed" not in key[0] and "pass16" not in key[0] and "fwd_pass" not in key[0]:
         continue
@@ -80,7 +83,7 @@ for key in sorted(f):
     traffic[f"{name}_salu_per_valu"] = v[key]["SQ_INSTS_SALU"] / v[key]["SQ_INSTS_VALU"]
 traffic["note"] = ("per launch at batch_per_gpu polynomials x 30 limbs; bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes, gfx950 half-count "
                    "correction on reads); valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs over SQ_BUSY_CU_CYCLES / 256 CUs; source "
-                   "profiles/r02_bench_pmc.txt")
+                   f"profiles/{TAG}_bench_pmc.txt")
 open(os.path.join(out, f"{TAG}_bench_pmc.txt"), "w").write("\n".join(pm) + "\n")
 json.dump(traffic, open(os.path.join(out, f"traffic_{TAG}.json"), "w"), indent=1)
 print("\n".join(pm))
