@@ -1059,7 +1059,10 @@ __global__ void __launch_bounds__(NTT_THREADS, NTT_PASS_WAVES) ntt_fwd_pass_mixe
 // four stages through a 4096-word LDS tile.  Arithmetic, entry and range handling are those of
 // ntt_fwd_pass; the class decision (exact fp64 vs signed integer routine) is taken per lane.
 // ------------------------------------------------------------------------------------------------
-#define NTT_COL_THREADS 256
+#ifndef NTT_COL_THREADS
+#define NTT_COL_THREADS 128   // columns per block = contiguous 8-byte words per row and block (measured at the bench workload,
+                              // column pass alone: 64 -> 0.72-0.73 ms, 128 -> 0.68-0.70, 256 -> 0.71-0.73, 512 -> 0.79-0.80)
+#endif
 
 // row pointer of a column step as an opaque SGPR pair: keeps the compiler from folding the lane index into 2^K
 // per-lane 64-bit addresses (32 VGPRs held from the loads to the stores at K = 4)
