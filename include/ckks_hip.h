@@ -55,6 +55,9 @@ int lf_limits(int which);
  *                             the column kernel + 4096-word tiled pass, 8..16 times the blocks.  Default INT_MAX (off):
  *                             measured slower on MI355X at every preset size (profiles/r03_one_launch_ab.txt). */
 #define LF_TUNE_KS_ONE_MIN_PAIRS 0
+/*   LF_TUNE_KS_EXT_COLS_MAX   largest logN - 12 (0 .. 4) for which the key switch's extension + leading stages run as the
+ *                             column kernel (one register step per column, no LDS); above it the LDS-tiled form. */
+#define LF_TUNE_KS_EXT_COLS_MAX 1
 int lf_tune(int which, int value);
 
 /* ---- elementwise family --------------------------------------------------------------------- */

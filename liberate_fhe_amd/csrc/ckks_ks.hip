@@ -255,35 +255,34 @@ __device__ __forceinline__ void ks_ext_cols_body(int b, const i64 *__restrict__ 
     c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
     c.relaxed = 1;
     c.inv_reduce = 0;
-    const int row_start = (int)desc[p * 3 + 0], alpha = (int)desc[p * 3 + 1] & 0xff;
-    const bool wide = ((int)desc[p * 3 + 1] >> 8) & 1;
+    // (pinned to SGPRs: the digit loop below runs on the scalar unit and feeds SGPR row pointers)
+    const int row_start = __builtin_amdgcn_readfirstlane((int)desc[p * 3 + 0]);
+    const int alpha = __builtin_amdgcn_readfirstlane((int)desc[p * 3 + 1] & 0xff);
+    const bool wide = __builtin_amdgcn_readfirstlane(((int)desc[p * 3 + 1] >> 8) & 1) != 0;
     const i64 e_off = desc[p * 3 + 2] + crow;
     const unsigned lane = threadIdx.x;
     const i64 *src = state + (i64)ctu * kg.state_stride + (i64)row_start * kg.N + chunk * NTT_COL_THREADS;
     i64 *dst = tmp + ((((i64)ctu * kg.nparts + p) * kg.rows + crow) << kg.logN) + chunk * NTT_COL_THREADS;
 
     if (DP) {
-        double cst[KS_MAX_ALPHA], cst31[KS_MAX_ALPHA];
-#pragma unroll
-        for (int i = 0; i < KS_MAX_ALPHA; ++i) {
-            cst[i] = i < alpha ? Ed[e_off + (i64)i * kg.rows] : 0.0;
-            cst31[i] = wide ? dp_mulmod(cst[i], 2147483648.0, c.d) : 0.0;
-        }
+        // the digit loop is a RUNTIME loop with wave-uniform constants (scalar loads): at most R loads in flight beside the
+        // R accumulated words — the unrolled form kept 8 x R loads alive (90 VGPRs at R = 16, measured slower at logN 16)
         double x[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) x[k] = 0.0;
+        for (int i = 0; i < alpha; ++i) {
+            const double cst = Ed[e_off + (i64)i * kg.rows];
+            const i64 *rowi = src + ((i64)i << kg.logN);   // wave-uniform (scalar base + lane offset in the loads below)
+            if (!wide) {
 #pragma unroll
-        for (int i = 0; i < KS_MAX_ALPHA; ++i) {
-            if (i < alpha) {
-                const i64 *rowi = src + (i64)i * kg.N;
+                for (int k = 0; k < R; ++k)   // signed digit words (|y| < 2^43): the formula is sign-agnostic
+                    x[k] += dp_mulmod_bal(dp_from_signed(rowi[((i64)k << logC) + lane]), cst, c.d);
+            } else {
+                const double cst31 = dp_mulmod(cst, 2147483648.0, c.d);
 #pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    const i64 y = uniform_row(const_cast<i64 *>(rowi), (i64)k << logC)[lane];
-                    if (!wide)   // signed digit words (|y| < 2^43): the formula is sign-agnostic
-                        x[k] += dp_mulmod_bal(dp_from_signed(y), cst[i], c.d);
-                    else         // 60-bit digit words: 31-bit halves through the native 32-bit conversions
-                        x[k] += dp_mulmod_bal((double)(int)(y >> 31), cst31[i], c.d) +
-                                dp_mulmod_bal((double)(unsigned)(y & 0x7fffffffll), cst[i], c.d);
+                for (int k = 0; k < R; ++k) {   // 60-bit digit words: 31-bit halves through the native 32-bit conversions
+                    const i64 y = rowi[((i64)k << logC) + lane];
+                    x[k] += dp_mulmod_bal((double)(int)(y >> 31), cst31, c.d) + dp_mulmod_bal((double)(unsigned)(y & 0x7fffffffll), cst, c.d);
                 }
             }
         }
@@ -291,39 +290,42 @@ __device__ __forceinline__ void ks_ext_cols_body(int b, const i64 *__restrict__ 
 #pragma unroll
         for (int k = 0; k < R; ++k) uniform_row(dst, (i64)k << logC)[lane] = dp_to_word(dp_reduce(x[k], c.d.q, c.d.qinv));
     } else {
-        i64 cst[KS_MAX_ALPHA];
-#pragma unroll
-        for (int i = 0; i < KS_MAX_ALPHA; ++i) cst[i] = i < alpha ? E[e_off + (i64)i * kg.rows] : 0;
         i64 w[R];
+        if (wide && alpha > 1) {   // several 60-bit limbs in one digit (no preset has that): term by term
 #pragma unroll
-        for (int k = 0; k < R; ++k) {
-            i64 a;
-            if (wide && alpha > 1) {   // several 60-bit limbs in one digit (no preset has that): term by term
-                a = 0;
+            for (int k = 0; k < R; ++k) w[k] = 0;
+            for (int i = 0; i < alpha; ++i) {
+                const i64 cst = E[e_off + (i64)i * kg.rows];
+                const i64 *rowi = src + ((i64)i << kg.logN);   // wave-uniform (scalar base + lane offset in the loads below)
 #pragma unroll
-                for (int i = 0; i < KS_MAX_ALPHA; ++i) {
-                    if (i < alpha) {
-                        const i64 y = uniform_row(const_cast<i64 *>(src + (i64)i * kg.N), (i64)k << logC)[lane];
-                        const i64 t = mm62s(y, cst[i], c.m.q, c.m.k);
-                        a = i == 0 ? t : csub(a + t, c.m.q2);
-                    }
+                for (int k = 0; k < R; ++k) {
+                    const i64 t = mm62s(rowi[((i64)k << logC) + lane], cst, c.m.q, c.m.k);
+                    w[k] = i == 0 ? t : csub(w[k] + t, c.m.q2);
                 }
-            } else {                   // sum_i y_i * (L_{i-1} R^2 mod q) in 128 bits, ONE REDC (see ks_ext_body)
-                i128 acc = 0;
-#pragma unroll
-                for (int i = 0; i < KS_MAX_ALPHA; ++i) {
-                    if (i < alpha) {
-                        const i64 y = uniform_row(const_cast<i64 *>(src + (i64)i * kg.N), (i64)k << logC)[lane];
-                        acc += (i128)y * (i128)cst[i];
-                    }
-                }
-                a = redc62_wide(acc, c.m.q, c.m.k);
             }
-            w[k] = a < 0 ? a + c.m.q2 : a;           // residues only: fold into [0, 2q)
+        } else {                   // sum_i y_i * (L_{i-1} R^2 mod q) in 128 bits, ONE REDC (see ks_ext_body); 8 words at a time
+#pragma unroll
+            for (int g0 = 0; g0 < R; g0 += 8) {
+                constexpr int G = R < 8 ? R : 8;
+                i128 acc[G];
+#pragma unroll
+                for (int k = 0; k < G; ++k) acc[k] = 0;
+                for (int i = 0; i < alpha; ++i) {
+                    const i64 cst = E[e_off + (i64)i * kg.rows];
+                    const i64 *rowi = src + ((i64)i << kg.logN);   // wave-uniform (scalar base + lane offset in the loads below)
+#pragma unroll
+                    for (int k = 0; k < G; ++k)
+                        acc[k] += (i128)rowi[((i64)(g0 + k) << logC) + lane] * (i128)cst;
+                }
+#pragma unroll
+                for (int k = 0; k < G; ++k) w[g0 + k] = redc62_wide(acc[k], c.m.q, c.m.k);
+            }
         }
+#pragma unroll
+        for (int k = 0; k < R; ++k) w[k] = w[k] < 0 ? w[k] + c.m.q2 : w[k];   // residues only: fold into [0, 2q)
         cols_fwd_stages<ArithShoup, K>(w, c);
 #pragma unroll
-        for (int k = 0; k < R; ++k) uniform_row(dst, (i64)k << logC)[lane] = ArithShoup::canon(c, w[k]);
+        for (int k = 0; k < R; ++k) dst[((i64)k << logC) + lane] = ArithShoup::canon(c, w[k]);
     }
 }
 
@@ -665,6 +667,11 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
 // while a 1024-thread block at 128 VGPRs is alone on its CU (nothing covers its load phase, its four block barriers and
 // the half-occupancy exchange rounds) and 152 blocks leave 104 CUs idle where the two-pass form has 1 216 small ones.
 int g_ks_one_min_pairs = 0x7fffffff;
+// largest number of leading stages (logN - 12) whose extension + strided pass runs as the column kernel (lf_tune).
+// With the digit loop as a runtime loop (R loads in flight, 100 VGPRs at R = 16) the column form also wins at logN 16:
+// gold cc_mult 2 104-2 130 -> 2 168-2 183 ops/s, rotate 2 653-2 695 -> 2 733-2 763, 64 rotations under one key
+// 3 110 -> 3 300 /s (tools/eo.py --ext-cols-max 3 | 4, one box); round 2's fully unrolled form had lost there (116 vs 95 us).
+int g_ks_ext_cols_max = 4;
 
 void classify_rows(int rows, const int64_t *q_host, RowList &dp, RowList &in) {
     dp.n = in.n = 0;
@@ -703,9 +710,8 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
         return (int)hipGetLastError();
     }
     // K2: extend + strided pass — as one register step per column when the strided pass has at most 4 stages
-    // (measured on MI355X, extension kernel alone: silver / logN 15 22.5 -> 20.0 us; gold / logN 16 95 -> 116 us — 16 words
-    // per column cost 90 VGPRs and 64 loads in flight per thread — so logN 16 keeps the LDS-tiled form)
-    if (S1 <= 3) {
+    // (measured on MI355X, extension kernel alone: silver / logN 15 22.5 -> 20.0 us; gold / logN 16 see g_ks_ext_cols_max)
+    if (S1 <= g_ks_ext_cols_max) {
         const unsigned per_limb = ((1u << tl) / NTT_COL_THREADS) * polys;   // column chunks x digits x ciphertexts
         const ClassLists cl = class_lists(in, dp, per_limb * (unsigned)in.n);   // either list may be empty
         const dim3 grid((unsigned)cl.in_blocks + per_limb * (unsigned)dp.n), block(NTT_COL_THREADS);
@@ -715,7 +721,7 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
                            (const i64 *)desc, (const i64 *)E, Ed, (const i64 *)psi_br, psi_dp, (const i64 *)ql,         \
                            (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);                                         \
         break;
-        switch (S1) { LF_EXT_COLS_CASE(1) LF_EXT_COLS_CASE(2) LF_EXT_COLS_CASE(3) }
+        switch (S1) { LF_EXT_COLS_CASE(1) LF_EXT_COLS_CASE(2) LF_EXT_COLS_CASE(3) LF_EXT_COLS_CASE(4) }
 #undef LF_EXT_COLS_CASE
     } else if (mixed) {
         const ClassLists cl = class_lists(in, dp, tiles * in.n * polys);
@@ -819,9 +825,10 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
 extern "C" {
 
 int lf_tune(int which, int value) {
-    if (which != LF_TUNE_KS_ONE_MIN_PAIRS) return -1;
-    const int old = g_ks_one_min_pairs;
-    if (value >= 0) g_ks_one_min_pairs = value;
+    int *knob = which == LF_TUNE_KS_ONE_MIN_PAIRS ? &g_ks_one_min_pairs : which == LF_TUNE_KS_EXT_COLS_MAX ? &g_ks_ext_cols_max : nullptr;
+    if (!knob) return -1;
+    const int old = *knob;
+    if (value >= 0 && !(which == LF_TUNE_KS_EXT_COLS_MAX && value > 4)) *knob = value;
     return old;
 }
 

@@ -505,3 +505,19 @@ def test_public_key_switch_step_methods_checker():
 def test_public_key_switch_step_methods_hip(params):
     from liberate_fhe_amd.fhe import ckks_engine
     _check_step_methods(ckks_engine(devices=["cuda:0"], **params))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cols_max", [("gold", 3), ("silver", 0), ("bronze", 0)])
+def test_key_switch_extension_column_and_tiled_forms(name, cols_max):
+    """The key switch's extension + leading stages as the column kernel (one register step per column) and as the LDS-tiled
+    kernel, forced through lf_tune for the size whose default is the other one: the reference digests either way."""
+    from liberate_fhe_amd._native import lib
+    from liberate_fhe_amd.fhe import ckks_engine
+    old = lib.lf_tune(1, -1)
+    try:
+        lib.lf_tune(1, cols_max)
+        rec = GOLD[name]
+        check_config(ckks_engine(devices=["cuda:0"], **rec["params"]), rec)
+    finally:
+        lib.lf_tune(1, old)

@@ -14,6 +14,9 @@ g.build()
 if "--ks-one-min" in sys.argv:   # launch-shape threshold of the one-launch key-switch transform (lf_tune)
     from liberate_fhe_amd._native import lib
     lib.lf_tune(0, int(sys.argv[sys.argv.index("--ks-one-min") + 1]))
+if "--ext-cols-max" in sys.argv:   # largest logN - 12 whose extension runs as the column kernel (lf_tune)
+    from liberate_fhe_amd._native import lib
+    lib.lf_tune(1, int(sys.argv[sys.argv.index("--ext-cols-max") + 1]))
 rates, roof = bench.engine_rates("cuda:0", quick=len(sys.argv) > 1 and sys.argv[1] == "quick")
 print(json.dumps({k: round(v, 1) for k, v in rates.items()}))
 print(json.dumps({k: round(v["frac"], 4) for k, v in roof.items()}))
