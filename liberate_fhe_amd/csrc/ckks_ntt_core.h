@@ -1126,6 +1126,30 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
     i64 *colu = a + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS;
     const unsigned lane = threadIdx.x;
 
+    if (RS && DP && g.relaxed) {
+        // relaxed fp64 class (cc_mult's opening): only residues matter, so the rescale itself runs in fp64 — one balanced
+        // product per word with the PLAIN constant q_l^-1 mod q instead of a 62-bit REDC, and no canonical fix-up
+        // (|in - row0| < 2^42; the balanced arithmetic of the stages is sign-agnostic)
+        const i64 j = (i64)chunk * NTT_COL_THREADS + threadIdx.x;
+        const i64 *src = rsrc->in[poly] + ((i64)crow << g.logN) + j;
+        const i64 *z0 = rsrc->row0[poly] + j;
+        i64 sp = redc62(rsrc->scales[crow], c.m.q, c.m.k);
+        sp = sp < (i64)c.m.q ? sp : sp - (i64)c.m.q;
+        const double scp = (double)sp;
+        const double r1 = enter ? (double)((1ull << 62) % c.m.q) : 0.0;
+        double x[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const i64 z = z0[(i64)k << logC];
+            double v = dp_mulmod_bal(dp_from_signed(src[(i64)k << logC] - z), scp, c.d) + (z > rsrc->round_at ? 1.0 : 0.0);
+            if (enter) v = dp_mulmod_bal(v, r1, c.d);
+            x[k] = v;
+        }
+        cols_fwd_stages<ArithDpR, K>(x, c);
+#pragma unroll
+        for (int k = 0; k < R; ++k) uniform_row(colu, (i64)k << logC)[lane] = dp_to_word(dp_reduce(x[k], c.d.q, c.d.qinv));
+        return;
+    }
     i64 w[R];
     if (RS) {
         const i64 j = (i64)chunk * NTT_COL_THREADS + threadIdx.x;
