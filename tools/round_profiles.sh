@@ -11,5 +11,7 @@ python3 tools/summarize_engine_ops.py $TAG > gpurun_out/summarize_engine_ops_$TA
 mkdir -p gpurun_out/profiles_$TAG
 cp profiles/${TAG}_* profiles/traffic_${TAG}.json gpurun_out/profiles_$TAG/ 2>/dev/null
 cp gpurun_out/bench_$TAG.json gpurun_out/profiles_$TAG/${TAG}_bench_line.json 2>/dev/null
+cp gpurun_out/*_$TAG.log gpurun_out/profiles_$TAG/ 2>/dev/null
+rm -rf gpurun_out/pmc2_* gpurun_out/prof_* gpurun_out/eo_* gpurun_out/kt_* gpurun_out/kto   # raw traces stay on the box (64 MiB limit)
 ls -la gpurun_out/profiles_$TAG
 tail -3 gpurun_out/summarize_round_$TAG.log
