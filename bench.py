@@ -232,15 +232,15 @@ def engine_rates(dev, quick):
     return out, roof
 
 
-def cpu_engine_baseline(budget_s=25.0):
-    """cc_mult(+relinearize) at silver on the host cores: this package's orchestration over the CHECKER backend
+def cpu_engine_baseline(preset="silver", budget_s=25.0, max_reps=10):
+    """cc_mult(+relinearize) of a preset on the host cores: this package's orchestration over the CHECKER backend
     (tests/oracle_backend.py: the reference's composition of ntt_cuda calls, each call the C oracle with OpenMP
     over limb rows, torch elementwise ops in between — what the reference engine would do if its extension were
     a CPU library).  Bounded sample: as many ops as fit the budget, at least one."""
     from liberate_fhe_amd.fhe import ckks_engine, presets
     from liberate_fhe_amd.utils import synth
     from tests.oracle_backend import OracleBackend
-    params = {k: v for k, v in presets.params["silver"].items() if k != "devices"}
+    params = {k: v for k, v in presets.params[preset].items() if k != "devices"}
     eng = ckks_engine(devices=["cpu"], backend=OracleBackend(), **params)
     a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
     evk = synth.key_switch_key(eng, 5)
@@ -249,11 +249,11 @@ def cpu_engine_baseline(budget_s=25.0):
     while True:
         eng.cc_mult(a, b, evk)
         reps += 1
-        if time.time() - t0 > budget_s or reps >= 10:
+        if time.time() - t0 > budget_s or reps >= max_reps:
             break
     dt = (time.time() - t0) / reps
-    return {"value": 1.0 / dt, "unit": "cc_mult_evk(silver)/s", "cores": os.cpu_count() or 1, "kind": "port",
-            "sample": f"{reps} x cc_mult+relinearize, silver (logN 15, level 0 -> 1), checker backend (C oracle + OpenMP, "
+    return {"value": 1.0 / dt, "unit": f"cc_mult_evk({preset})/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "sample": f"{reps} x cc_mult+relinearize, {preset} (logN {eng.ctx.logN}, level 0 -> 1), checker backend (C oracle + OpenMP, "
                       f"reference-shaped orchestration), after one warm-up op"}
 
 
@@ -587,10 +587,11 @@ def main():
         extra.update(rates)
         result["roofline_engine_ops"] = roof     # cc_mult_evk / rotate_single: the metric's second half, per preset
         result["cpu_baseline"] = cpu_baseline(ctx, rows_idx, batch=min(B, 16))   # bounded sample of the same workload
-        try:
-            result["cpu_baseline"]["cc_mult_evk_silver"] = cpu_engine_baseline()
-        except Exception as e:
-            result["cpu_baseline"]["cc_mult_evk_silver"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        for preset, budget, reps in (("silver", 20.0, 10), ("bronze", 6.0, 10), ("gold", 15.0, 3)):
+            try:
+                result["cpu_baseline"][f"cc_mult_evk_{preset}"] = cpu_engine_baseline(preset, budget, reps)
+            except Exception as e:
+                result["cpu_baseline"][f"cc_mult_evk_{preset}"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         for preset in ("bronze", "silver", "gold"):     # the oracle transform at every preset's full chain
             try:
                 result["cpu_baseline"][f"ntt_{preset}"] = cpu_ntt_baseline_preset(preset)

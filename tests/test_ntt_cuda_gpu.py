@@ -1,4 +1,6 @@
 """GPU parity of the 15 `ntt_cuda` ops (through the C ABI) against the CPU oracle — bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -477,3 +479,33 @@ def test_relaxed_transforms_require_the_auxiliary_table():
     assert lib.lf_intt(x.data_ptr(), 1, lim.rows, logN, ipsi.data_ptr(), 0, q_host.ctypes.data, Ninv.data_ptr(), 2, 1, q2.data_ptr(), *cp, 0, st) == 10001
     torch.cuda.synchronize()
     assert torch.equal(x, keep)
+
+
+def test_integration_md_binding_snippet_runs():
+    """The binding INTEGRATION.md (path A) shows a reference maintainer — taken from the file, executed as written (only the
+    library path is resolved) — gives what the tested shim gives, on reference-shaped [rows, logN, N/2] twiddle tables."""
+    import re
+    from liberate_fhe_amd import _native
+    from liberate_fhe_amd.ntt import ntt_cuda
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# src/liberate/ntt/ntt_cuda\.py.*?)```", text, re.S).group(1)
+    code = code.replace('ctypes.CDLL("libckks_hip.so")', f'ctypes.CDLL({_native.LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    logN = 12
+    lim = Limbs(logN, pick_primes(logN, 2, 1))
+    N = lim.N
+    from liberate_fhe_amd.fhe.context.ckks_context import stage_butterfly_indices
+    _, _, tw = stage_butterfly_indices(logN, inverse=False)
+    stage = np.ascontiguousarray(lim.mont_tables()[0][:, tw])      # the reference's [rows, logN, N/2] per-stage layout
+    assert stage.shape == (lim.rows, logN, N // 2)
+    c = [dev(v) for v in (lim.ql, lim.qh, lim.kl, lim.kh)]
+    a, b = dev(lim.uniform(5, lazy=True)), dev(lim.uniform(6, lazy=True))
+    got = ns["mont_mult"]([a], [b], [c[0]], [c[1]], [c[2]], [c[3]])[0]
+    want = ntt_cuda.mont_mult([a], [b], [c[0]], [c[1]], [c[2]], [c[3]])[0]
+    assert torch.equal(got, want)
+    x1, x2 = a.clone(), a.clone()
+    psi_s, q2 = dev(stage), dev(lim._2q)
+    ns["ntt"]([x1], None, None, [psi_s], [q2], [c[0]], [c[1]], [c[2]], [c[3]])
+    ntt_cuda.ntt([x2], None, None, [psi_s], [q2], [c[0]], [c[1]], [c[2]], [c[3]])
+    assert torch.equal(x1, x2)
