@@ -42,6 +42,10 @@ int lf_cc_mult_evk(const lf_ks_plan *p, const int64_t *const *in, const int64_t 
         return e;
     const int64_t *ss[2] = {p->sum, p->sum + (int64_t)rows * N};
     int64_t *outs[2] = {out0, out1};
+    // ONE special prime (bronze): no elimination among special rows to share, so the single-launch form saves the pivot
+    // launch (bronze cc_mult 98.5-99.4 -> 96.4-97.6 us, rotate 73 -> 71.6; with two primes — silver — it measured no faster)
+    if (p->K == 1)
+        return lf_ks_moddown_batch(ss, outs, nullptr, 2, ell, p->K, N, p->PiR, p->PiP, p->Rs, 0, nullptr, p->ql, p->qh, p->kl, p->kh, dev, stream);
     return lf_ks_moddown_ws(ss, outs, nullptr, 2, ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, 0, nullptr, p->ql,
                             p->qh, p->kl, p->kh, dev, stream);
 }
@@ -62,6 +66,8 @@ int lf_switch_key(const lf_ks_plan *p, const int64_t *c0, const int64_t *c1, int
     const int64_t *ss[2] = {p->sum, p->sum + (int64_t)rows * N};
     int64_t *outs[2] = {out0, out1};
     const int64_t *adds[2] = {c0, nullptr};
+    if (p->K == 1)   // see lf_cc_mult_evk
+        return lf_ks_moddown_batch(ss, outs, adds, 2, ell, p->K, N, p->PiR, p->PiP, p->Rs, gal_pinv, g2q, p->ql, p->qh, p->kl, p->kh, dev, stream);
     return lf_ks_moddown_ws(ss, outs, adds, 2, ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, gal_pinv, g2q, p->ql,
                             p->qh, p->kl, p->kh, dev, stream);
 }
