@@ -133,3 +133,27 @@ def test_unpickler_accepts_what_the_reference_load_accepts(tmp_path):
     for proto in (2, 4, 5):
         back = _PortableUnpickler(io.BytesIO(pickle.dumps(payload, protocol=proto))).load()
         assert (back.data[0] == payload.data[0]).all() and back.data[1] == 1.5 + 2j and torch.equal(back.data[2], payload.data[2])
+
+
+def test_lf_tune_is_a_pure_host_call():
+    """Launch-shape thresholds: read, set, restore, unknown knob -> -1; no device is touched."""
+    from liberate_fhe_amd._native import lib
+    old = lib.lf_tune(0, -1)
+    assert old > 0
+    assert lib.lf_tune(0, 123) == old and lib.lf_tune(0, -1) == 123
+    lib.lf_tune(0, old)
+    cols = lib.lf_tune(1, -1)
+    assert 0 <= cols <= 4
+    assert lib.lf_tune(1, 9) == cols and lib.lf_tune(1, -1) == cols      # out of range: ignored
+    assert lib.lf_tune(77, 1) == -1
+
+
+def test_bench_refuses_more_ranks_than_gpus_without_touching_one():
+    """`python bench.py --gpus N` with no launcher around it starts its own ranks — after counting the GPUs WITHOUT
+    initialising one; on a box with fewer than N it says so and exits 2 (no rank is started, nothing hangs)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LF_BENCH_REHEARSE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "GPU(s)" in r.stderr and r.stdout.strip() == ""
