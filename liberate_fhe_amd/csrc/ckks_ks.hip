@@ -33,6 +33,13 @@
 
 #define KS_WORDS ((1 << NTT_TILE_LOG_MAX) / NTT_THREADS)   // tile words owned by one thread (8)
 
+// streaming stores of the extension kernels (ckks_ntt_core.h: "Streaming accesses")
+#define KS_ST(p, v)                                                  \
+    do {                                                             \
+        if (NT_KS_EXT) __builtin_nontemporal_store((i64)(v), p);     \
+        else *(p) = (v);                                             \
+    } while (0)
+
 namespace {
 
 struct KsGeom {
@@ -288,7 +295,7 @@ __device__ __forceinline__ void ks_ext_cols_body(int b, const i64 *__restrict__ 
         }
         cols_fwd_stages<ArithDpR, K>(x, c);          // |x| < alpha * q on the way in (balanced terms)
 #pragma unroll
-        for (int k = 0; k < R; ++k) uniform_row(dst, (i64)k << logC)[lane] = dp_to_word(dp_reduce(x[k], c.d.q, c.d.qinv));
+        for (int k = 0; k < R; ++k) KS_ST(uniform_row(dst, (i64)k << logC) + lane, dp_to_word(dp_reduce(x[k], c.d.q, c.d.qinv)));
     } else {
         i64 w[R];
         if (wide && alpha > 1) {   // several 60-bit limbs in one digit (no preset has that): term by term
@@ -325,7 +332,7 @@ __device__ __forceinline__ void ks_ext_cols_body(int b, const i64 *__restrict__ 
         for (int k = 0; k < R; ++k) w[k] = w[k] < 0 ? w[k] + c.m.q2 : w[k];   // residues only: fold into [0, 2q)
         cols_fwd_stages<ArithShoup, K>(w, c);
 #pragma unroll
-        for (int k = 0; k < R; ++k) dst[((i64)k << logC) + lane] = ArithShoup::canon(c, w[k]);
+        for (int k = 0; k < R; ++k) KS_ST(dst + ((i64)k << logC) + lane, ArithShoup::canon(c, w[k]));
     }
 }
 

@@ -1072,6 +1072,60 @@ __device__ __forceinline__ i64 *uniform_row(i64 *base, i64 off) {
     return p;
 }
 
+// Streaming accesses (the `nt` bit of global loads / stores): words a pass reads once and writes once should not displace
+// the twiddle rows — as many bytes per tile as the data, re-read by every polynomial of the batch — from L1 / L2.
+// In-process A/B on the headline step (tools/ab_inproc.py, -DLF_NT_OFF build beside this one): whole step -2.8 %, tiled pass
+// -2.3 %, column pass -2.0 %.  Exact transforms (the standalone lf_ntt / lf_intt of large batches) stream everything.
+// Relaxed ones are the engine's internal passes, where the NEXT kernel may still find a pass's output in cache: loads of the
+// tiled pass, the extension kernel's stores and the inverse passes stream (gold rotate -1 %, silver -3 %); the tiled pass's
+// STORES do not (streamed, the inner product that reads them next went 102 -> 118 us at gold), nor the column pass of
+// cc_mult's opening, the inner product's digit loads or its sums.
+typedef long long ll2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ longlong2 nt_load2(const i64 *p) {
+    const ll2_t v = __builtin_nontemporal_load(reinterpret_cast<const ll2_t *>(p));
+    longlong2 r;
+    r.x = v.x, r.y = v.y;
+    return r;
+}
+__device__ __forceinline__ void nt_store2(i64 *p, const longlong2 &v) {
+    ll2_t t;
+    t.x = v.x, t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<ll2_t *>(p));
+}
+#ifdef LF_NT_OFF   // A/B builds only
+#define NT_EXACT false
+#define NT_RLOAD false
+#define NT_INV false
+#define NT_KS_EXT false
+#else
+#define NT_EXACT true
+#define NT_RLOAD true
+#define NT_INV true
+#define NT_KS_EXT true
+#endif
+#define NT_RSTORE false
+#define NT_RCOLS false
+// (nt: wave-uniform)
+#define COLS_LD_ALL(dst, ptr)                                                            \
+    if (nt) {                                                                            \
+        _Pragma("unroll") for (int k = 0; k < R; ++k) dst[k] = __builtin_nontemporal_load(ptr); \
+    } else {                                                                             \
+        _Pragma("unroll") for (int k = 0; k < R; ++k) dst[k] = *(ptr);                   \
+    }
+#define COLS_ST_ALL(ptr, val)                                                            \
+    if (nt) {                                                                            \
+        _Pragma("unroll") for (int k = 0; k < R; ++k) __builtin_nontemporal_store((i64)(val), ptr); \
+    } else {                                                                             \
+        _Pragma("unroll") for (int k = 0; k < R; ++k) *(ptr) = (val);                    \
+    }
+#define INV_LD(p) (NT_INV ? __builtin_nontemporal_load(p) : *(p))
+#define INV_LD2(p) (NT_INV ? nt_load2(p) : *reinterpret_cast<const longlong2 *>(p))
+#define INV_ST(p, v)                                              \
+    do {                                                          \
+        if (NT_INV) __builtin_nontemporal_store((i64)(v), p);     \
+        else *(p) = (v);                                          \
+    } while (0)
+
 template <class A, int K>
 __device__ __forceinline__ void cols_fwd_stages(typename A::T (&x)[1 << K], const Ctx &c) {
 #pragma unroll
@@ -1125,6 +1179,7 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
     // addresses in VGPRs from the loads to the stores)
     i64 *colu = a + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS;
     const unsigned lane = threadIdx.x;
+    const bool nt = g.relaxed ? NT_RCOLS : NT_EXACT;
 
     if (RS && DP && g.relaxed) {
         // relaxed fp64 class (cc_mult's opening): only residues matter, so the rescale itself runs in fp64 — one balanced
@@ -1146,8 +1201,7 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
             x[k] = v;
         }
         cols_fwd_stages<ArithDpR, K>(x, c);
-#pragma unroll
-        for (int k = 0; k < R; ++k) uniform_row(colu, (i64)k << logC)[lane] = dp_to_word(dp_reduce(x[k], c.d.q, c.d.qinv));
+        COLS_ST_ALL(uniform_row(colu, (i64)k << logC) + lane, dp_to_word(dp_reduce(x[k], c.d.q, c.d.qinv)))
         return;
     }
     i64 w[R];
@@ -1163,8 +1217,7 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
             w[k] = v < qq ? v : v - qq;
         }
     } else {
-#pragma unroll
-        for (int k = 0; k < R; ++k) w[k] = uniform_row(colu, (i64)k << logC)[lane];
+        COLS_LD_ALL(w, uniform_row(colu, (i64)k << logC) + lane)
     }
     int odd = 0;
 #pragma unroll
@@ -1188,8 +1241,7 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
         if (g.relaxed) cols_fwd_stages<ArithDpR, K>(x, c);
         else cols_fwd_stages<ArithDp, K>(x, c);
         const double md = g.relaxed ? c.d.q : c.d.q2, mi = g.relaxed ? c.d.qinv : c.d.q2inv;
-#pragma unroll
-        for (int k = 0; k < R; ++k) uniform_row(colu, (i64)k << logC)[lane] = dp_to_word(dp_reduce(x[k], md, mi));
+        COLS_ST_ALL(uniform_row(colu, (i64)k << logC) + lane, dp_to_word(dp_reduce(x[k], md, mi)))
     } else {
         // integer class, or a lane of the fp64 class holding signed-lazy words
         if (enter) {
@@ -1202,14 +1254,12 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
         if (!DP && g.relaxed) {
             // residues only: Shoup products on lazy words (the fold / the entry left them in [0, 2q)), canonical out
             cols_fwd_stages<ArithShoup, K>(w, c);
-#pragma unroll
-            for (int k = 0; k < R; ++k) uniform_row(colu, (i64)k << logC)[lane] = ArithShoup::canon(c, w[k]);
+            COLS_ST_ALL(uniform_row(colu, (i64)k << logC) + lane, ArithShoup::canon(c, w[k]))
             return;
         }
         if (odd || DP) cols_fwd_stages<ArithInt<true>, K>(w, c);
         else cols_fwd_stages<ArithInt<false>, K>(w, c);
-#pragma unroll
-        for (int k = 0; k < R; ++k) uniform_row(colu, (i64)k << logC)[lane] = w[k];
+        COLS_ST_ALL(uniform_row(colu, (i64)k << logC) + lane, w[k])
     }
 }
 
@@ -1430,7 +1480,7 @@ __device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const 
 
     i64 w[R];
 #pragma unroll
-    for (int k = 0; k < R; ++k) w[k] = uniform_row(colu, (i64)k << logC)[lane];
+    for (int k = 0; k < R; ++k) w[k] = INV_LD(uniform_row(colu, (i64)k << logC) + lane);
     int odd = 0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -1462,20 +1512,20 @@ __device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const 
                 if (dp_below_fix_limit(z)) z = dp_lazy_fix(z, (u64)tr, (u64)ninv_mont, c.d.q);
                 if (tail == 1) z = (z == c.d.q) ? c.d.q : dp_mulmod(z, rinv, c.d);   // redc(q) = q (K.cu:587-606)
             }
-            uniform_row(colu, (i64)k << logC)[lane] = (tail >= 3) ? (i64)z : dp_to_word(z);
+            INV_ST(uniform_row(colu, (i64)k << logC) + lane, (tail >= 3) ? (i64)z : dp_to_word(z));
         }
     } else {
         if (!DP && g.relaxed) {   // residues only (the words are canonical: this library's relaxed tiled pass wrote them)
             cols_inv_stages<ArithShoup, K>(w, c);
 #pragma unroll
             for (int k = 0; k < R; ++k)
-                uniform_row(colu, (i64)k << logC)[lane] = inv_tail_int(ArithShoup::canon(c, w[k]), tail, ninv_mont, c);
+                INV_ST(uniform_row(colu, (i64)k << logC) + lane, inv_tail_int(ArithShoup::canon(c, w[k]), tail, ninv_mont, c));
             return;
         }
         if (odd || DP) cols_inv_stages<ArithInt<true>, K>(w, c);
         else cols_inv_stages<ArithInt<false>, K>(w, c);
 #pragma unroll
-        for (int k = 0; k < R; ++k) uniform_row(colu, (i64)k << logC)[lane] = inv_tail_int(w[k], tail, ninv_mont, c);
+        for (int k = 0; k < R; ++k) INV_ST(uniform_row(colu, (i64)k << logC) + lane, inv_tail_int(w[k], tail, ninv_mont, c));
     }
 }
 

@@ -277,9 +277,13 @@ __device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int t
     const int w = lf_tid();
     const int base = tile << 12, E = g.logN, s = g.s0;
     constexpr bool CHECK = !RLX;   // relaxed tiles take the canonical words the library's own first pass wrote
+    constexpr bool NTL = RLX ? NT_RLOAD : NT_EXACT, NTS = RLX ? NT_RSTORE : NT_EXACT;   // streaming accesses, ckks_ntt_core.h
     i64 raw[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) raw[e] = uniform_row(row + base, e << 8)[(unsigned)w];   // SGPR row pointers + lane index
+    for (int e = 0; e < 16; ++e) {   // SGPR row pointers + lane index
+        if constexpr (NTL) raw[e] = __builtin_nontemporal_load(uniform_row(row + base, e << 8) + (unsigned)w);
+        else raw[e] = uniform_row(row + base, e << 8)[(unsigned)w];
+    }
     if (CHECK) {
         int odd = 0;
 #pragma unroll
@@ -326,7 +330,8 @@ __device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int t
         longlong2 v;
         v.x = so[i * 136];
         v.y = so[i * 136 + 1];
-        *reinterpret_cast<longlong2 *>(row + base + L0 + (i << 7)) = v;
+        if constexpr (NTS) nt_store2(row + base + L0 + (i << 7), v);
+        else *reinterpret_cast<longlong2 *>(row + base + L0 + (i << 7)) = v;
     }
 }
 
@@ -381,11 +386,11 @@ __device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst
     {
         longlong2 in[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) in[i] = *reinterpret_cast<const longlong2 *>(src_row + base + L0 + (i << 7));
+        for (int i = 0; i < 8; ++i) in[i] = INV_LD2(src_row + base + L0 + (i << 7));
         if (MUL) {
             longlong2 mb[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) mb[i] = *reinterpret_cast<const longlong2 *>(mul_row + base + L0 + (i << 7));
+            for (int i = 0; i < 8; ++i) mb[i] = INV_LD2(mul_row + base + L0 + (i << 7));
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 if (DP) {
@@ -426,17 +431,17 @@ __device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst
         ok = inv_tile16_steps<AD, true, RLX>(reinterpret_cast<double *>(sm), sm, x, w, base, logN, s, cc, CHECK);
         if (ok) {   // exact: the lazy word in [0, 2q); relaxed: balanced residue -> canonical
 #pragma unroll
-            for (int e = 0; e < 16; ++e) uniform_row(out, e << 8)[(unsigned)w] = dp_to_word(RLX ? dp_addmask(x[e], c.d.q) : x[e]);
+            for (int e = 0; e < 16; ++e) INV_ST(uniform_row(out, e << 8) + (unsigned)w, dp_to_word(RLX ? dp_addmask(x[e], c.d.q) : x[e]));
         }
     } else if (RLX) {
         ok = inv_tile16_steps<ArithShoup, false, true>(sm, sm, raw, w, base, logN, s, cc, false);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) uniform_row(out, e << 8)[(unsigned)w] = ArithShoup::canon(c, raw[e]);
+        for (int e = 0; e < 16; ++e) INV_ST(uniform_row(out, e << 8) + (unsigned)w, ArithShoup::canon(c, raw[e]));
     } else {
         ok = inv_tile16_steps<ArithInt<false>, false, RLX>(sm, sm, raw, w, base, logN, s, cc, true);
         if (ok) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) uniform_row(out, e << 8)[(unsigned)w] = raw[e];
+            for (int e = 0; e < 16; ++e) INV_ST(uniform_row(out, e << 8) + (unsigned)w, raw[e]);
         }
     }
     if (!ok) {
