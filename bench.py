@@ -512,6 +512,47 @@ def main():
     one_pass(1)
     torch.cuda.synchronize()
     cols_ms = event_time_ms(lambda: one_pass(1), n_roof)
+    # Shader clock and package power WHILE the kernels run: a one-wave probe (lf_clock_probe) on a second stream counts core
+    # cycles per tick of the constant 100 MHz counter; the SMI is read once in the middle of a ~1.5 s run of tiled passes.
+    # (MI355X caps the package at 1 400 W; the headline kernels sit at the cap and the clock is what gives)
+    def clock_under(work, launches):
+        try:
+            probe_out = torch.zeros(2 * 24, dtype=torch.int64, device=dev)
+            side = torch.cuda.Stream(device=dev)
+            torch.cuda.synchronize()
+            for _ in range(max(1, launches // 4)):
+                work()
+            check(lib.lf_clock_probe(probe_out.data_ptr(), 24, 100_000, local_rank, side.cuda_stream), "lf_clock_probe")
+            for _ in range(launches):
+                work()
+            torch.cuda.synchronize()
+            o = probe_out.cpu().numpy().reshape(24, 2).astype(np.float64)
+            return float(np.median(o[:, 0] / o[:, 1] * 100.0))
+        except Exception:
+            return None
+
+    def package_power_under(work, launches):
+        import re, subprocess
+        try:
+            torch.cuda.synchronize()
+            for _ in range(launches):                      # enqueue only: the device works through them while the SMI is read
+                work()
+            time.sleep(0.5)
+            txt = subprocess.run(["rocm-smi", "--showpower", "--showmaxpower"], capture_output=True, text=True, timeout=30).stdout
+            torch.cuda.synchronize()
+            cur = re.search(r"Current Socket Graphics Package Power \(W\): ([0-9.]+)", txt)
+            cap = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)", txt)
+            return (float(cur.group(1)) if cur else None), (float(cap.group(1)) if cap else None)
+        except Exception:
+            torch.cuda.synchronize()
+            return None, None
+
+    clocks = power = None
+    if rank == 0 and world == 1:
+        clocks = {"idle": clock_under(lambda: None, 0), "tiled_pass": clock_under(lambda: one_pass(2), 40),
+                  "column_pass": clock_under(lambda: one_pass(1), 60), "whole_transform": clock_under(step, 25)}
+        pw, cap = package_power_under(lambda: one_pass(2), 1500)
+        power = {"tiled_pass_package_W": pw, "package_cap_W": cap, "source": "rocm-smi --showpower, read while 1 500 tiled passes run"}
     alg_bytes_per_launch = 8 * N * L_LIMBS * B                      # 16*N per limb per transform, two launches
     achieved = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
     traffic = valu = valu_busy = cols_traffic = None
@@ -548,6 +589,9 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes_per_launch,
                      "whole_step_algorithmic_GBps": 16 * N * L_LIMBS * B / (dev_ms * 1e-3) / 1e9,
                      "column_pass_traffic": cols_traffic,
+                     # measured while the kernels run (lf_clock_probe on a second stream; idle = 2 400): the package sits at its
+                     # power cap under both passes and the shader clock is what gives — `frac` is reached at THAT clock
+                     "shader_clock_mhz": clocks, "package_power": power,
                      # what actually bounds the kernel: VALU issue.  PMC pass of profiles/r02_bench_pmc.txt: wave-level
                      # VALU instructions per launch (scaled to the batch) and the fraction of cycles the SIMDs' VALU is
                      # busy (SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs over SQ_BUSY_CU_CYCLES / 256 CUs) — a utilisation,

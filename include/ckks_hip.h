@@ -34,7 +34,7 @@ extern "C" {
 
 #define LF_ERR_ARG 10001
 
-/* Library probe: returns the ABI version (currently 8; __graft_entry__.build() asserts it). */
+/* Library probe: returns the ABI version (currently 9; __graft_entry__.build() asserts it). */
 int lf_abi_version(void);
 
 /* Compile-time capacities of the fused kernels, so that callers can refuse a parameter set BEFORE any launch
@@ -59,6 +59,13 @@ int lf_limits(int which);
  *                             column kernel (one register step per column, no LDS); above it the LDS-tiled form. */
 #define LF_TUNE_KS_EXT_COLS_MAX 1
 int lf_tune(int which, int value);
+
+/* Measurement entry (not one of the reference's ops; the engine never calls it): ONE wave, launched on `stream`, takes
+ * `samples` readings of the shader clock — out[2 i] = core-clock cycles (s_memtime) that passed during out[2 i + 1] ticks
+ * (>= `ticks`) of the constant 100 MHz counter (s_memrealtime), so MHz = 100 * out[2 i] / out[2 i + 1].  Launched on a
+ * second stream beside a kernel under test it reports the clock that kernel actually runs at (bench.py: the headline
+ * kernels run with the package at its 1 400 W cap).  out: device, 2 * samples 64-bit words. */
+int lf_clock_probe(uint64_t *out, int samples, uint64_t ticks, int device, void *stream);
 
 /* ---- elementwise family --------------------------------------------------------------------- */
 

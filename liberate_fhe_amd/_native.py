@@ -29,6 +29,7 @@ _SIGNATURES = {
     "lf_abi_version": [],
     "lf_limits": [_I],
     "lf_tune": [_I, _I],
+    "lf_clock_probe": [_P, _I, _U, _I, _P],
     "lf_ntt_pass": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
     "lf_mont_mult": [_P, _P, _P, _I, _L, _P, _P, _P, _P, _I, _P],
     "lf_mont_enter": [_P, _P, _I, _L, _P, _P, _P, _P, _I, _P],

@@ -102,6 +102,19 @@ __global__ void __launch_bounds__(256) galois_kernel(GaloisBatch gb, int logN, i
     dst[((i64)row << logN) + (i64)(pn & (u64)(N - 1))] = v;
 }
 
+// one wave: core-clock cycles per stretch of >= `ticks` ticks of the constant 100 MHz counter (lf_clock_probe)
+__global__ void clock_probe_kernel(unsigned long long *out, int samples, unsigned long long ticks) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < samples; ++i) {
+        const unsigned long long r0 = wall_clock64(), c0 = clock64();
+        unsigned long long r1 = r0;
+        while (r1 - r0 < ticks) r1 = wall_clock64();
+        const unsigned long long c1 = clock64();
+        out[2 * i] = c1 - c0;
+        out[2 * i + 1] = r1 - r0;
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -109,7 +122,15 @@ __global__ void __launch_bounds__(256) galois_kernel(GaloisBatch gb, int logN, i
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int lf_abi_version(void) { return 8; }
+int lf_abi_version(void) { return 9; }
+
+int lf_clock_probe(uint64_t *out, int samples, uint64_t ticks, int device, void *stream) {
+    if (!out || samples < 1 || samples > 4096 || ticks < 1 || ticks > 100000000ull) return LF_ERR_ARG;
+    if (int e = lf_set_device(device)) return e;
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long *)out, samples,
+                       (unsigned long long)ticks);
+    return (int)hipGetLastError();
+}
 
 // capacities compiled into the kernels (ckks_common.h)
 int lf_limits(int which) {

@@ -20,7 +20,7 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(so, n), f"{n} declared in include/ckks_hip.h but not exported"
     assert sorted(_native.EXPORTED) == names, "python binding table out of sync with the header"
-    assert _native.lib.lf_abi_version() == 8     # pure host call, no HIP runtime use
+    assert _native.lib.lf_abi_version() == 9     # pure host call, no HIP runtime use
 
 
 def test_shim_exposes_the_fifteen_reference_functions():
@@ -146,6 +146,14 @@ def test_lf_tune_is_a_pure_host_call():
     assert 0 <= cols <= 4
     assert lib.lf_tune(1, 9) == cols and lib.lf_tune(1, -1) == cols      # out of range: ignored
     assert lib.lf_tune(77, 1) == -1
+
+
+def test_clock_probe_checks_its_arguments_on_the_host():
+    """lf_clock_probe (measurement entry): bad arguments are refused before any HIP call."""
+    from liberate_fhe_amd._native import lib
+    assert lib.lf_clock_probe(None, 4, 1000, 0, None) != 0
+    assert lib.lf_clock_probe(8, 0, 1000, 0, None) != 0
+    assert lib.lf_clock_probe(8, 4, 0, 0, None) != 0
 
 
 def test_bench_refuses_more_ranks_than_gpus_without_touching_one():

@@ -509,3 +509,17 @@ def test_integration_md_binding_snippet_runs():
     ns["ntt"]([x1], None, None, [psi_s], [q2], [c[0]], [c[1]], [c[2]], [c[3]])
     ntt_cuda.ntt([x2], None, None, [psi_s], [q2], [c[0]], [c[1]], [c[2]], [c[3]])
     assert torch.equal(x1, x2)
+
+
+@pytest.mark.gpu
+def test_clock_probe_reports_a_plausible_shader_clock():
+    """lf_clock_probe (measurement entry of the C ABI): cycles per 100 MHz tick on an idle device -> 0.5 .. 3.5 GHz."""
+    import torch
+    from liberate_fhe_amd._native import lib, check
+    out = torch.zeros(2 * 4, dtype=torch.int64, device="cuda:0")
+    check(lib.lf_clock_probe(out.data_ptr(), 4, 20_000, 0, torch.cuda.current_stream().cuda_stream), "lf_clock_probe")
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().reshape(4, 2)
+    assert (o[:, 1] >= 20_000).all()
+    mhz = o[:, 0] / o[:, 1] * 100.0
+    assert ((mhz > 500) & (mhz < 3500)).all(), mhz

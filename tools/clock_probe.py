@@ -1,21 +1,14 @@
 """Shader clock while the headline kernels run (development aid):  python tools/clock_probe.py
-A one-wave kernel on a second stream (tools/ubench/clock_probe.hip, built in-tree by this script) counts core-clock
-cycles per tick of the constant 100 MHz counter while the main stream runs (a) nothing, (b) the tiled pass, (c) the
-column pass, (d) whole transforms, back to back."""
-import ctypes, os, subprocess, sys, warnings
+A one-wave kernel on a second stream (lf_clock_probe, include/ckks_hip.h) counts core-clock cycles per tick of the
+constant 100 MHz counter while the main stream runs (a) nothing, (b) the tiled pass, (c) the column pass, (d) whole
+transforms, back to back.  LF_HIP_LIB=<variant .so> probes another build (tools/mkvariant.sh)."""
+import os, sys, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 warnings.filterwarnings("ignore")
 import numpy as np
 import torch
 import __graft_entry__ as g
 g.build()
-here = os.path.dirname(os.path.abspath(__file__))
-so = os.path.join(here, "ubench", "libclock_probe.so")
-if not os.path.exists(so):
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", so,
-                           os.path.join(here, "ubench", "clock_probe.hip")])
-probe = ctypes.CDLL(so)
-probe.clock_probe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p]
 from liberate_fhe_amd._native import lib, check
 from liberate_fhe_amd.ntt import twiddles, ntt_context
 from liberate_fhe_amd.fhe.context.ckks_context import ckks_context
@@ -54,7 +47,7 @@ def measure(name, work, launches):
     torch.cuda.synchronize()
     for _ in range(launches // 4):          # the main stream is busy before the probe starts
         work()
-    probe.clock_probe(out.data_ptr(), SAMPLES, TICKS, side.cuda_stream)
+    check(lib.lf_clock_probe(out.data_ptr(), SAMPLES, TICKS, 0, side.cuda_stream), "lf_clock_probe")
     for _ in range(launches):
         work()
     torch.cuda.synchronize()
