@@ -12,7 +12,7 @@ tiled pass is 10 block rounds instead of 80).  Inputs are synthetic (splitmix64 
 Polynomials are independent, so ranks shard them with no data-path collective: weak scaling.
 
 The JSON line also carries
-  roofline     : the dominant kernel (ntt_pass16_mixed: the tiled pass of all 30 limbs, the second of the two
+  roofline     : the dominant kernel (ntt_pass16_fwd_seq: the tiled pass of all 30 limbs, the second of the two
                  launches of a transform, 12 of its 16 stages) against the 8 TB/s HBM peak; algorithmic bytes
                  per launch = 8*N*limbs (a transform is 16*N bytes per limb, SURVEY.md §8d, spread over its two
                  launches); its launch duration is measured live with HIP events on the launch stream, the
@@ -495,7 +495,7 @@ def main():
 
     value = world * B / (wall / args.steps)                         # poly-NTT(30)/s, whole job
 
-    # Roofline of the dominant kernel, ntt_pass16_mixed: the tiled pass (12 of the 16 stages) of all 30 limbs,
+    # Roofline of the dominant kernel, ntt_pass16_fwd_seq: the tiled pass (12 of the 16 stages) of all 30 limbs,
     # integer-class blocks first, then the fp64 class.  In the step above it follows the column pass, so it is
     # timed on its own here: lf_ntt_pass(which = 2), the library's measurement entry, launches exactly that kernel,
     # once, with the grid it has inside the full step.  (x is scratch afterwards.)
@@ -582,7 +582,7 @@ def main():
         # utilisation of the pipe that actually limits it (PMC; null when the counters were not taken on this build)
         "roofline": {"bound": "valu_issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "issue_frac": valu_busy, "traffic": traffic,
-                     "kernel": "ntt_pass16_mixed<false,false> (tiled pass = 12 of 16 stages, 16 words per thread, all 30 limbs: 5 integer-class + 25 fp64-class)",
+                     "kernel": "ntt_pass16_fwd_seq<false> (tiled pass = 12 of 16 stages, 16 words per thread, 8 tiles per block, all 30 limbs: 5 integer-class + 25 fp64-class)",
                      "launches_per_transform": 2, "avg_launch_ms": k_ms, "launches_timed": n_roof,
                      "column_pass_launch_ms": cols_ms,
                      "column_pass_algorithmic_GBps": alg_bytes_per_launch / (cols_ms * 1e-3) / 1e9,

@@ -52,14 +52,25 @@ struct Tw16Early {
 };
 
 // forward: stage u of the step uses the 2^u table entries (i0 << u) .. (cf. fwd_step)
+// the 8 twiddles of a step's last stage, held by the caller (several tiles per block, ntt_pass16_fwd_seq)
 template <class A>
-__device__ __forceinline__ void fwd_regs16(typename A::T (&x)[16], int i0, const Ctx &c, const Tw16Early<A> *early = nullptr) {
+struct Tw16Last {
+    typename A::W w8[8];
+    __device__ __forceinline__ void load(const Ctx &c, int i) { A::tw_group(c, i << 3, 8, w8); }
+};
+
+template <class A>
+__device__ __forceinline__ void fwd_regs16(typename A::T (&x)[16], int i0, const Ctx &c, const Tw16Early<A> *early = nullptr,
+                                           const Tw16Last<A> *last = nullptr) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int du = 1 << (3 - u);
         typename A::W wv[8];
         if (early && u < 3) early->get(1 << u, wv);
-        else A::tw_group(c, i0 << u, 1 << u, wv);
+        else if (last && u == 3) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = last->w8[j];
+        } else A::tw_group(c, i0 << u, 1 << u, wv);
 #pragma unroll
         for (int j = 0; j < (1 << u); ++j) {
             const int e0 = j << (4 - u);
@@ -71,13 +82,17 @@ __device__ __forceinline__ void fwd_regs16(typename A::T (&x)[16], int i0, const
 }
 
 // exact fp64 class (ArithDp semantics, bit for bit): products of a stage first, one uniform test, then add / sub
-__device__ __forceinline__ void fwd_regs16_exact(double (&x)[16], int i0, const Ctx &c, const Tw16Early<ArithDp> *early = nullptr) {
+__device__ __forceinline__ void fwd_regs16_exact(double (&x)[16], int i0, const Ctx &c, const Tw16Early<ArithDp> *early = nullptr,
+                                                 const Tw16Last<ArithDp> *last = nullptr) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int du = 1 << (3 - u);
         double wv[8];
         if (early && u < 3) early->get(1 << u, wv);
-        else ArithDp::tw_group(c, i0 << u, 1 << u, wv);
+        else if (last && u == 3) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = last->w8[j];
+        } else ArithDp::tw_group(c, i0 << u, 1 << u, wv);
         double V[8];
 #pragma unroll
         for (int j = 0; j < (1 << u); ++j) {
@@ -222,9 +237,10 @@ template <> struct DpArith<true> { typedef ArithDpR type; };
 
 // one radix-16 step of arithmetic class A in mode RLX (the exact fp64 class has its own stage-wise routine)
 template <class A, bool EXACT_DP>
-__device__ __forceinline__ void fwd_step16(typename A::T (&x)[16], int i0, const Ctx &c, const Tw16Early<A> *early) {
-    if constexpr (EXACT_DP) fwd_regs16_exact(x, i0, c, early);
-    else fwd_regs16<A>(x, i0, c, early);
+__device__ __forceinline__ void fwd_step16(typename A::T (&x)[16], int i0, const Ctx &c, const Tw16Early<A> *early,
+                                           const Tw16Last<A> *last = nullptr) {
+    if constexpr (EXACT_DP) fwd_regs16_exact(x, i0, c, early, last);
+    else fwd_regs16<A>(x, i0, c, early, last);
 }
 template <class A, bool EXACT_DP>
 __device__ __forceinline__ void inv_step16(typename A::T (&x)[16], int il, const Ctx &c, const Tw16Early<A> *early) {
@@ -237,7 +253,7 @@ __device__ __forceinline__ void inv_step16(typename A::T (&x)[16], int il, const
 // three stages are requested before the barrier that ends the current one.
 template <class A, bool DP, bool RLX>
 __device__ __forceinline__ bool fwd_tile16_steps(typename A::T *smt, const i64 *sm, typename A::T (&x)[16], int w, int base,
-                                                 int E, int s, const Ctx &c, bool check) {
+                                                 int E, int s, const Ctx &c, bool check, const Tw16Last<A> *lastC = nullptr) {
     constexpr bool EX = DP && !RLX;
     const int iA = (1 << s) + (base >> (E - s));                 // tile-uniform
     const int pB = ((w >> 4) << 8) | (w & 15);
@@ -268,12 +284,19 @@ __device__ __forceinline__ bool fwd_tile16_steps(typename A::T *smt, const i64 *
 #pragma unroll
         for (int e = 0; e < 16; ++e) x[e] = sp[e];
     }
-    fwd_step16<A, EX>(x, iC, c, &twC);
+    fwd_step16<A, EX>(x, iC, c, &twC, lastC);
     return true;
 }
 
+// arithmetic class of a forward tile
+template <bool DP, bool RLX> struct FwdArith { typedef ArithInt<false> type; };
+template <> struct FwdArith<true, false> { typedef ArithDp type; };
+template <> struct FwdArith<true, true> { typedef ArithDpR type; };
+template <> struct FwdArith<false, true> { typedef ArithShoup type; };
+
 template <bool DP, bool RLX>
-__device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int tile, const PassGeom &g, const Ctx &c) {
+__device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int tile, const PassGeom &g, const Ctx &c,
+                                           const Tw16Last<typename FwdArith<DP, RLX>::type> *lastC = nullptr) {
     const int w = lf_tid();
     const int base = tile << 12, E = g.logN, s = g.s0;
     constexpr bool CHECK = !RLX;   // relaxed tiles take the canonical words the library's own first pass wrote
@@ -292,22 +315,22 @@ __device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int t
     }
     i64 o[16];
     bool ok;
-    if (DP) {
+    if constexpr (DP) {
         typedef typename DpArith<RLX>::type AD;
         double x[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) x[e] = RLX ? dp_from_signed(raw[e]) : dp_from_word(raw[e]);
-        ok = fwd_tile16_steps<AD, true, RLX>(reinterpret_cast<double *>(sm), sm, x, w, base, E, s, c, CHECK);
+        ok = fwd_tile16_steps<AD, true, RLX>(reinterpret_cast<double *>(sm), sm, x, w, base, E, s, c, CHECK, lastC);
         // the pass accumulated without subtractions: back to the lazy word in [0, 2q) (relaxed: canonical residue)
         const double md = RLX ? c.d.q : c.d.q2, mi = RLX ? c.d.qinv : c.d.q2inv;
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[e] = dp_to_word(dp_reduce(x[e], md, mi));
-    } else if (RLX) {   // residues only: Shoup products on lazy words (ArithShoup), canonical on the way out
-        ok = fwd_tile16_steps<ArithShoup, false, true>(sm, sm, raw, w, base, E, s, c, false);
+    } else if constexpr (RLX) {   // residues only: Shoup products on lazy words (ArithShoup), canonical on the way out
+        ok = fwd_tile16_steps<ArithShoup, false, true>(sm, sm, raw, w, base, E, s, c, false, lastC);
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[e] = ArithShoup::canon(c, raw[e]);
     } else {
-        ok = fwd_tile16_steps<ArithInt<false>, false, RLX>(sm, sm, raw, w, base, E, s, c, true);
+        ok = fwd_tile16_steps<ArithInt<false>, false, RLX>(sm, sm, raw, w, base, E, s, c, true, lastC);
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[e] = raw[e];
     }
@@ -518,6 +541,81 @@ __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_mul_mixed(const i
     }
 }
 
+// ---- several tiles per block, the last stage's twiddles kept in registers --------------------------------------------
+// Consecutive virtual blocks of one XCD lane (b0, b0 + 8, ..) are the same (limb, tile) pair of consecutive polynomials:
+// the 8 twiddles per thread of the transform's LAST stage — half of all the twiddle bytes a tile reads, and the only group
+// that is requested where it is used — are loaded once per pair and block instead of once per tile.
+struct TileAt {
+    int live, poly, crow, tile;
+};
+// block b of class list rl (live: inside the class's real range); scalar reads only (a vector load here would put a full
+// vmcnt wait — behind the previous tile's stores — at the top of every tile; sub-dword loads exist as vector loads only)
+__device__ __forceinline__ TileAt tile_at(const PassGeom &g, const RowList &rl, int b, bool live) {
+    TileAt t;
+    t.live = 0, t.poly = 0, t.crow = 0, t.tile = 0;
+    if (!live) return t;
+    const int tiles = 1 << (g.logN - g.tl);
+    const int pairs = rl.n * tiles;
+    int pair, poly;
+    if ((pairs & 7) == 0) {
+        const int r = b >> 3;
+        poly = r % g.batch;
+        pair = (r / g.batch) * 8 + (b & 7);
+    } else {
+        pair = b / g.batch;
+        poly = b % g.batch;
+    }
+    pair = __builtin_amdgcn_readfirstlane(pair);
+    t.poly = __builtin_amdgcn_readfirstlane(poly);
+    const int li = pair >> (g.logN - g.tl);
+    t.crow = (int)((reinterpret_cast<const unsigned *>(rl.id)[li >> 1] >> ((li & 1) << 4)) & 0xffffu);
+    t.tile = pair & (tiles - 1);
+    t.live = 1;
+    return t;
+}
+
+template <bool DP, bool RLX>
+__device__ __forceinline__ void seq16_loop(i64 *sm, i64 *dst, const PassGeom &g, const RowList &rl, int b0, int bend, int tpb,
+                                           const i64 *__restrict__ tw_br, const double *__restrict__ tw_dp,
+                                           const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                           const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    typedef typename FwdArith<DP, RLX>::type AC;
+    const int w = lf_tid();
+    Tw16Last<AC> last;
+    int last_crow = -1, last_tile = -1;
+    for (int i = 0; i < tpb; ++i) {
+        const int b = b0 + 8 * i;
+        const TileAt t = tile_at(g, rl, b, b < bend);
+        if (!t.live) break;
+        Ctx c;
+        c.m = load_mod(ql, qh, kl, kh, t.crow);
+        c.tw_mont = tw_br + ((i64)t.crow << g.logN);
+        set_aux<DP>(c, tw_dp, t.crow, g.logN);
+        c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
+        c.relaxed = RLX ? 1 : 0;
+        c.inv_reduce = 0;
+        if (t.crow != last_crow || t.tile != last_tile) {
+            last.load(c, (1 << (g.s0 + 8)) + (((t.tile << 12) + 16 * w) >> (g.logN - g.s0 - 8)));
+            last_crow = t.crow, last_tile = t.tile;
+        }
+        if (i) lds_barrier();   // the waves' store spans are rewritten block-wide by this tile's first exchange
+        fwd_tile16<DP, RLX>(sm, dst + ((i64)(t.poly * g.rows + t.crow) << g.logN), t.tile, g, c, &last);
+    }
+}
+
+// cl.in_blocks is a multiple of 8 * tpb here (launch_pass16): a block's tiles are of one class
+template <bool RLX>
+__global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_fwd_seq(i64 *dst, PassGeom g, ClassLists cl, int total, int tpb,
+                                                                         const i64 *__restrict__ tw_br,
+                                                                         const double *__restrict__ tw_dp,
+                                                                         const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                         const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT16_LDS_WORDS + 1];
+    const int vb0 = (int)(blockIdx.x & 7) + 8 * (int)(blockIdx.x >> 3) * tpb;
+    if (vb0 < cl.in_blocks) seq16_loop<false, RLX>(sm, dst, g, cl.in, vb0, cl.in_real, tpb, tw_br, tw_dp, ql, qh, kl, kh);
+    else seq16_loop<true, RLX>(sm, dst, g, cl.dp, vb0 - cl.in_blocks, total - cl.in_blocks, tpb, tw_br, tw_dp, ql, qh, kl, kh);
+}
+
 // one arithmetic class per launch (used when a transform has a single class)
 template <bool DP, bool RLX, bool INV>
 __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16(const i64 *src, i64 *dst, PassGeom g, RowList rl,
@@ -553,6 +651,15 @@ inline void launch_pass16_class(bool inverse, int relaxed, unsigned blocks, hipS
     }
 }
 
+// tiles per block of ntt_pass16_fwd_seq, and the launch size (in such blocks) from which it is taken: four rounds of the
+// 1 024 co-resident blocks (below that the tail of 8-tile blocks costs more than the kept twiddles save).  In-process A/B
+// on the headline step (tools/ab_inproc.py): tiled pass -1.6 .. -2.4 % at 8 and 16 tiles per block, nothing at 4 or 32;
+// keeping the 4 twiddles of the stage before as well (124 VGPRs) adds nothing.
+#ifndef NTT16_SEQ_TILES
+#define NTT16_SEQ_TILES 8
+#endif
+#define NTT16_SEQ_MIN_BLOCKS 4096
+
 // host: the contiguous 12-stage pass of `polys` polynomials (forward: in place on dst; inverse: src -> dst, no tail).
 // ms (relaxed inverse only): the pass transforms the product of two stacks, see MulSrc.
 inline void launch_pass16(bool inverse, int relaxed, int polys, hipStream_t st, const i64 *src, i64 *dst, const PassGeom &g,
@@ -576,6 +683,17 @@ inline void launch_pass16(bool inverse, int relaxed, int polys, hipStream_t st, 
         if (relaxed) hipLaunchKernelGGL((ntt_pass16_mixed<true, true>), grid, block, 0, st, src, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
         else hipLaunchKernelGGL((ntt_pass16_mixed<false, true>), grid, block, 0, st, src, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
     } else {
+        const int tpb = NTT16_SEQ_TILES;
+        // (exact transforms only: on the relaxed passes of batched key switches — 100 k .. 400 k tiles — it measured neutral)
+        if (tpb > 1 && !relaxed && (int)grid.x >= tpb * NTT16_SEQ_MIN_BLOCKS) {
+            ClassLists cm = cl;   // classes padded to whole blocks of tpb tiles per XCD lane
+            const unsigned unit = 8u * (unsigned)tpb, dpb = per_row * (unsigned)dp.n;
+            cm.in_blocks = (int)(((unsigned)cl.in_real + unit - 1u) / unit * unit);
+            const int total = cm.in_blocks + (int)dpb;
+            const dim3 mg((unsigned)cm.in_blocks / (unsigned)tpb + 8u * ((dpb + unit - 1u) / unit));
+            hipLaunchKernelGGL((ntt_pass16_fwd_seq<false>), mg, block, 0, st, dst, g, cm, total, tpb, tw_br, tw_dp, ql, qh, kl, kh);
+            return;
+        }
         if (relaxed) hipLaunchKernelGGL((ntt_pass16_mixed<true, false>), grid, block, 0, st, src, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
         else hipLaunchKernelGGL((ntt_pass16_mixed<false, false>), grid, block, 0, st, src, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
     }

@@ -69,3 +69,68 @@ def test_gold_rotate_batch_of_64_equals_loop_and_reference_digest():
         for comp in range(2):
             assert torch.equal(one.data[comp][0], batch[i].data[comp][0]), (i, comp)
         del one
+
+
+def test_large_batch_transform_takes_the_eight_tile_kernel_and_equals_small_batches():
+    """lf_ntt on 70 polynomials x 30 limbs at logN 16 (33 600 tiles: above NTT16_SEQ_MIN_BLOCKS x 8, the tiled pass runs
+    as ntt_pass16_fwd_seq — 8 tiles per block, last-stage twiddles kept in registers) against the same polynomials in two
+    calls of 35 (one tile per block) — exact; relaxed transforms (one tile per block at any size) likewise; a few tiles hold
+    signed-lazy words (odd-tile path inside the block's loop); polynomial 0 against the oracle."""
+    from liberate_fhe_amd._native import lib, check
+    from liberate_fhe_amd.fhe.context.ckks_context import ckks_context
+    from liberate_fhe_amd.ntt import ntt_context, twiddles
+    from oracle import oracle as orc
+    LOGN, L, B = 16, 30, 70
+    ctx = ckks_context(logN=LOGN, num_special_primes=4)
+    ntt = ntt_context(ctx, devices=["cuda:0"])
+    total = len(ctx.q)
+    rows = list(range(total - L, total))
+    host = np.stack([synth.uniform_rows(300 + b, rows, ctx.q, ctx.N, lazy=True) for b in range(B)])
+    q = np.array([ctx.q[i] for i in rows], dtype=np.int64)
+    for b, r, j in ((0, 3, 5), (0, 29, 4096 * 7 + 11), (41, 0, 65535), (69, 17, 4096 * 15)):   # signed-lazy words (D.4)
+        host[b, r, j] -= 2 * q[r]
+    sl = lambda t: t[0][total - L:]
+    psi, q2, ql, qh, kl, kh = (sl(t) for t in (ntt.psi, ntt._2q, ntt.ql, ntt.qh, ntt.kl, ntt.kh))
+    st = torch.cuda.current_stream().cuda_stream
+    psi_dp = twiddles.dp_pointer(psi, ql, qh, kl, kh, 0, st)
+
+    def run(x, batch, flags):
+        check(lib.lf_ntt(x.data_ptr(), batch, L, LOGN, psi.data_ptr(), psi_dp, q.ctypes.data, 0, flags, q2.data_ptr(),
+                         ql.data_ptr(), qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), 0, st), "lf_ntt")
+
+    for flags in (0, 1):                                   # exact, LF_NTT_RELAXED
+        big = torch.from_numpy(host).cuda()
+        run(big, B, flags)
+        halves = torch.from_numpy(host).cuda()
+        run(halves[:35], 35, flags)
+        run(halves[35:], 35, flags)
+        torch.cuda.synchronize()
+        assert torch.equal(big, halves), f"flags {flags}: 70-polynomial call differs from 2 x 35"
+        if flags == 0:
+            h = lambda v: np.asarray(v, dtype=np.int64)
+            pick = lambda v: h(v)[total - L:]
+            psi_h = np.ascontiguousarray(ctx.psi_br[total - L:].copy())
+            orc.mont_enter(psi_h, pick(ctx.R_square), L, pick(ctx.q_lower_bits), pick(ctx.q_higher_bits), pick(ctx.k_lower_bits), pick(ctx.k_higher_bits))
+            want = host[0].copy()
+            orc.ntt(want, psi_h, L, LOGN, pick(ctx.q_double), pick(ctx.q_lower_bits), pick(ctx.q_higher_bits), pick(ctx.k_lower_bits), pick(ctx.k_higher_bits))
+            assert (big[0].cpu().numpy() == want).all(), "polynomial 0 differs from the oracle"
+        del big, halves
+
+
+def test_gold_cc_mult_batch_of_8_equals_loop():
+    """8 gold multiplications under one key in one cc_mult_batch call (d0 / d1 folded into the key-switch sums, the
+    (digit, own limb) pairs skipped): every result equals cc_mult's, the fixture's pair the reference engine's digest."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    rec = GOLD["gold"]
+    eng = ckks_engine(devices=["cuda:0"], **rec["params"])
+    s = rec["seeds"]
+    evk = synth.key_switch_key(eng, s["evk"])
+    pairs = [(synth.ciphertext(eng, s["ct_a"], 0), synth.ciphertext(eng, s["ct_b"], 0))]
+    pairs += [(synth.ciphertext(eng, 200 + i, 0), synth.ciphertext(eng, 300 + i, 0)) for i in range(7)]
+    batch = eng.cc_mult_batch(pairs, evk)
+    assert _digest(batch[0]) == rec["ops"]["cc_mult(a,b,evk)"]               # the reference engine's output
+    for i, (a, b) in enumerate(pairs):
+        one = eng.cc_mult(a, b, evk)
+        for comp in range(2):
+            assert torch.equal(one.data[comp][0], batch[i].data[comp][0]), (i, comp)
+        del one
