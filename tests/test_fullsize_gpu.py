@@ -71,23 +71,26 @@ def test_gold_rotate_batch_of_64_equals_loop_and_reference_digest():
         del one
 
 
-def test_large_batch_transform_takes_the_eight_tile_kernel_and_equals_small_batches():
-    """lf_ntt on 70 polynomials x 30 limbs at logN 16 (33 600 tiles: above NTT16_SEQ_MIN_BLOCKS x 8, the tiled pass runs
-    as ntt_pass16_fwd_seq — 8 tiles per block, last-stage twiddles kept in registers) against the same polynomials in two
-    calls of 35 (one tile per block) — exact; relaxed transforms (one tile per block at any size) likewise; a few tiles hold
-    signed-lazy words (odd-tile path inside the block's loop); polynomial 0 against the oracle."""
+@pytest.mark.parametrize("LOGN,L,B,ctx_kw", [(16, 30, 70, dict(num_special_primes=4)),
+                                              (13, 28, 600, dict(num_scales=23, num_special_primes=4, is_secured=False))])
+def test_large_batch_transform_takes_the_eight_tile_kernel_and_equals_small_batches(LOGN, L, B, ctx_kw):
+    """lf_ntt on B polynomials x L limbs — 33 600 tiles both times: above NTT16_SEQ_MIN_BLOCKS x 8, so the tiled pass of
+    the EXACT transform runs as ntt_pass16_fwd_seq (8 tiles per block, last-stage twiddles kept in registers) — against the
+    same polynomials in two calls of B / 2 (one tile per block); relaxed transforms likewise.  logN 16: tile pairs per class
+    are multiples of 8 (XCD-aware block order); logN 13 with 23 + 5 limbs: they are not (plain order).  A few tiles hold
+    signed-lazy words (odd-tile path inside a block's loop); polynomial 0 against the oracle."""
     from liberate_fhe_amd._native import lib, check
     from liberate_fhe_amd.fhe.context.ckks_context import ckks_context
     from liberate_fhe_amd.ntt import ntt_context, twiddles
     from oracle import oracle as orc
-    LOGN, L, B = 16, 30, 70
-    ctx = ckks_context(logN=LOGN, num_special_primes=4)
+    ctx = ckks_context(logN=LOGN, **ctx_kw)
     ntt = ntt_context(ctx, devices=["cuda:0"])
-    total = len(ctx.q)
+    total, N = len(ctx.q), ctx.N
+    assert total >= L and B * L * (N >> 12) >= 8 * 4096
     rows = list(range(total - L, total))
-    host = np.stack([synth.uniform_rows(300 + b, rows, ctx.q, ctx.N, lazy=True) for b in range(B)])
+    host = np.stack([synth.uniform_rows(300 + b, rows, ctx.q, N, lazy=True) for b in range(B)])
     q = np.array([ctx.q[i] for i in rows], dtype=np.int64)
-    for b, r, j in ((0, 3, 5), (0, 29, 4096 * 7 + 11), (41, 0, 65535), (69, 17, 4096 * 15)):   # signed-lazy words (D.4)
+    for b, r, j in ((0, 3, 5), (0, L - 1, N // 2 + 11), (B // 2 + 6, 0, N - 1), (B - 1, 17, N - 4096)):   # signed-lazy words (D.4)
         host[b, r, j] -= 2 * q[r]
     sl = lambda t: t[0][total - L:]
     psi, q2, ql, qh, kl, kh = (sl(t) for t in (ntt.psi, ntt._2q, ntt.ql, ntt.qh, ntt.kl, ntt.kh))
@@ -102,17 +105,18 @@ def test_large_batch_transform_takes_the_eight_tile_kernel_and_equals_small_batc
         big = torch.from_numpy(host).cuda()
         run(big, B, flags)
         halves = torch.from_numpy(host).cuda()
-        run(halves[:35], 35, flags)
-        run(halves[35:], 35, flags)
+        run(halves[:B // 2], B // 2, flags)
+        run(halves[B // 2:], B - B // 2, flags)
         torch.cuda.synchronize()
-        assert torch.equal(big, halves), f"flags {flags}: 70-polynomial call differs from 2 x 35"
+        assert torch.equal(big, halves), f"flags {flags}: {B}-polynomial call differs from two half-batches"
         if flags == 0:
             h = lambda v: np.asarray(v, dtype=np.int64)
             pick = lambda v: h(v)[total - L:]
+            cs = (pick(ctx.q_lower_bits), pick(ctx.q_higher_bits), pick(ctx.k_lower_bits), pick(ctx.k_higher_bits))
             psi_h = np.ascontiguousarray(ctx.psi_br[total - L:].copy())
-            orc.mont_enter(psi_h, pick(ctx.R_square), L, pick(ctx.q_lower_bits), pick(ctx.q_higher_bits), pick(ctx.k_lower_bits), pick(ctx.k_higher_bits))
+            orc.mont_enter(psi_h, pick(ctx.R_square), L, *cs)
             want = host[0].copy()
-            orc.ntt(want, psi_h, L, LOGN, pick(ctx.q_double), pick(ctx.q_lower_bits), pick(ctx.q_higher_bits), pick(ctx.k_lower_bits), pick(ctx.k_higher_bits))
+            orc.ntt(want, psi_h, L, LOGN, pick(ctx.q_double), *cs)
             assert (big[0].cpu().numpy() == want).all(), "polynomial 0 differs from the oracle"
         del big, halves
 
