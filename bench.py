@@ -552,7 +552,9 @@ def main():
         clocks = {"idle": clock_under(lambda: None, 0), "tiled_pass": clock_under(lambda: one_pass(2), 40),
                   "column_pass": clock_under(lambda: one_pass(1), 60), "whole_transform": clock_under(step, 25)}
         pw, cap = package_power_under(lambda: one_pass(2), 1500)
-        power = {"tiled_pass_package_W": pw, "package_cap_W": cap, "source": "rocm-smi --showpower, read while 1 500 tiled passes run"}
+        power = {"tiled_pass_package_W": pw, "package_cap_W": cap,
+                 "at_cap": None if pw is None or cap is None else bool(pw >= 0.97 * cap),
+                 "source": "rocm-smi --showpower, read while 1 500 tiled passes run"}
     alg_bytes_per_launch = 8 * N * L_LIMBS * B                      # 16*N per limb per transform, two launches
     achieved = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
     traffic = valu = valu_busy = cols_traffic = None
