@@ -64,7 +64,8 @@ int lf_tune(int which, int value);
  * `samples` readings of the shader clock — out[2 i] = core-clock cycles (s_memtime) that passed during out[2 i + 1] ticks
  * (>= `ticks`) of the constant 100 MHz counter (s_memrealtime), so MHz = 100 * out[2 i] / out[2 i + 1].  Launched on a
  * second stream beside a kernel under test it reports the clock that kernel actually runs at (bench.py: the headline
- * kernels run with the package at its 1 400 W cap).  out: device, 2 * samples 64-bit words. */
+ * kernels run with the package at its 1 400 W cap).  out: device, 2 * samples 64-bit words;
+ * samples <= 4096, samples * ticks <= 10^9 (ten seconds of spinning), else LF_ERR_ARG. */
 int lf_clock_probe(uint64_t *out, int samples, uint64_t ticks, int device, void *stream);
 
 /* ---- elementwise family --------------------------------------------------------------------- */

@@ -125,7 +125,9 @@ extern "C" {
 int lf_abi_version(void) { return 9; }
 
 int lf_clock_probe(uint64_t *out, int samples, uint64_t ticks, int device, void *stream) {
-    if (!out || samples < 1 || samples > 4096 || ticks < 1 || ticks > 100000000ull) return LF_ERR_ARG;
+    // (at most 10 s of spinning in all: the wave holds its CU slot for samples x ticks x 10 ns)
+    if (!out || samples < 1 || samples > 4096 || ticks < 1 || ticks > 100000000ull || (uint64_t)samples * ticks > 1000000000ull)
+        return LF_ERR_ARG;
     if (int e = lf_set_device(device)) return e;
     hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long *)out, samples,
                        (unsigned long long)ticks);

@@ -154,6 +154,7 @@ def test_clock_probe_checks_its_arguments_on_the_host():
     assert lib.lf_clock_probe(None, 4, 1000, 0, None) != 0
     assert lib.lf_clock_probe(8, 0, 1000, 0, None) != 0
     assert lib.lf_clock_probe(8, 4, 0, 0, None) != 0
+    assert lib.lf_clock_probe(8, 4096, 1_000_000, 0, None) != 0           # more than ten seconds of spinning
 
 
 def test_bench_refuses_more_ranks_than_gpus_without_touching_one():
