@@ -513,7 +513,7 @@ def main():
     torch.cuda.synchronize()
     cols_ms = event_time_ms(lambda: one_pass(1), n_roof)
     # Shader clock and package power WHILE the kernels run: a one-wave probe (lf_clock_probe) on a second stream counts core
-    # cycles per tick of the constant 100 MHz counter; the SMI is read once in the middle of a ~1.5 s run of tiled passes.
+    # cycles per tick of the constant 100 MHz counter; the hwmon power file is read once in the middle of a ~1.5 s run of tiled passes.
     # (MI355X caps the package at 1 400 W; the headline kernels sit at the cap and the clock is what gives)
     def clock_under(work, launches):
         try:
@@ -531,18 +531,39 @@ def main():
         except Exception:
             return None
 
+    def read_hwmon_power():
+        """(package power W, cap W) of this rank's GPU from the amdgpu hwmon files (what the SMI prints); no child process:
+        under a profiler a child would inherit its preloaded library.  (None, None) when the files are not there."""
+        import glob
+        cards = []
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            cards = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+        except Exception:
+            pass
+        cards = cards or glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")
+        best = (None, None)
+        for d in cards:
+            try:
+                name = "power1_average" if os.path.exists(d + "/power1_average") else "power1_input"
+                cur = int(open(f"{d}/{name}").read()) / 1e6
+                cap = int(open(f"{d}/power1_cap").read()) / 1e6 if os.path.exists(d + "/power1_cap") else None
+                if best[0] is None or cur > best[0]:
+                    best = (cur, cap)
+            except Exception:
+                continue
+        return best
+
     def package_power_under(work, launches):
-        import re, subprocess
         try:
             torch.cuda.synchronize()
-            for _ in range(launches):                      # enqueue only: the device works through them while the SMI is read
+            for _ in range(launches):                      # enqueue only: the device works through them while the file is read
                 work()
-            time.sleep(0.5)
-            txt = subprocess.run(["rocm-smi", "--showpower", "--showmaxpower"], capture_output=True, text=True, timeout=30).stdout
+            time.sleep(0.7)
+            pw = read_hwmon_power()
             torch.cuda.synchronize()
-            cur = re.search(r"Current Socket Graphics Package Power \(W\): ([0-9.]+)", txt)
-            cap = re.search(r"Max Graphics Package Power \(W\): ([0-9.]+)", txt)
-            return (float(cur.group(1)) if cur else None), (float(cap.group(1)) if cap else None)
+            return pw
         except Exception:
             torch.cuda.synchronize()
             return None, None
@@ -554,7 +575,7 @@ def main():
         pw, cap = package_power_under(lambda: one_pass(2), 1500)
         power = {"tiled_pass_package_W": pw, "package_cap_W": cap,
                  "at_cap": None if pw is None or cap is None else bool(pw >= 0.97 * cap),
-                 "source": "rocm-smi --showpower, read while 1 500 tiled passes run"}
+                 "source": "amdgpu hwmon power1_average / power1_cap, read while 1 500 tiled passes run"}
     alg_bytes_per_launch = 8 * N * L_LIMBS * B                      # 16*N per limb per transform, two launches
     achieved = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
     traffic = valu = valu_busy = cols_traffic = None
