@@ -17,6 +17,9 @@ The JSON line also carries
                  per launch = 8*N*limbs (a transform is 16*N bytes per limb, SURVEY.md §8d, spread over its two
                  launches); its launch duration is measured live with HIP events on the launch stream, the
                  kernel launched alone (lf_ntt_pass, the measurement entry) with the grid it has inside the full step;
+                 `shader_clock_mhz` = the clock the CUs run at beside each kernel (lf_clock_probe on a second stream) and
+                 `package_power` = the amdgpu hwmon reading while the dominant kernel runs: both passes sit at the 1 400 W
+                 package cap and the tiled pass runs at ~1.9 of 2.4 GHz — `frac` is what that clock allows (DESIGN.md §4);
   cpu_baseline : the C oracle (strict reference-kernel semantics) on this box's host cores, same workload,
                  bounded sample;
   roofline_engine_ops : cc_mult_evk / rotate_single per preset against the same HBM peak with SURVEY.md §8(d)'s
