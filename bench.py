@@ -166,13 +166,37 @@ def algorithmic_rows(eng, op):
     return 2 * ell + 2 * dnum * (ell + K) + 2 * ell
 
 
-def op_roofline(eng, op, ops_per_s, profile):
+def classify_bound(pmc_kernels):
+    """What bounds an engine op, from the per-kernel PMC table of THIS build (profiles/<tag>_engine_ops_pmc.json):
+    a kernel counts as `hbm` when it moves >= 70 % of the 6.3 TB/s a streaming kernel reaches, as `valu_issue` when its
+    SIMDs issue a VALU instruction in >= 70 % of the busy cycles, else as `latency` (neither pipe saturated: short
+    launches, dependent LDS exchanges); the op's bound is the class holding most of its kernel time.  Returns
+    (bound, {class: share of the op's kernel time}) or (None, None) without counters."""
+    if not pmc_kernels:
+        return None, None
+    share = {"hbm": 0.0, "valu_issue": 0.0, "latency": 0.0}
+    for k in pmc_kernels:
+        us = k["us"] * k.get("per_op", 1)
+        cls = "hbm" if k["moved_TBps"] >= 0.7 * HBM_ACHIEVABLE_GBS / 1e3 else "valu_issue" if k["valu_busy"] >= 0.70 else "latency"
+        share[cls] += us
+    total = sum(share.values()) or 1.0
+    share = {k: round(v / total, 3) for k, v in share.items()}
+    return max(share, key=share.get), share
+
+
+def op_roofline(eng, op, ops_per_s, profile, pmc=None):
     rows = algorithmic_rows(eng, op)
     nbytes = rows * eng.ctx.N * 8
     achieved = nbytes * ops_per_s / 1e9
-    out = {"bound": "hbm", "algorithmic_rows": rows, "algorithmic_bytes": nbytes, "ops_per_s": ops_per_s,
+    bound, share = classify_bound((pmc or {}).get("kernels"))
+    out = {"bound": bound, "bound_shares": share, "algorithmic_rows": rows, "algorithmic_bytes": nbytes, "ops_per_s": ops_per_s,
            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "frac_of_achievable_6300": achieved / HBM_ACHIEVABLE_GBS}
+    if bound is None:
+        out["bound_note"] = "no PMC table of this build (profiles/<tag>_engine_ops_pmc.json, digest-stamped): bound not stated"
+    if pmc:
+        out["traffic"] = pmc.get("bytes_per_op")      # HBM bytes per op from the PMC passes (reads corrected, MI355X_MICROARCH.md)
+        out["traffic_over_algorithmic"] = None if not pmc.get("bytes_per_op") else pmc["bytes_per_op"] / nbytes
     if profile:
         out["from_profile"] = profile    # dominant kernel + per-kernel time, rocprofv3 summary under profiles/
     return out
@@ -186,6 +210,7 @@ def engine_rates(dev, quick):
     out = {}
     roof = {}
     prof = stamped_profile("r*_engine_ops_summary.json") or {}   # per-kernel times: only if taken on this build
+    pmc = stamped_profile("r*_engine_ops_pmc.json") or {}        # per-kernel HBM bytes / VALU utilisation, same rule
     for name in ("silver", "gold"):
         eng = ckks_engine(**{**presets.params[name], "devices": [dev]})
         a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
@@ -201,10 +226,10 @@ def engine_rates(dev, quick):
         n = 5 if quick else (100 if name == "silver" else 60)
         ms = event_time_ms(lambda: eng.cc_mult(a, b, evk), n)
         out[f"cc_mult_evk_{name}_ops_per_s"] = 1e3 / ms
-        roof[f"cc_mult_evk_{name}"] = op_roofline(eng, "cc_mult", 1e3 / ms, prof.get(f"{name}_cc_mult"))
+        roof[f"cc_mult_evk_{name}"] = op_roofline(eng, "cc_mult", 1e3 / ms, prof.get(f"{name}_cc_mult"), pmc.get(f"{name}_cc_mult"))
         ms = event_time_ms(lambda: eng.rotate_single(a, rotk), n)
         out[f"rotate_single_{name}_ops_per_s"] = 1e3 / ms
-        roof[f"rotate_single_{name}"] = op_roofline(eng, "rotate", 1e3 / ms, prof.get(f"{name}_rotate"))
+        roof[f"rotate_single_{name}"] = op_roofline(eng, "rotate", 1e3 / ms, prof.get(f"{name}_rotate"), pmc.get(f"{name}_rotate"))
         # configs[4]: a batch of ciphertexts rotated by the same step (one key): groups of 4 per key-switch launch set
         nb = 16
         cts = [synth.ciphertext(eng, 100 + i, 0) for i in range(nb)]
@@ -233,6 +258,76 @@ def engine_rates(dev, quick):
         del eng, a, b, evk, rotk
         torch.cuda.empty_cache()
     return out, roof
+
+
+def api_endpoints(dev):
+    """Wall-clock of the API endpoints the reference's example notebook times (`examples/[Example] CKKS
+    engine.ipynb` cells 6-12, silver, unnamed NVIDIA GPU — context, not a target).  Every figure here is SYNCHRONISED
+    (the notebook's key timings are asynchronous launch times); `first_call` includes table builds, `warm` is the median
+    of 20 calls after it."""
+    from liberate_fhe_amd.fhe import ckks_engine, presets
+    out = {"preset": "silver", "reference_notebook": {"engine_construction_s": 2.63, "create_secret_key_us": 873, "create_public_key_us": 633,
+                                                      "encode_encrypt_decrypt_decode_first_call_ms": 99, "encorypt_decrode_ms": 4.02,
+                                                      "note": "unnamed NVIDIA GPU; key timings there are asynchronous launches, no sync"}}
+
+    def timed(fn, reps=20):
+        ts = []
+        res = None
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2], res
+
+    try:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng = ckks_engine(**{**presets.params["silver"], "devices": [dev]})
+        torch.cuda.synchronize()
+        out["engine_construction_s"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        eng2 = ckks_engine(**{**presets.params["silver"], "devices": [dev]})
+        torch.cuda.synchronize()
+        out["engine_construction_second_s"] = time.perf_counter() - t0
+        del eng2
+        t0 = time.perf_counter()
+        sk = eng.create_secret_key()
+        torch.cuda.synchronize()
+        out["create_secret_key_first_call_ms"] = 1e3 * (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        pk = eng.create_public_key(sk)
+        torch.cuda.synchronize()
+        out["create_public_key_first_call_ms"] = 1e3 * (time.perf_counter() - t0)
+        dt, sk = timed(eng.create_secret_key)
+        out["create_secret_key_ms"] = 1e3 * dt
+        dt, pk = timed(lambda: eng.create_public_key(sk))
+        out["create_public_key_ms"] = 1e3 * dt
+        dt, evk = timed(lambda: eng.create_evk(sk), 5)
+        out["create_evk_ms"] = 1e3 * dt
+        m = eng.example(-1, 1)
+        t0 = time.perf_counter()
+        back = eng.decrode(eng.encorypt(m, pk), sk)
+        out["encorypt_decrode_first_call_ms"] = 1e3 * (time.perf_counter() - t0)
+        out["encorypt_decrode_max_abs_error"] = float(np.abs(back - m).max())
+        dt, ct = timed(lambda: eng.encorypt(m, pk))
+        out["encorypt_ms"] = 1e3 * dt
+        dt, _ = timed(lambda: eng.decrode(ct, sk))
+        out["decrode_ms"] = 1e3 * dt
+        dt, _ = timed(lambda: eng.decrode(eng.encorypt(m, pk), sk))
+        out["encorypt_decrode_ms"] = 1e3 * dt
+        # the mult endpoint on top of it (what the metric's second half times, here through the public dispatch)
+        ct2 = eng.encorypt(m, pk)
+        dt, prod = timed(lambda: eng.mult(ct, ct2, evk))
+        out["mult_ms"] = 1e3 * dt
+        out["mult_decode_max_abs_error"] = float(np.abs(eng.decrode(prod, sk) - m * m).max())
+        del eng
+        torch.cuda.empty_cache()
+    except Exception as e:   # a context figure, never a reason to lose the line
+        out["error"] = f"{type(e).__name__}: {e}"[:300]
+    return out
 
 
 def cpu_engine_baseline(preset="silver", budget_s=25.0, max_reps=10):
@@ -277,7 +372,70 @@ def _natural(eng, ct):
     return out
 
 
-def multi_gpu_rates(dev, world, rank, out, sharded=True):
+def comm_prepare(dev, world, rank, local_rank):
+    """N > 1, BEFORE the watchdog starts: the process group of the limb-sharded legs and one untimed all-pairs exchange on
+    it.  RCCL sets a point-to-point channel up lazily, on a pair's first message; the first key switch of the sharded
+    engine addresses all N (N - 1) directed pairs in one group — that set-up belongs here, under the communicator's
+    long timeout, not inside the 300 s watchdog of the timed legs.  Returns (group, comm block of the JSON line)."""
+    import datetime
+    import torch.distributed as dist
+    # (its timeout must NOT undercut the watchdog: a communicator that times out first tears the process down before the
+    # line is printed)
+    grp = dist.new_group(ranks=list(range(world)), timeout=datetime.timedelta(seconds=900))
+    pr = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": rank, "device": dev, "name": pr.name,
+          "pci": f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}.0",
+          "uuid": str(getattr(pr, "uuid", ""))}
+    seen = [None] * world
+    dist.all_gather_object(seen, me, group=grp)
+    t0 = time.perf_counter()
+    box = torch.full((world, 64), rank, dtype=torch.int64, device=dev)
+    ops = []
+    for p in range(world):
+        if p != rank:
+            ops.append(dist.P2POp(dist.isend, box[rank], dist.get_global_rank(grp, p), grp))
+            ops.append(dist.P2POp(dist.irecv, box[p], dist.get_global_rank(grp, p), grp))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    torch.cuda.synchronize()
+    ok = bool((box == torch.arange(world, device=dev, dtype=torch.int64)[:, None]).all().item())
+    block = {"backend": str(dist.get_backend(grp)), "world_size": dist.get_world_size(grp), "ranks_seen": len([x for x in seen if x]),
+             "devices": seen, "distinct_pci_ids": len({x["pci"] for x in seen if x}),
+             "p2p_warmup_s": time.perf_counter() - t0, "p2p_warmup_all_pairs_ok": ok,
+             "transport": "RCCL point-to-point batches (ncclGroup of send / recv) over xGMI" if "nccl" in str(dist.get_backend(grp))
+                          else "gloo + host staging (REHEARSAL transport, tests/gloo_device_p2p.py)"}
+    return grp, block
+
+
+def link_bytes(eng, level):
+    """Bytes one key switch at `level` puts on each directed link (owner -> peer) of the point-to-point batch, and the
+    rows each rank owns: from the engine's exchange schedule (`_ks_tables(level)["groups"]`)."""
+    tabs = eng._ks_tables(level)
+    n_alive = eng.len_devices[level]
+    per_owner = {}
+    for owner, first, count, row0, nrows, src_row in tabs["groups"]:
+        per_owner[owner] = per_owner.get(owner, 0) + nrows * eng.ctx.N * 8
+    return {"alive_ranks": n_alive, "bytes_per_link_by_owner": per_owner,
+            "max_bytes_per_link": max(per_owner.values()) if per_owner else 0,
+            "bytes_received_per_rank": {r: sum(v for o, v in per_owner.items() if o != r) for r in range(n_alive)},
+            "messages_per_batch_per_rank": {r: sum((n_alive - 1) if g[0] == r else 1 for g in tabs["groups"]) for r in range(n_alive)}}
+
+
+def host_enqueue_us(fn, bursts=7, n=8):
+    """Median host time to ENQUEUE one op (bursts of `n` from an idle queue, no synchronisation inside a burst)."""
+    ts = []
+    for _ in range(bursts):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        ts.append((time.perf_counter() - t0) / n)
+        torch.cuda.synchronize()
+    ts.sort()
+    return 1e6 * ts[len(ts) // 2]
+
+
+def multi_gpu_rates(dev, world, rank, out, sharded=True, grp=None, comm_block=None):
     """N > 1.  Fills `out` (a dict that main() prints even if a leg below never returns, see the watchdog):
       replicas      gold cc_mult(+relinearize) on N independent engines, zero communication: N x single rate;
       config 5      64 gold ciphertexts rotated under one key, 64 / N per rank (batch replicas, full key per GPU);
@@ -342,10 +500,12 @@ def multi_gpu_rates(dev, world, rank, out, sharded=True):
         return
     try:
         from liberate_fhe_amd.fhe.comm import DistComm
-        # (its timeout must NOT undercut the watchdog below: a communicator that times out first tears the process down
-        # before the line is printed)
-        grp = dist.new_group(ranks=list(range(world)), timeout=datetime.timedelta(seconds=900))
+        if grp is None:
+            grp, comm_block = comm_prepare(dev, world, rank, torch.cuda.current_device())
         eng = ckks_engine(devices=[dev], comm=DistComm(group=grp, local_device=dev), **params)
+        if comm_block is not None:
+            comm_block["key_switch_batch_level0"] = link_bytes(eng, 0)
+            comm_block["key_switch_batch_level10"] = link_bytes(eng, 10)
         evk = synth.key_switch_key(eng, 5)
         rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
         # parity gate (every rank, every row it holds)
@@ -378,6 +538,14 @@ def multi_gpu_rates(dev, world, rank, out, sharded=True):
         ms = _max_over_ranks(event_time_ms(lambda: eng.rotate_single(a, rotk), 40), dev)
         out["rotate_single_gold_limb_sharded_ops_per_s"] = 1e3 / ms
         out["limb_sharded_rows_per_rank_level0"] = [len(d) for d in eng.ntt.p.destination_arrays_with_special[0]]
+        # host time this rank spends ENQUEUEING one sharded op (the margin before the host, not the GPU, paces a rank)
+        if comm_block is not None:
+            mine = torch.tensor([host_enqueue_us(lambda: eng.cc_mult(a, b, evk)), host_enqueue_us(lambda: eng.rotate_single(a, rotk))],
+                                dtype=torch.float64, device=dev)
+            every = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine, group=grp)
+            comm_block["host_enqueue_us_per_sharded_cc_mult_by_rank"] = [round(float(t[0]), 1) for t in every]
+            comm_block["host_enqueue_us_per_sharded_rotate_by_rank"] = [round(float(t[1]), 1) for t in every]
     except Exception as e:   # the headline line must survive a failure of this leg
         out["multi_gpu_limb_sharded_error"] = f"{type(e).__name__}: {e}"[:300]
 
@@ -498,6 +666,39 @@ def main():
 
     value = world * B / (wall / args.steps)                         # poly-NTT(30)/s, whole job
 
+    # Parity spot check of what the timed kernel computes, on THIS box, outside the timed region: polynomial 0 is reloaded
+    # from its seed, the whole batch goes through one more step, and two of its limbs — the first integer-class one (a
+    # 60-bit prime, REDC62 path) and the first fp64-class one (a 40-bit prime) — are compared word for word with the C oracle.
+    def parity_spot_check():
+        from oracle import oracle as orc      # the checker, never the thing measured
+        src = synth.uniform_rows(1000 * rank, rows_idx, ctx.q, N, lazy=True)
+        x[0] = torch.from_numpy(src).to(dev)
+        step()
+        torch.cuda.synchronize()
+        got = x[0].cpu().numpy()
+        h = lambda v, i: np.asarray([v[i]], dtype=np.int64)
+        picks = [next(r for r, i in enumerate(rows_idx) if ctx.q[i] >= (1 << 41)), next(r for r, i in enumerate(rows_idx) if ctx.q[i] < (1 << 41))]
+        for r in picks:
+            i = rows_idx[r]
+            ql_, qh_, kl_, kh_ = h(ctx.q_lower_bits, i), h(ctx.q_higher_bits, i), h(ctx.k_lower_bits, i), h(ctx.k_higher_bits, i)
+            psi_row = np.ascontiguousarray(ctx.psi_br[i:i + 1].copy())
+            orc.mont_enter(psi_row, h(ctx.R_square, i), 1, ql_, qh_, kl_, kh_)
+            want = np.ascontiguousarray(src[r:r + 1].copy())
+            orc.ntt(want, psi_row, 1, ctx.logN, h(ctx.q_double, i), ql_, qh_, kl_, kh_)
+            if not (want[0] == got[r]).all():
+                return f"MISMATCH: limb {r} (prime index {i}, {ctx.q[i].bit_length()} bits): {int((want[0] != got[r]).sum())} of {N} words differ from the oracle"
+        return "ok"
+
+    try:
+        spot = parity_spot_check()
+    except Exception as e:
+        spot = f"ERROR: {type(e).__name__}: {e}"[:300]
+    if world > 1:
+        t = torch.tensor([0 if spot == "ok" else 1], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if int(t.item()) and spot == "ok":
+            spot = f"MISMATCH on {int(t.item())} other rank(s)"
+
     # Roofline of the dominant kernel, ntt_pass16_fwd_seq: the tiled pass (12 of the 16 stages) of all 30 limbs,
     # integer-class blocks first, then the fp64 class.  In the step above it follows the column pass, so it is
     # timed on its own here: lf_ntt_pass(which = 2), the library's measurement entry, launches exactly that kernel,
@@ -581,7 +782,7 @@ def main():
                  "source": "amdgpu hwmon power1_average / power1_cap, read while 1 500 tiled passes run"}
     alg_bytes_per_launch = 8 * N * L_LIMBS * B                      # 16*N per limb per transform, two launches
     achieved = alg_bytes_per_launch / (k_ms * 1e-3) / 1e9
-    traffic = valu = valu_busy = cols_traffic = None
+    traffic = valu = valu_busy = cols_traffic = cols_valu = None
     tj = stamped_profile("traffic_r*.json")   # PMC figures per launch, only if collected on THIS build (else null)
     pmc_source = None
     if tj is not None:
@@ -594,12 +795,35 @@ def main():
         valu = tj.get("ntt_fwd_pass_mixed_valu_wave_instr_per_launch")
         valu = None if valu is None else valu * scale
         valu_busy = tj.get("ntt_fwd_pass_mixed_valu_busy_frac")
+        cols_valu = tj.get("ntt_fwd_cols_mixed_valu_wave_instr_per_launch")
+        cols_valu = None if cols_valu is None else cols_valu * scale
+    # The ceiling THIS design can reach on THIS part: every VALU instruction of a wave occupies its SIMD for 4 cycles
+    # (64 lanes over 16-lane pipes; tools/ubench: fp64 FMA, 64-bit integer multiply-adds and compares all issue at that
+    # rate), so a launch cannot be shorter than its wave-level VALU instructions / (1024 SIMDs x clock / 4) — at the
+    # clock the package's 1 400 W cap leaves the kernel.  `issue_ceiling_frac` is that time expressed like `frac` (algorithmic
+    # bytes over it, against 8 TB/s): the number 0.25-0.3 is to be read against, not the 0.60 of an HBM-bound kernel.
+    issue_ceiling = None
+    if valu is not None and cols_valu is not None and clocks and clocks.get("tiled_pass") and clocks.get("column_pass"):
+        rate = lambda mhz: 1024 * mhz * 1e6 / 4.0       # wave-level VALU instructions per second, chip-wide
+        t_tiled, t_cols = valu / rate(clocks["tiled_pass"]), cols_valu / rate(clocks["column_pass"])
+        step_bytes = 16 * N * L_LIMBS * B
+        issue_ceiling = {
+            "tiled_pass_min_ms": 1e3 * t_tiled, "column_pass_min_ms": 1e3 * t_cols,
+            "kernel_frac": alg_bytes_per_launch / t_tiled / 1e9 / HBM_PEAK_GBS,
+            "whole_step_frac": step_bytes / (t_tiled + t_cols) / 1e9 / HBM_PEAK_GBS,
+            "whole_step_poly_ntt_per_s": B / (t_tiled + t_cols),
+            "kernel_at_fraction_of_ceiling": t_tiled / (k_ms * 1e-3),
+            "whole_step_at_fraction_of_ceiling": (t_tiled + t_cols) / (dev_ms * 1e-3),
+            "wave_instr_per_step": valu + cols_valu,
+            "note": "min time = VALU wave-instructions (PMC, this build) / (1024 SIMDs x measured shader clock / 4 cycles)"}
 
     result = {
         "metric": "NTTs/sec (forward negacyclic poly-NTT, logN=16, L=30 limbs, bit-exact vs reference semantics)",
         "value": value, "unit": "poly-NTT/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int64", "data": "synthetic",
+        # one polynomial of one more (untimed) step, an integer-class and an fp64-class limb, word for word vs the C oracle
+        "parity_spot_check": spot,
         "config": {"workload": f"gold preset (logN=16), rows {lo}..{total - 1} of the prime chain (25 scale + base + 4 special"
                                f" primes = 30 limbs), {B} polynomials per GPU per step, forward NTT via lf_ntt (C ABI)",
                    "batch_per_gpu": B, "limbs": L_LIMBS, "logN": LOGN, "parallelism": f"replicas x{world} (independent polynomials)"},
@@ -608,6 +832,8 @@ def main():
         # utilisation of the pipe that actually limits it (PMC; null when the counters were not taken on this build)
         "roofline": {"bound": "valu_issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "issue_frac": valu_busy, "traffic": traffic,
+                     "issue_ceiling_frac": None if issue_ceiling is None else issue_ceiling["kernel_frac"],
+                     "issue_ceiling": issue_ceiling,
                      "kernel": "ntt_pass16_fwd_seq<false> (tiled pass = 12 of 16 stages, 16 words per thread, 8 tiles per block, all 30 limbs: 5 integer-class + 25 fp64-class)",
                      "launches_per_transform": 2, "avg_launch_ms": k_ms, "launches_timed": n_roof,
                      "column_pass_launch_ms": cols_ms,
@@ -653,6 +879,7 @@ def main():
         extra["poly_ntt_per_s_ciphertext_limbs_1_integer_class"] = B / (ct_ms * 1e-3)
         extra["ciphertext_limbs_note"] = (f"rows {lo_ct}..{total - 5}: 29 scale primes + base prime (a level-5 ciphertext, no special primes);"
                                           " reported for the limb-mix sensitivity only, the metric above keeps its 5 integer-class limbs")
+        extra["api_endpoints"] = api_endpoints(dev)
         rates, roof = engine_rates(dev, quick=False)
         extra.update(rates)
         result["roofline_engine_ops"] = roof     # cc_mult_evk / rotate_single: the metric's second half, per preset
@@ -675,6 +902,13 @@ def main():
         # os._exit(3) — nothing is re-exec'ed, the process just ends, and the launcher reports the failure.
         import threading
         done = threading.Event()
+        grp = comm_block = None
+        if not args.no_sharded:
+            try:
+                grp, comm_block = comm_prepare(dev, world, rank, local_rank)     # untimed channel set-up, before the watchdog
+                result["comm"] = comm_block
+            except Exception as e:
+                result["comm"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
         def watchdog():
             if not done.wait(args.leg_timeout):
@@ -683,7 +917,7 @@ def main():
                     print(json.dumps(result), flush=True)
                 os._exit(3)     # a hung leg is a failure: the partial line is printed, the exit code says so
         threading.Thread(target=watchdog, daemon=True).start()
-        multi_gpu_rates(dev, world, rank, extra, sharded=not args.no_sharded)
+        multi_gpu_rates(dev, world, rank, extra, sharded=not args.no_sharded and grp is not None, grp=grp, comm_block=comm_block)
         done.set()
     if rank == 0:
         print(json.dumps(result), flush=True)
@@ -693,6 +927,8 @@ def main():
             dist.destroy_process_group()
         except Exception:
             pass
+    if spot != "ok":
+        sys.exit(4)      # the headline kernel's words differ from the oracle's on this box: the line says so, the exit code too
 
 
 if __name__ == "__main__":

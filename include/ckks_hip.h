@@ -50,13 +50,9 @@ int lf_limits(int which);
 
 /* Launch-shape thresholds (never results: every setting produces the same words).  Returns the previous value, -1 for an
  * unknown `which`; value < 0 only reads.  Process-wide; set before launching from several threads.
- *   LF_TUNE_KS_ONE_MIN_PAIRS  (digit, target limb) pairs from which the key switch of a logN 13..15 ring runs extension +
- *                             the WHOLE forward transform as one launch, a block per pair (csrc/ckks_ntt_one.h); below it
- *                             the column kernel + 4096-word tiled pass, 8..16 times the blocks.  Default INT_MAX (off):
- *                             measured slower on MI355X at every preset size (profiles/r03_one_launch_ab.txt). */
-#define LF_TUNE_KS_ONE_MIN_PAIRS 0
-/*   LF_TUNE_KS_EXT_COLS_MAX   largest logN - 12 (0 .. 4) for which the key switch's extension + leading stages run as the
- *                             column kernel (one register step per column, no LDS); above it the LDS-tiled form. */
+ *   LF_TUNE_KS_EXT_COLS_MAX   largest logN - 12 (0 .. 4) for which the key switch's extension + leading stages run as the
+ *                             column kernel (one register step per column, no LDS); above it the LDS-tiled form.
+ *   (knob 0 was the one-launch key-switch transform of round 3: slower at every preset size on MI355X, removed.) */
 #define LF_TUNE_KS_EXT_COLS_MAX 1
 int lf_tune(int which, int value);
 

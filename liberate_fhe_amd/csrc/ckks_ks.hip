@@ -29,7 +29,6 @@
 #include "../../include/ckks_hip.h"
 #include "ckks_ntt_core.h"
 #include "ckks_ntt_tile16.h"
-#include "ckks_ntt_one.h"
 
 #define KS_WORDS ((1 << NTT_TILE_LOG_MAX) / NTT_THREADS)   // tile words owned by one thread (8)
 
@@ -352,149 +351,6 @@ __global__ void __launch_bounds__(NTT_COL_THREADS) ks_ext_cols_mixed(const i64 *
     }
 }
 
-// ---- K2 + P2 in ONE launch (logN 13 .. 15): extension + the whole forward transform of a (digit, target limb) pair per block --
-// ckks_ntt_one.h: the limb lives in the registers of N / 32 threads.  The extended digit makes a single trip to HBM
-// (16 N bytes per limb pair instead of 8 N written + 8 N read + 8 N written), one launch instead of two.
-template <bool DP, int LOGN>
-__device__ __forceinline__ void ks_ext1_body(i64 *sm, int b, const i64 *__restrict__ state, i64 *__restrict__ tmp, const KsGeom &kg,
-                                             const RowList &rl, const i64 *__restrict__ desc, const i64 *__restrict__ E,
-                                             const double *__restrict__ Ed, const i64 *__restrict__ psi_br,
-                                             const double *__restrict__ psi_dp, const i64 *__restrict__ ql,
-                                             const i64 *__restrict__ qh, const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
-    typedef OneGeom<LOGN> G;
-    const int per_ct = kg.nparts * rl.n;
-    const int ct = b / per_ct;
-    b -= ct * per_ct;
-    int ri, p;   // the blocks of one digit differ in the target limb and re-read the same digit words: one XCD per digit
-    if ((kg.nparts & 7) == 0) {
-        const int x = b & 7, r = b >> 3;
-        ri = r % rl.n;
-        p = (r / rl.n) * 8 + x;
-    } else {
-        ri = b % rl.n;
-        p = b / rl.n;
-    }
-    p = __builtin_amdgcn_readfirstlane(p);
-    const int crow = __builtin_amdgcn_readfirstlane((int)rl.id[ri]);
-    const int ctu = __builtin_amdgcn_readfirstlane(ct);
-    if (kg.own != nullptr && (int)kg.own[crow] == kg.p0 + p) return;   // the digit's own limb: nothing to extend
-
-    Ctx c;
-    c.m = load_mod(ql, qh, kl, kh, crow);
-    c.tw_mont = psi_br + ((i64)crow << LOGN);
-    set_aux<DP>(c, psi_dp, crow, LOGN);
-    c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
-    c.relaxed = 1;
-    c.inv_reduce = 0;
-    const int row_start = (int)desc[p * 3 + 0], alpha = (int)desc[p * 3 + 1] & 0xff;
-    const bool wide = ((int)desc[p * 3 + 1] >> 8) & 1;
-    const i64 e_off = desc[p * 3 + 2] + crow;
-    const int t = threadIdx.x;
-    const i64 *src = state + (i64)ctu * kg.state_stride + ((i64)row_start << LOGN) + (t << G::SUB);
-    i64 *dst = tmp + ((((i64)ctu * kg.nparts + p) * kg.rows + crow) << LOGN);
-    // element e of the first step = word (e >> SUB) * 1024 + t * 2^SUB + (e & (2^SUB - 1)) of the limb
-#define LF_ONE_WORD(e) ((((e) >> G::SUB) << 10) + ((e) & ((1 << G::SUB) - 1)))
-    i64 o[32];
-    if (DP) {
-        double x[32];
-        // 8 words at a time (the digit loop inside): at most 8 loads in flight beside the 32 accumulated words
-#pragma unroll
-        for (int g0 = 0; g0 < 32; g0 += 8) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) x[g0 + k] = 0.0;
-            for (int i = 0; i < alpha; ++i) {
-                const double cst = Ed[e_off + (i64)i * kg.rows];                     // wave-uniform: scalar loads
-                const i64 *rowi = src + ((i64)i << LOGN);
-                if (!wide) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)   // signed digit words (|y| < 2^43): the formula is sign-agnostic
-                        x[g0 + k] += dp_mulmod_bal(dp_from_signed(rowi[LF_ONE_WORD(g0 + k)]), cst, c.d);
-                } else {
-                    const double cst31 = dp_mulmod(cst, 2147483648.0, c.d);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {   // 60-bit digit words: 31-bit halves through the native 32-bit conversions
-                        const i64 y = rowi[LF_ONE_WORD(g0 + k)];
-                        x[g0 + k] += dp_mulmod_bal((double)(int)(y >> 31), cst31, c.d) + dp_mulmod_bal((double)(unsigned)(y & 0x7fffffffll), cst, c.d);
-                    }
-                }
-            }
-        }
-        one_fwd_steps<ArithDpR, LOGN>(reinterpret_cast<double *>(sm), x, t, c);
-#pragma unroll
-        for (int e = 0; e < 32; ++e) o[e] = dp_to_word(dp_reduce(x[e], c.d.q, c.d.qinv));
-    } else {
-        i64 w[32];
-        if (wide && alpha > 1) {   // several 60-bit limbs in one digit (no preset has that): term by term, as the reference
-#pragma unroll
-            for (int e = 0; e < 32; ++e) w[e] = 0;
-            for (int i = 0; i < alpha; ++i) {
-                const i64 cst = E[e_off + (i64)i * kg.rows];
-                const i64 *rowi = src + ((i64)i << LOGN);
-#pragma unroll
-                for (int e = 0; e < 32; ++e) {
-                    const i64 v = mm62s(rowi[LF_ONE_WORD(e)], cst, c.m.q, c.m.k);
-                    w[e] = i == 0 ? v : csub(w[e] + v, c.m.q2);
-                }
-            }
-        } else {
-            // sum_i y_i * (L_{i-1} R^2 mod q) in 128 bits, ONE REDC per word (see ks_ext_body); 8 words at a time
-#pragma unroll
-            for (int g0 = 0; g0 < 32; g0 += 8) {
-                i128 acc[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[k] = 0;
-                for (int i = 0; i < alpha; ++i) {
-                    const i64 cst = E[e_off + (i64)i * kg.rows];
-                    const i64 *rowi = src + ((i64)i << LOGN);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[k] += (i128)rowi[LF_ONE_WORD(g0 + k)] * (i128)cst;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) w[g0 + k] = redc62_wide(acc[k], c.m.q, c.m.k);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 32; ++e) w[e] = w[e] < 0 ? w[e] + c.m.q2 : w[e];   // residues only: fold into [0, 2q)
-        one_fwd_steps<ArithShoup, LOGN>(sm, w, t, c);
-#pragma unroll
-        for (int e = 0; e < 32; ++e) o[e] = ArithShoup::canon(c, w[e]);
-    }
-#undef LF_ONE_WORD
-    lds_barrier();   // the store transposition reuses the LDS of the half-wave transposes of OTHER waves' neighbours
-    one_store<LOGN>(sm, o, dst, t);
-}
-
-#ifdef LF_ANALYZE
-template <bool DP, int LOGN>
-__global__ void __launch_bounds__(OneGeom<LOGN>::T, 4) ks_ext1_single(const i64 *__restrict__ state, i64 *__restrict__ tmp, KsGeom kg,
-                                                                      RowList rl, const i64 *__restrict__ desc,
-                                                                      const i64 *__restrict__ E, const double *__restrict__ Ed,
-                                                                      const i64 *__restrict__ psi_br, const double *__restrict__ psi_dp,
-                                                                      const i64 *__restrict__ ql, const i64 *__restrict__ qh,
-                                                                      const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
-    __shared__ i64 sm[OneGeom<LOGN>::LDS_WORDS];
-    ks_ext1_body<DP, LOGN>(sm, blockIdx.x, state, tmp, kg, rl, desc, E, Ed, psi_br, psi_dp, ql, qh, kl, kh);
-}
-template __global__ void ks_ext1_single<true, 15>(const i64 *, i64 *, KsGeom, RowList, const i64 *, const i64 *, const double *, const i64 *, const double *, const i64 *, const i64 *, const i64 *, const i64 *);
-template __global__ void ks_ext1_single<false, 15>(const i64 *, i64 *, KsGeom, RowList, const i64 *, const i64 *, const double *, const i64 *, const double *, const i64 *, const i64 *, const i64 *, const i64 *);
-#endif
-
-template <int LOGN>
-__global__ void __launch_bounds__(OneGeom<LOGN>::T, 4) ks_ext1_mixed(const i64 *__restrict__ state, i64 *__restrict__ tmp, KsGeom kg,
-                                                                      ClassLists cl, const i64 *__restrict__ desc,
-                                                                      const i64 *__restrict__ E, const double *__restrict__ Ed,
-                                                                      const i64 *__restrict__ psi_br, const double *__restrict__ psi_dp,
-                                                                      const i64 *__restrict__ ql, const i64 *__restrict__ qh,
-                                                                      const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
-    __shared__ i64 sm[OneGeom<LOGN>::LDS_WORDS];
-    const int b = blockIdx.x;
-    if (b < cl.in_blocks) {
-        if (b < cl.in_real) ks_ext1_body<false, LOGN>(sm, b, state, tmp, kg, cl.in, desc, E, Ed, psi_br, psi_dp, ql, qh, kl, kh);
-    } else {
-        ks_ext1_body<true, LOGN>(sm, b - cl.in_blocks, state, tmp, kg, cl.dp, desc, E, Ed, psi_br, psi_dp, ql, qh, kl, kh);
-    }
-}
-
 // The key (gold: 429 MB per key switch) is read exactly once: nontemporal loads (global_load_dwordx4 .. nt) keep it
 // from displacing the digits, which the forward pass has just written, out of L2 / Infinity Cache
 // (measured at gold: 124.8 -> 96.2 us together with one 16-byte column per thread instead of two).
@@ -666,14 +522,6 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
     }
 }
 
-// (digit, limb) pairs from which the key switch of a logN <= 15 ring takes the one-launch form (lf_tune).  Measured on
-// MI355X (tools/one_probe.py, profiles/r03_one_launch_ab.txt) the one-launch form LOSES at every preset size, so the
-// default leaves it off: silver rotate 149 vs 115 us, cc_mult 192 vs 154 us, 16 rotations under one key 74 vs 68 us each;
-// bronze 85 vs 68, 115 vs 94, 31-34 vs 32.  The kernel takes 80 us for silver's 152 pairs against 19 + 27 us for the two
-// launches it replaces: these transforms are bound by instruction issue, not by HBM, so the halved traffic buys nothing,
-// while a 1024-thread block at 128 VGPRs is alone on its CU (nothing covers its load phase, its four block barriers and
-// the half-occupancy exchange rounds) and 152 blocks leave 104 CUs idle where the two-pass form has 1 216 small ones.
-int g_ks_one_min_pairs = 0x7fffffff;
 // largest number of leading stages (logN - 12) whose extension + strided pass runs as the column kernel (lf_tune).
 // With the digit loop as a runtime loop (R loads in flight, 100 VGPRs at R = 16) the column form also wins at logN 16:
 // gold cc_mult 2 104-2 130 -> 2 168-2 183 ops/s, rotate 2 653-2 695 -> 2 733-2 763, 64 rotations under one key
@@ -701,21 +549,6 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
     const unsigned tiles = 1u << (logN - tl);
     const unsigned polys = (unsigned)nparts * (unsigned)nct;   // extended digits of all ciphertexts: one stack
     const bool mixed = dp.n && in.n;   // both arithmetic classes in one launch per step
-    // logN 13 .. 15, opt-in (lf_tune; off by default, see g_ks_one_min_pairs): extension + the WHOLE transform in one
-    // launch, a block per (digit, limb) pair
-    if (logN <= 15 && (int)polys * rows >= g_ks_one_min_pairs) {
-        const ClassLists cl = class_lists(in, dp, polys * (unsigned)in.n);
-        const dim3 grid((unsigned)cl.in_blocks + polys * (unsigned)dp.n);
-#define LF_ONE_CASE(LN)                                                                                                \
-    case LN:                                                                                                           \
-        hipLaunchKernelGGL((ks_ext1_mixed<LN>), grid, dim3(OneGeom<LN>::T), 0, st, (const i64 *)state, (i64 *)tmp, kg, cl, \
-                           (const i64 *)desc, (const i64 *)E, Ed, (const i64 *)psi_br, psi_dp, (const i64 *)ql,        \
-                           (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);                                        \
-        break;
-        switch (logN) { LF_ONE_CASE(13) LF_ONE_CASE(14) LF_ONE_CASE(15) }
-#undef LF_ONE_CASE
-        return (int)hipGetLastError();
-    }
     // K2: extend + strided pass — as one register step per column when the strided pass has at most 4 stages
     // (measured on MI355X, extension kernel alone: silver / logN 15 22.5 -> 20.0 us; gold / logN 16 see g_ks_ext_cols_max)
     if (S1 <= g_ks_ext_cols_max) {
@@ -832,7 +665,7 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
 extern "C" {
 
 int lf_tune(int which, int value) {
-    int *knob = which == LF_TUNE_KS_ONE_MIN_PAIRS ? &g_ks_one_min_pairs : which == LF_TUNE_KS_EXT_COLS_MAX ? &g_ks_ext_cols_max : nullptr;
+    int *knob = which == LF_TUNE_KS_EXT_COLS_MAX ? &g_ks_ext_cols_max : nullptr;
     if (!knob) return -1;
     const int old = *knob;
     if (value >= 0 && !(which == LF_TUNE_KS_EXT_COLS_MAX && value > 4)) *knob = value;

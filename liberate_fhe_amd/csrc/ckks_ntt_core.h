@@ -1074,7 +1074,7 @@ __device__ __forceinline__ i64 *uniform_row(i64 *base, i64 off) {
 
 // Streaming accesses (the `nt` bit of global loads / stores): words a pass reads once and writes once should not displace
 // the twiddle rows — as many bytes per tile as the data, re-read by every polynomial of the batch — from L1 / L2.
-// In-process A/B on the headline step (tools/ab_inproc.py, -DLF_NT_OFF build beside this one): whole step -2.8 %, tiled pass
+// In-process A/B on the headline step (tools/ab_inproc.py, a build with the four switches below false beside this one): whole step -2.8 %, tiled pass
 // -2.3 %, column pass -2.0 %.  Exact transforms (the standalone lf_ntt / lf_intt of large batches) stream everything.
 // Relaxed ones are the engine's internal passes, where the NEXT kernel may still find a pass's output in cache: loads of the
 // tiled pass, the extension kernel's stores and the inverse passes stream (gold rotate -1 %, silver -3 %); the tiled pass's
@@ -1092,17 +1092,10 @@ __device__ __forceinline__ void nt_store2(i64 *p, const longlong2 &v) {
     t.x = v.x, t.y = v.y;
     __builtin_nontemporal_store(t, reinterpret_cast<ll2_t *>(p));
 }
-#ifdef LF_NT_OFF   // A/B builds only
-#define NT_EXACT false
-#define NT_RLOAD false
-#define NT_INV false
-#define NT_KS_EXT false
-#else
 #define NT_EXACT true
 #define NT_RLOAD true
 #define NT_INV true
 #define NT_KS_EXT true
-#endif
 #define NT_RSTORE false
 #define NT_RCOLS false
 // (nt: wave-uniform)

@@ -286,6 +286,9 @@ class HipBackend:
         plan.psi, plan.ipsi = _p(psi), _p(ipsi)
         plan.psi_dp = twiddles.dp_pointer(psi, c.ql, c.qh, c.kl, c.kh, dev, st)
         plan.ipsi_dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
+        # the plan outlives this call (the engine caches it per level): it holds the auxiliary twins its two raw
+        # addresses point into, so a rebuilt twin (new table version) can never leave the plan reading freed memory
+        keep += [twiddles.twin_of(psi), twiddles.twin_of(ipsi)]
         return plan, keep
 
     def cc_mult_evk(self, plan, ins, row0s, key, first_part, row_off, out):

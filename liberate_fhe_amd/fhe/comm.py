@@ -48,6 +48,14 @@ class DistComm:
         self._ops = {}
         self.local_device = local_device if local_device is not None else (
             f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cpu")
+        self.backend_name = str(dist.get_backend(group))
+        # gloo moves host memory only: device buffers need RCCL ("nccl") — or, on a one-GPU rehearsal box, a transport
+        # underneath dist.batch_isend_irecv that declares it stages device memory (tests/gloo_device_p2p.py).  Fail HERE
+        # with the reason, not deep inside the first key switch with the backend's own message.
+        if str(self.local_device).startswith("cuda") and "gloo" in self.backend_name and "nccl" not in self.backend_name \
+                and not getattr(dist.batch_isend_irecv, "moves_device_memory", False):
+            raise RuntimeError("DistComm: the process group's backend is gloo, which cannot move the engine's DEVICE buffers "
+                               "point to point; initialise torch.distributed with backend 'nccl' (RCCL) for GPU ranks")
 
     def _global(self, group_rank):
         """torch.distributed addresses peers by GLOBAL rank; the engine speaks in ranks of its group."""

@@ -57,6 +57,15 @@ def dp_pointer(table: torch.Tensor, ql, qh, kl, kh, dev: int, stream: int) -> in
     return ptr
 
 
+def twin_of(table: torch.Tensor) -> torch.Tensor:
+    """The auxiliary tensor the last dp_pointer(table, ...) address points into (for callers that cache the raw address:
+    holding the twin keeps that address valid)."""
+    hit = _views.get(id(table))
+    if hit is None or hit[0]() is not table:
+        raise KeyError("dp_pointer() has not been called for this table")
+    return hit[4]
+
+
 _host_q = {}
 
 

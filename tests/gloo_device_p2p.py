@@ -49,6 +49,7 @@ def install():
         return [_StagedWork(real(host_ops), landings)]
 
     staged._lf_staged = True
+    staged.moves_device_memory = True      # what DistComm looks for on a gloo group with device buffers
     staged._lf_log = log
     dist.batch_isend_irecv = staged
     return log

@@ -52,6 +52,23 @@ def test_product_package_never_imports_the_oracle():
                 assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src.replace("checker", ""), f
 
 
+def test_every_include_and_every_source_file_is_part_of_the_library_digest():
+    """build() rebuilds (and bench.py drops stamped profiles) when library_digest() changes: every file the library is
+    compiled from must be in it — each #include "..." of csrc/ and each .hip / .h file that exists there."""
+    import __graft_entry__ as g
+    csrc = os.path.join(ROOT, "liberate_fhe_amd", "csrc")
+    known = {os.path.realpath(p) for p in g.library_sources()}
+    for f in os.listdir(csrc):
+        if not f.endswith((".hip", ".h")):
+            continue
+        path = os.path.join(csrc, f)
+        assert os.path.realpath(path) in known, f"{f} exists in csrc/ but is not a library source"
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), flags=re.M):
+            target = os.path.realpath(os.path.join(csrc, inc))
+            assert os.path.exists(target), f"{f} includes {inc}: no such file"
+            assert target in known, f"{f} includes {inc}, which library_sources() does not list"
+
+
 def test_library_reads_no_environment_variables():
     """A drop-in library's results must not depend on ambient env vars: no getenv anywhere in the C sources."""
     csrc = os.path.join(ROOT, "liberate_fhe_amd", "csrc")
@@ -138,10 +155,7 @@ def test_unpickler_accepts_what_the_reference_load_accepts(tmp_path):
 def test_lf_tune_is_a_pure_host_call():
     """Launch-shape thresholds: read, set, restore, unknown knob -> -1; no device is touched."""
     from liberate_fhe_amd._native import lib
-    old = lib.lf_tune(0, -1)
-    assert old > 0
-    assert lib.lf_tune(0, 123) == old and lib.lf_tune(0, -1) == 123
-    lib.lf_tune(0, old)
+    assert lib.lf_tune(0, -1) == -1     # the round-3 one-launch knob is gone
     cols = lib.lf_tune(1, -1)
     assert 0 <= cols <= 4
     assert lib.lf_tune(1, 9) == cols and lib.lf_tune(1, -1) == cols      # out of range: ignored

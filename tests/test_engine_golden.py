@@ -428,36 +428,6 @@ def test_hip_native_op_entries_equal_the_step_by_step_engine(name):
     assert outs[0] == outs[1]
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("params", [dict(logN=13, scale_bits=30, num_scales=6, num_special_primes=2, is_secured=False),
-                                    dict(logN=13, scale_bits=45, num_scales=6, num_special_primes=2, is_secured=False),
-                                    dict(logN=13, num_scales=9, num_special_primes=3, is_secured=False),
-                                    dict(logN=14, num_special_primes=1), dict(logN=15, num_special_primes=2)])
-def test_one_launch_key_switch_equals_two_pass_form(params):
-    """The key switch of a logN 13..15 ring with extension + the whole forward transform in ONE launch per (digit, limb)
-    pair (csrc/ckks_ntt_one.h: the limb in the registers of N / 32 threads) against the column kernel + tiled pass, forced
-    either way through lf_tune: same words for cc_mult, rotate, conjugate and the batched forms, at two levels."""
-    from liberate_fhe_amd._native import lib
-    from liberate_fhe_amd.fhe import ckks_engine
-    outs = []
-    old = lib.lf_tune(0, -1)
-    try:
-        for min_pairs in (1, 1 << 30):
-            lib.lf_tune(0, min_pairs)
-            eng = ckks_engine(devices=["cuda:0"], **params)
-            evk, rotk = synth.key_switch_key(eng, 5), synth.key_switch_key(eng, 6, origin="rotation key:3")
-            conjk = synth.key_switch_key(eng, 7, origin="conjugation key")
-            res = []
-            for level in (0, 2):
-                a, b = synth.ciphertext(eng, 50 + level, level), synth.ciphertext(eng, 60 + level, level)
-                res += [eng.cc_mult(a, b, evk), eng.rotate_single(a, rotk), eng.conjugate(a, conjk)]
-                res += eng.rotate_single_batch([a, b, a, b, a], rotk) + eng.cc_mult_batch([(a, b), (b, a), (a, a)], evk)
-            outs.append([digest(x) for x in res])
-    finally:
-        lib.lf_tune(0, old)
-    assert outs[0] == outs[1]
-
-
 def _reference_shaped_switcher(eng, a, ksk, level):
     """create_switcher as the reference composes it from its step methods (eng.py:746-904) on ONE device: digits per part,
     extension + NTT + key products per part, sums, inverse transform, division by P through the checker's chain."""

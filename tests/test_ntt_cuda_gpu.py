@@ -344,19 +344,18 @@ def test_ntt_pass_entry_is_the_two_halves_of_lf_ntt():
 
 @pytest.mark.parametrize("logN", [13, 14, 15, 16])
 @pytest.mark.parametrize("flags", [0, 1])
-def test_large_batch_co_scheduled_passes_equal_the_two_separate_passes(mods, logN, flags):
-    """Large batches (4 chunks' worth, the last one shorter): with -DLF_NTT_DUO > 1 they run as chunks whose tiled
-    pass shares a launch with the next chunk's column pass (ntt_fwd_duo; off in the shipped build, DESIGN.md §4 —
-    tools/mkvariant.sh + LF_HIP_LIB run this test against such a build).  Words must equal the two plain passes launched one after the other (lf_ntt_pass, which the
-    previous test ties to lf_ntt at small batch), and the oracle on polynomials of the first, a middle and the
-    last (shorter) chunk — including tiles that leave the fast form (signed words) inside the merged launch."""
+def test_large_batch_transform_equals_its_two_passes_and_the_oracle(mods, logN, flags):
+    """Large batches (16 384+ tiles, an odd polynomial count): whatever launch shapes lf_ntt picks for them (8 tiles per
+    block from 32 768 tiles up) must give the words of the two plain passes launched one after the other (lf_ntt_pass,
+    which the previous test ties to lf_ntt at small batch), and the oracle's on the first, a middle and the last
+    polynomial — including tiles that leave the fast form (signed words) inside the big launch."""
     from liberate_fhe_amd._native import lib, check
     from liberate_fhe_amd.ntt import twiddles
     nc, orc = mods
     lim = Limbs(logN, pick_primes(logN, 3, 2))
     rows = lim.rows
     min_polys = -(-4096 // (rows << (logN - 12)))
-    batch = 4 * min_polys + 3                       # 4 chunks, the last one shorter
+    batch = 4 * min_polys + 3
     psi_np = lim.mont_tables()[0]
     psi, q2 = dev(psi_np), dev(lim._2q)
     c = [dev(v) for v in (lim.ql, lim.qh, lim.kl, lim.kh)]

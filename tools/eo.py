@@ -1,5 +1,5 @@
 """Engine-op rates on this GPU (the figures bench.py reports as `extra`), without the NTT / CPU legs:
-    python tools/eo.py [quick] [--ks-one-min PAIRS]"""
+    python tools/eo.py [quick] [--ext-cols-max K]"""
 import json
 import os
 import sys
@@ -11,9 +11,6 @@ import bench  # noqa: E402
 import __graft_entry__ as g  # noqa: E402
 
 g.build()
-if "--ks-one-min" in sys.argv:   # launch-shape threshold of the one-launch key-switch transform (lf_tune)
-    from liberate_fhe_amd._native import lib
-    lib.lf_tune(0, int(sys.argv[sys.argv.index("--ks-one-min") + 1]))
 if "--ext-cols-max" in sys.argv:   # largest logN - 12 whose extension runs as the column kernel (lf_tune)
     from liberate_fhe_amd._native import lib
     lib.lf_tune(1, int(sys.argv[sys.argv.index("--ext-cols-max") + 1]))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Build a variant of libckks_hip.so for an in-box A/B (tools/ab_bench.sh, tools/ab_engine_ops.sh):  tools/mkvariant.sh <name> [git-rev|-] [extra hipcc flags...]
+# Build a variant of libckks_hip.so for an in-box A/B (tools/ab_ntt.sh, tools/ab_inproc.py, tools/ab_engine_ops.sh):  tools/mkvariant.sh <name> [git-rev|-] [extra hipcc flags...]
 #   rev "-" = the working tree.  Output: liberate_fhe_amd/csrc/variants/lib_<name>.so (git-ignored, travels with gpurun)
 set -e
 NAME=$1; REV=${2:--}; shift 2 || true
