@@ -223,9 +223,25 @@ int lf_ks_moddown(const int64_t *s, int64_t *out, const int64_t *addend, int ell
  *   q_host     HOST primes of the `rows` limbs (required: selects the arithmetic class per limb) */
 int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,
                const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
-               int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
+               int key_format, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
                const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
                const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+
+/* Key formats of the fused key-switch entries (`key_format`).  The inner product with the key is the one launch of a key
+ * switch that runs at the HBM rate, and most of what it reads is the key (gold: 450 of 687 MB), read once per call and never
+ * modified: a binding may therefore keep a second, smaller copy of a key for these entries.
+ *   LF_KEY_RAW     the reference's layout: 64-bit words, ksk[p*part_stride + comp*comp_stride + (row_off + r)*N + j];
+ *   LF_KEY_PLANES  what lf_key_planes writes: same strides and row slots, but a row whose prime is below 2^41 holds,
+ *                  in the first 6 N bytes of its slot, N 32-bit low words followed by N 16-bit high words of the
+ *                  CANONICAL residues; rows of larger primes are raw.  N % 1024 == 0, 16-byte aligned base and strides.
+ * The sums are the same residues either way, so every output word of the entries below is identical.
+ * lf_key_planes converts one block of `rows` rows (any lazy / signed-lazy words) from src to dst (dst != src, both 16-byte
+ * aligned; ql / qh: DEVICE 31-bit halves of the rows' primes as everywhere in this header); a key is converted block by
+ * block — one call per (part, component) — into a tensor of the raw key's shape. */
+#define LF_KEY_RAW 0
+#define LF_KEY_PLANES 1
+int lf_key_planes(const int64_t *src, int64_t *dst, int rows, int64_t N, const int64_t *ql, const int64_t *qh, int device,
+                  void *stream);
 
 /* lf_ks_digits(_galois) of `count` (<= 8) polynomials in one launch: a / state are HOST arrays of device pointers
  * (gal_pinv = 0: no Galois map). */
@@ -239,7 +255,7 @@ int lf_ks_digits_batch(const int64_t *const *a, int64_t *const *state, int count
  * [nct][nparts][rows][N]; s out [nct][2][rows][N].  Results equal nct calls of lf_ks_core. */
 int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int nparts, int rows, int logN, const int64_t *desc,
                      const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
-                     int64_t row_off, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
+                     int64_t row_off, int key_format, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
                      const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
                      const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 
@@ -254,7 +270,7 @@ int lf_ks_fwd(const int64_t *state, int nparts, int rows, int logN, const int64_
               int64_t *tmp, const int64_t *psi_br, const double *psi_dp, const int64_t *q_host, const int64_t *ql,
               const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 int lf_ks_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
-               const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
+               int key_format, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
                const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
                void *stream);
 
@@ -268,7 +284,7 @@ int lf_ks_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_
  * addend, is the relinearised ciphertext: the same canonical words as the reference's chain. */
 int lf_relin_core_batch(const int64_t *state, int64_t state_stride, int nct, int nparts, int rows, int logN, const int64_t *desc,
                         const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
-                        int64_t row_off, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
+                        int64_t row_off, int key_format, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
                         const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *x, int64_t x_ct_stride,
                         const int64_t *PR, int ell, const uint8_t *own, const int64_t *q_host, const int64_t *ql, const int64_t *qh,
                         const int64_t *kl, const int64_t *kh, int device, void *stream);
@@ -282,7 +298,7 @@ int lf_relin_fwd(const int64_t *state, int first, int nparts, int rows, int logN
                  const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
                  void *stream);
 int lf_relin_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
-                  const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
+                  int key_format, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
                   const int64_t *x, const int64_t *PR, int ell, const uint8_t *own, const int64_t *q_host, const int64_t *ql,
                   const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 
@@ -358,16 +374,17 @@ typedef struct lf_ks_plan {
 
 /* ckks_engine.cc_mult(a, b, evk) with relinearisation, level l -> l + 1 (ckks_engine.py:1072-1151): in[0..3] = first
  * SURVIVING row of a.c0, a.c1, b.c0, b.c1 (HOST array of device pointers, as lf_rescale_batch), row0[0..3] their dropped
- * rows; the plan describes level l + 1; key addressed as in lf_ks_inner; out0 / out1 [ell][N] canonical. */
+ * rows; the plan describes level l + 1; key addressed as in lf_ks_inner, in `key_format`; out0 / out1 [ell][N] canonical. */
 int lf_cc_mult_evk(const lf_ks_plan *plan, const int64_t *const *in, const int64_t *const *row0, const int64_t *ksk,
-                   int64_t part_stride, int64_t comp_stride, int64_t row_off, int64_t *out0, int64_t *out1, void *stream);
+                   int64_t part_stride, int64_t comp_stride, int64_t row_off, int key_format, int64_t *out0, int64_t *out1,
+                   void *stream);
 
 /* ckks_engine.switch_key / rotate_single / conjugate of a coefficient-domain ciphertext (c0, c1), [ell][N] each
  * (ckks_engine.py:939-961, 1180-1206, 1718-1734): out = (c0(X^p) + ks_0, ks_1) with ks = key switch of c1(X^p);
  * gal_pinv = p^-1 mod 2N (0: no automorphism), gal_canonical != 0: rotate_single's make_unsigned + reduce_2q. */
 int lf_switch_key(const lf_ks_plan *plan, const int64_t *c0, const int64_t *c1, int64_t gal_pinv, int gal_canonical,
-                  const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off, int64_t *out0, int64_t *out1,
-                  void *stream);
+                  const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off, int key_format, int64_t *out0,
+                  int64_t *out1, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Samplers: the reference's csprng extensions, src/liberate/csprng/.

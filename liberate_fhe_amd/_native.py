@@ -64,14 +64,15 @@ _SIGNATURES = {
     "lf_discrete_gaussian_fast": [_P, _P, _L, _P, _I, _I, _U, _I, _P],
     "lf_discrete_gaussian": [_P, _L, _P, _I, _I, _I, _P],
     "lf_randround": [_P, _P, _L, _I, _P],
-    "lf_ks_core_batch": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lf_key_planes": [_P, _P, _I, _L, _P, _P, _I, _P],
+    "lf_ks_core_batch": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_ks_fwd": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
-    "lf_ks_tail": [_I, _I, _I, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lf_ks_tail": [_I, _I, _I, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_intt_mul": [_P, _P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
-    "lf_relin_core_batch": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lf_relin_core_batch": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_relin_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
-    "lf_relin_tail": [_I, _I, _I, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
-    "lf_ks_core": [_P, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lf_relin_tail": [_I, _I, _I, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lf_ks_core": [_P, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
 }
 
 
@@ -85,8 +86,8 @@ class KsPlan(ctypes.Structure):
                                      "state", "ext", "sum", "md_ws", "x4", "d2")])
 
 
-_SIGNATURES["lf_cc_mult_evk"] = [ctypes.POINTER(KsPlan), _P, _P, _P, _L, _L, _L, _P, _P, _P]
-_SIGNATURES["lf_switch_key"] = [ctypes.POINTER(KsPlan), _P, _P, _L, _I, _P, _L, _L, _L, _P, _P, _P]
+_SIGNATURES["lf_cc_mult_evk"] = [ctypes.POINTER(KsPlan), _P, _P, _P, _L, _L, _L, _I, _P, _P, _P]
+_SIGNATURES["lf_switch_key"] = [ctypes.POINTER(KsPlan), _P, _P, _L, _I, _P, _L, _L, _L, _I, _P, _P, _P]
 
 for _name, _args in _SIGNATURES.items():
     _fn = getattr(lib, _name)
@@ -104,5 +105,7 @@ def check(code: int, what: str):
 
 
 EXPORTED = tuple(_SIGNATURES)
+LF_KEY_RAW = 0
+LF_KEY_PLANES = 1
 LF_NTT_RELAXED = 1
 LF_NTT_PLAIN = 2

@@ -20,7 +20,8 @@ static int plan_ok(const lf_ks_plan *p) {
 }
 
 int lf_cc_mult_evk(const lf_ks_plan *p, const int64_t *const *in, const int64_t *const *row0, const int64_t *ksk,
-                   int64_t part_stride, int64_t comp_stride, int64_t row_off, int64_t *out0, int64_t *out1, void *stream) {
+                   int64_t part_stride, int64_t comp_stride, int64_t row_off, int key_format, int64_t *out0, int64_t *out1,
+                   void *stream) {
     if (!plan_ok(p) || !p->rescale_scales || !p->PR || !p->x4 || !p->d2 || !in || !row0 || !ksk || !out0 || !out1) return LF_ERR_ARG;
     const int ell = p->ell, rows = p->ell + p->K, logN = p->logN, dev = p->device;
     const int64_t N = (int64_t)1 << logN, poly = (int64_t)ell * N;
@@ -37,7 +38,7 @@ int lf_cc_mult_evk(const lf_ks_plan *p, const int64_t *const *in, const int64_t 
     if (int e = lf_ks_digits(p->d2, p->state, p->dig_nparts, p->dig_desc, p->dig_tab, N, p->ql, p->qh, p->kl, p->kh, dev, stream))
         return e;
     if (int e = lf_relin_core_batch(p->state, 0, 1, p->nparts, rows, logN, p->ext_desc, p->E, p->Ed, ksk, part_stride, comp_stride,
-                                    row_off, p->ext, p->sum, p->psi, p->psi_dp, p->ipsi, p->ipsi_dp, p->Ninv, p->x4, 0, p->PR, ell,
+                                    row_off, key_format, p->ext, p->sum, p->psi, p->psi_dp, p->ipsi, p->ipsi_dp, p->Ninv, p->x4, 0, p->PR, ell,
                                     p->own, p->q_host, p->ql, p->qh, p->kl, p->kh, dev, stream))
         return e;
     const int64_t *ss[2] = {p->sum, p->sum + (int64_t)rows * N};
@@ -51,8 +52,8 @@ int lf_cc_mult_evk(const lf_ks_plan *p, const int64_t *const *in, const int64_t 
 }
 
 int lf_switch_key(const lf_ks_plan *p, const int64_t *c0, const int64_t *c1, int64_t gal_pinv, int gal_canonical,
-                  const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off, int64_t *out0, int64_t *out1,
-                  void *stream) {
+                  const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off, int key_format, int64_t *out0,
+                  int64_t *out1, void *stream) {
     if (!plan_ok(p) || !c1 || !ksk || !out0 || !out1) return LF_ERR_ARG;
     const int ell = p->ell, rows = p->ell + p->K, logN = p->logN, dev = p->device;
     const int64_t N = (int64_t)1 << logN;
@@ -60,7 +61,7 @@ int lf_switch_key(const lf_ks_plan *p, const int64_t *c0, const int64_t *c1, int
     if (int e = lf_ks_digits_galois(c1, p->state, p->dig_nparts, p->dig_desc, p->dig_tab, N, gal_pinv, g2q, p->ql, p->qh, p->kl, p->kh,
                                     dev, stream))
         return e;
-    if (int e = lf_ks_core(p->state, p->nparts, rows, logN, p->ext_desc, p->E, p->Ed, ksk, part_stride, comp_stride, row_off, p->ext,
+    if (int e = lf_ks_core(p->state, p->nparts, rows, logN, p->ext_desc, p->E, p->Ed, ksk, part_stride, comp_stride, row_off, key_format, p->ext,
                            p->sum, p->psi, p->psi_dp, p->ipsi, p->ipsi_dp, p->Ninv, p->q_host, p->ql, p->qh, p->kl, p->kh, dev, stream))
         return e;
     const int64_t *ss[2] = {p->sum, p->sum + (int64_t)rows * N};

@@ -11,7 +11,7 @@ import ctypes
 
 import torch
 
-from .._native import lib, check, KsPlan
+from .._native import lib, check, KsPlan, LF_KEY_PLANES
 from ..ntt import ntt_cuda, twiddles
 
 
@@ -208,6 +208,22 @@ class HipBackend:
         check(lib.lf_ks_inner(_p(ext), base, part_stride, comp_stride, row_off, _p(s0), _p(s1), nparts, rows, N,
                               *c.mont(), dev, st), "lf_ks_inner")
 
+    @staticmethod
+    def _kfmt(key):
+        """Format of a packed key tensor (LF_KEY_RAW unless key_planes() made it)."""
+        return getattr(key, "lf_key_format", 0)
+
+    def key_planes(self, src, dst, c: Consts):
+        """One [rows, N] block of a key (any lazy words) -> the planes format the fused key-switch entries read with
+        key_format = LF_KEY_PLANES (include/ckks_hip.h): fp64-class rows as 32-bit + 16-bit planes of canonical residues."""
+        dev, st = _ds(dst)
+        check(lib.lf_key_planes(_p(src), _p(dst), src.size(0), src.size(1), _p(c.ql), _p(c.qh), dev, st), "lf_key_planes")
+
+    @staticmethod
+    def mark_planes(t):
+        t.lf_key_format = LF_KEY_PLANES
+        return t
+
     fused_ks_min_logN = 13   # lf_ks_core needs a two-pass ring degree
     relin_fold = True        # cc_mult's d0 / d1 folded into the key-switch sums (lf_intt_mul, lf_relin_*)
 
@@ -224,12 +240,12 @@ class HipBackend:
         if fold is not None:
             x, PR, own = fold
             check(lib.lf_relin_core_batch(_p(state), 0, 1, nparts, rows, logN, _p(desc), _p(E), _pd(Ed), base, part_stride,
-                                          comp_stride, row_off, _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
+                                          comp_stride, row_off, self._kfmt(key), _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
                                           _p(x), 0, _p(PR), x.size(1), _pb(own), c.qptr(), *c.mont(), dev, st),
                   "lf_relin_core_batch")
             return
         check(lib.lf_ks_core(_p(state), nparts, rows, logN, _p(desc), _p(E), _pd(Ed), base, part_stride, comp_stride,
-                             row_off, _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
+                             row_off, self._kfmt(key), _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
                              c.qptr(), *c.mont(), dev, st), "lf_ks_core")
 
     def ks_fwd(self, state, first, count, rows, logN, desc, E, Ed, tmp, psi, c: Consts, own=None):
@@ -253,10 +269,10 @@ class HipBackend:
         ipsi_dp = twiddles.dp_pointer(ipsi, c.ql, c.qh, c.kl, c.kh, dev, st)
         if fold is not None:
             x, PR, own = fold
-            check(lib.lf_relin_tail(nparts, rows, logN, base, part_stride, comp_stride, row_off, _p(tmp), _p(s), _p(ipsi), ipsi_dp,
+            check(lib.lf_relin_tail(nparts, rows, logN, base, part_stride, comp_stride, row_off, self._kfmt(key), _p(tmp), _p(s), _p(ipsi), ipsi_dp,
                                     _p(Ninv), _p(x), _p(PR), x.size(1), _pb(own), c.qptr(), *c.mont(), dev, st), "lf_relin_tail")
             return
-        check(lib.lf_ks_tail(nparts, rows, logN, base, part_stride, comp_stride, row_off, _p(tmp), _p(s), _p(ipsi), ipsi_dp,
+        check(lib.lf_ks_tail(nparts, rows, logN, base, part_stride, comp_stride, row_off, self._kfmt(key), _p(tmp), _p(s), _p(ipsi), ipsi_dp,
                              _p(Ninv), c.qptr(), *c.mont(), dev, st), "lf_ks_tail")
 
     # ---- whole ops behind one native call (lf_cc_mult_evk / lf_switch_key over an lf_ks_plan) ------------------------
@@ -297,7 +313,7 @@ class HipBackend:
         part_stride, comp_stride = key.stride(0), key.stride(1)
         base = key.data_ptr() + first_part * part_stride * 8
         plane = out.stride(0) * 8
-        check(lib.lf_cc_mult_evk(ctypes.byref(plan), ins, row0s, base, part_stride, comp_stride, row_off, out.data_ptr(),
+        check(lib.lf_cc_mult_evk(ctypes.byref(plan), ins, row0s, base, part_stride, comp_stride, row_off, self._kfmt(key), out.data_ptr(),
                                  out.data_ptr() + plane, st), "lf_cc_mult_evk")
 
     def switch_key_native(self, plan, c0, c1, pinv, canonical, key, first_part, row_off, out):
@@ -306,7 +322,7 @@ class HipBackend:
         base = key.data_ptr() + first_part * part_stride * 8
         plane = out.stride(0) * 8
         check(lib.lf_switch_key(ctypes.byref(plan), _p(c0), _p(c1), pinv, 1 if canonical else 0, base, part_stride, comp_stride,
-                                row_off, out.data_ptr(), out.data_ptr() + plane, st), "lf_switch_key")
+                                row_off, self._kfmt(key), out.data_ptr(), out.data_ptr() + plane, st), "lf_switch_key")
 
     ks_batch_sizes = (4, 2)   # ciphertexts per lf_ks_core_batch call (largest first)
 
@@ -322,12 +338,12 @@ class HipBackend:
         if fold is not None:
             x, PR, own = fold
             check(lib.lf_relin_core_batch(_p(states), states.stride(0), states.size(0), nparts, rows, logN, _p(desc), _p(E),
-                                          _pd(Ed), base, part_stride, comp_stride, row_off, _p(tmp), _p(s), _p(psi), psi_dp,
+                                          _pd(Ed), base, part_stride, comp_stride, row_off, self._kfmt(key), _p(tmp), _p(s), _p(psi), psi_dp,
                                           _p(ipsi), ipsi_dp, _p(Ninv), _p(x), x.stride(0), _p(PR), x.size(2), _pb(own), c.qptr(),
                                           *c.mont(), dev, st), "lf_relin_core_batch")
             return
         check(lib.lf_ks_core_batch(_p(states), states.stride(0), states.size(0), nparts, rows, logN, _p(desc), _p(E),
-                                   _pd(Ed), base, part_stride, comp_stride, row_off, _p(tmp), _p(s), _p(psi), psi_dp,
+                                   _pd(Ed), base, part_stride, comp_stride, row_off, self._kfmt(key), _p(tmp), _p(s), _p(psi), psi_dp,
                                    _p(ipsi), ipsi_dp, _p(Ninv), c.qptr(), *c.mont(), dev, st), "lf_ks_core_batch")
 
     def ks_moddown(self, s, out, addend, ell, K, PiR, Rs, c: Consts, PiP=None):

@@ -429,18 +429,52 @@ class ckks_engine(EvaluatorOps):
         weakref.finalize(anchor, self._key_packs.pop, key, None)
         return packs
 
+    def _planes_wanted(self):
+        """Fused key switches (two-pass ring degrees) read the key in the planes format (include/ckks_hip.h LF_KEY_PLANES:
+        the inner product with the key runs at the HBM rate and most of its bytes are key words; fp64-class rows shrink to
+        6 of 8 bytes per word).  The unfused path (logN <= 12) and checker backends read raw words."""
+        return (getattr(self.backend, "key_planes", None) is not None and self.ctx.logN >= self.backend.fused_ks_min_logN
+                and self.ctx.N % 1024 == 0)
+
+    def _planes_of(self, blocks_of_part, i, d):
+        """Planes-format tensor [parts, 2, rows, N] of local device index i from per-part (b rows, a rows) tensors."""
+        c = self._consts(d, 0, True)
+        nparts = len(blocks_of_part)
+        out = torch.empty((nparts, 2, self.ntt.stops[0][d], self.ctx.N), dtype=torch.int64, device=self.ntt.devices[d])
+        for p_, (b_rows, a_rows) in enumerate(blocks_of_part):
+            for comp, rows in enumerate((b_rows, a_rows)):
+                self.backend.key_planes(rows if rows.is_contiguous() else rows.contiguous(), out[p_, comp], c)
+        return self.backend.mark_planes(out)
+
     def _key_pack(self, ksk):
-        """Packed per-device key tensors of a key-switch key; foreign (unpacked) keys are packed once, on the
-        CURRENT stream — callers that use the pack from another stream order themselves after this call
-        (see _run_groups: it is made before the side lane is forked)."""
-        hit = self._key_packs.get(id(self._key_anchor(ksk)))
-        if hit is not None and hit["ref"]() is self._key_anchor(ksk) and (hit["own"] or hit["versions"] == self._key_versions(ksk)):
-            return hit["packs"]
+        """Packed per-device key tensors of a key-switch key, in the format the engine's key switch reads (planes for the
+        fused path, raw words otherwise); built once per key, on the CURRENT stream — callers that use the pack from
+        another stream order themselves after this call (see _run_groups: it is made before the side lane is forked).
+        A key made by this engine is a set of views of its raw pack (in-place edits land there): its planes copy is
+        rebuilt when the pack's version counter moves.  A foreign key is converted part by part, no raw copy is kept."""
+        anchor = self._key_anchor(ksk)
+        hit = self._key_packs.get(id(anchor))
+        planes = self._planes_wanted()
         loc = self._loc(0, special=True)
+        if hit is not None and hit["ref"]() is anchor:
+            if hit["own"]:
+                if not planes:
+                    return hit["packs"]
+                ver = tuple(p._version for p in hit["packs"])
+                if hit.get("planes_ver") != ver:
+                    hit["planes"] = [self._planes_of([(pk[q_, 0], pk[q_, 1]) for q_ in range(pk.size(0))], i, d)
+                                     for i, (d, pk) in enumerate(zip(loc, hit["packs"]))]
+                    hit["planes_ver"] = ver
+                return hit["planes"]
+            if hit["versions"] == self._key_versions(ksk):
+                return hit["packs"]
         packs = []
         for i, d in enumerate(loc):
-            parts = [torch.stack([part.data[0][i], part.data[1][i]]) for part in ksk.data]
-            packs.append(torch.stack(parts).contiguous())
+            if planes:
+                packs.append(self._planes_of([(part.data[0][i], part.data[1][i]) for part in ksk.data], i, d))
+            else:
+                parts = [torch.stack([part.data[0][i], part.data[1][i]]) for part in ksk.data]
+                packs.append(torch.stack(parts).contiguous())
         return self._remember_pack(ksk, packs, own=False)
 
     def release_key(self, ksk):

@@ -428,6 +428,62 @@ def test_hip_native_op_entries_equal_the_step_by_step_engine(name):
     assert outs[0] == outs[1]
 
 
+@pytest.mark.gpu
+def test_key_planes_format_words_and_results():
+    """lf_key_planes: fp64-class rows become a 32-bit plane + a 16-bit plane of the CANONICAL residues, integer-class rows
+    stay raw — checked word for word against numpy on lazy and signed-lazy inputs; and the engine gives the same digests
+    whether its key switch reads the key in the planes format (the default for two-pass ring degrees) or raw, for a key
+    the engine made, a foreign key, and a key edited in place after its first use."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    params = dict(logN=13, num_scales=9, num_special_primes=3, is_secured=False)
+    eng = ckks_engine(devices=["cuda:0"], **params)
+    assert eng._planes_wanted()
+    N, c = eng.ctx.N, eng._consts(0, 0, True)
+    q = c.q_host
+    rng = np.random.default_rng(11)
+    src = np.stack([rng.integers(-int(p) + 1, 2 * int(p), size=N, dtype=np.int64) for p in q])     # signed-lazy and lazy words
+    dst = torch.full((len(q), N), -1, dtype=torch.int64, device="cuda:0")
+    eng.backend.key_planes(torch.from_numpy(src).cuda(), dst, c)
+    got = dst.cpu().numpy()
+    for r, p in enumerate(q):
+        canon = src[r] % int(p)
+        if int(p) >= (1 << 41):
+            assert (got[r] == src[r]).all()
+            continue
+        raw = got[r].view(np.uint32)
+        assert (raw[:N] == (canon & 0xffffffff).astype(np.uint32)).all()
+        assert (raw[N:N + N // 2].view(np.uint16) == (canon >> 32).astype(np.uint16)).all()
+        assert (got[r].view(np.uint32)[N + N // 2:] == 0xffffffff).all()          # the rest of the slot is not written
+
+    def run(e):
+        evk, rotk = synth.key_switch_key(e, 5), synth.key_switch_key(e, 6, origin="rotation key:3")     # foreign (unpacked) keys
+        sk = e.create_secret_key()
+        own = e.create_evk(sk)                                                                          # views of an engine-made pack
+        res = []
+        for level in (0, 3):
+            a, b = synth.ciphertext(e, 50 + level, level), synth.ciphertext(e, 60 + level, level)
+            res += [e.cc_mult(a, b, evk), e.rotate_single(a, rotk), e.cc_mult(a, b, own)]
+            res += e.rotate_single_batch([a, b, a], rotk) + e.cc_mult_batch([(a, b), (b, a)], own)
+        # in-place edit of a used key: the next use must see it (version counters of the pack / the foreign tensors)
+        own.data[1].data[0][0][2].add_(1)
+        evk.data[0].data[1][0][1].add_(1)
+        a, b = synth.ciphertext(e, 70, 1), synth.ciphertext(e, 71, 1)
+        res += [e.cc_mult(a, b, own), e.cc_mult(a, b, evk)]
+        return [digest(x) for x in res]
+
+    outs = []
+    for planes in (True, False):
+        e = ckks_engine(devices=["cuda:0"], **params)
+        if not planes:
+            e._planes_wanted = lambda: False
+        # identical randomness for the engine-made key on both sides
+        from tests.helpers import SeededCsprng
+        e.rng = SeededCsprng(e.ctx.N, [len(di) for di in e.ntt.p.d], max(e.ntt.num_special_primes, 2),
+                             devices=list(e.ntt.devices), seed=123)
+        outs.append(run(e))
+    assert outs[0] == outs[1]
+
+
 def _reference_shaped_switcher(eng, a, ksk, level):
     """create_switcher as the reference composes it from its step methods (eng.py:746-904) on ONE device: digits per part,
     extension + NTT + key products per part, sums, inverse transform, division by P through the checker's chain."""
