@@ -229,6 +229,26 @@ def run_encdec(params, keep):
     return rec
 
 
+def run_bronze_ntt():
+    """BASELINE configs[0]: bronze (logN 14), the forward NTT of ONE limb — every limb of the chain, one at a time — through
+    the reference's own ntt_context (its tables, its `ntt` / `enter_ntt` methods, special limbs included) with the C oracle
+    as the kernel.  Inputs: synth.uniform_rows(seed, ...) lazy words.  One digest per limb."""
+    eng = rd.reference_engine(1, **CONFIGS["bronze"])
+    ctx, N = eng.ctx, eng.ctx.N
+    rows = list(eng.ntt.p.d_special[0])                  # level 0 with the special limbs: every prime of the chain
+    rec = {"params": CONFIGS["bronze"], "seed": 2024, "q": [int(ctx.q[i]) for i in rows], "rows": [int(i) for i in rows],
+           "ntt": [], "enter_ntt": []}
+    x = synth.uniform_rows(2024, rows, ctx.q, N, lazy=True)
+    for name in ("ntt", "enter_ntt"):
+        t = torch.from_numpy(x.copy())
+        getattr(eng.ntt, name)([t], 0, -2)
+        out = t.numpy()
+        for r in range(len(rows)):
+            rec[name].append({"sha256": hashlib.sha256(np.ascontiguousarray(out[r]).tobytes()).hexdigest(),
+                              "head": [int(v) for v in out[r, :4]], "tail": [int(v) for v in out[r, -4:]]})
+    return rec
+
+
 def write_pickle_fixture(params):
     """A ciphertext file written by the REFERENCE's save() (host form, eng.py:2001-2015): data, not code."""
     import pickle
@@ -273,6 +293,9 @@ if __name__ == "__main__":
              "keygen_bronze": run_keygen(CONFIGS["bronze"], 1),
              "encdec_small": run_encdec(CONFIGS["small"], 1024), "encdec_silver": run_encdec(CONFIGS["silver"], 128)}
         json.dump(k, open(kpath, "w"), indent=1)
+    if "bronze_ntt" in which:   # BASELINE configs[0]
+        which.remove("bronze_ntt")
+        json.dump(run_bronze_ntt(), open(os.path.join(HERE, "bronze_ntt.json"), "w"), indent=1)
     if "gold_x8" in which:      # BASELINE configs[3]: the gold chain over 8 devices (11 / 8 rows with the special limbs)
         which.remove("gold_x8")
         out["gold_x8"] = run("gold", CONFIGS["gold"], 8)

@@ -106,3 +106,50 @@ def test_galois_matches_definition():
         for n in range(N):
             e = p * n % (2 * N)
             assert (dst[:, e % N] == (-a[:, n] if e >= N else a[:, n])).all()
+
+
+def test_bronze_single_limb_forward_ntt_equals_the_reference_fixture():
+    """BASELINE configs[0]: preset bronze (logN 14), the forward NTT of ONE limb on the CPU path, bit-exact.  The
+    expected words (tests/golden/bronze_ntt.json, generator tests/golden/make_golden.py bronze_ntt) were recorded from the
+    REFERENCE's ntt_context — its tables (ckks_context.py:294-341), its `ntt` / `enter_ntt` methods — over the C oracle; here
+    every limb of the chain is transformed on its own (rows = 1) with THIS package's context tables and the oracle's
+    formula-indexed transform, and a few output points are additionally held to the big-integer definition."""
+    import hashlib
+    import json
+    import os
+    from liberate_fhe_amd.fhe import presets
+    from liberate_fhe_amd.fhe.context.ckks_context import ckks_context
+    from liberate_fhe_amd.utils import synth
+    rec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bronze_ntt.json")))
+    params = {k: v for k, v in presets.params["bronze"].items() if k != "devices"}
+    assert {k: params[k] for k in rec["params"]} == rec["params"]
+    ctx = ckks_context(**params)
+    N, logN = ctx.N, ctx.logN
+    assert logN == 14 and [int(ctx.q[i]) for i in rec["rows"]] == rec["q"]
+    x = synth.uniform_rows(rec["seed"], rec["rows"], ctx.q, N, lazy=True)
+    h = lambda v, i: np.asarray([v[i]], dtype=np.int64)
+    brev = bit_reverse_indices(logN)
+    for r, i in enumerate(rec["rows"]):
+        q = int(ctx.q[i])
+        mont = (h(ctx.q_lower_bits, i), h(ctx.q_higher_bits, i), h(ctx.k_lower_bits, i), h(ctx.k_higher_bits, i))
+        psi = np.ascontiguousarray(ctx.psi_br[i:i + 1].copy())
+        orc.mont_enter(psi, h(ctx.R_square, i), 1, *mont)
+        for name in ("ntt", "enter_ntt"):
+            a = np.ascontiguousarray(x[r:r + 1].copy())
+            if name == "enter_ntt":
+                orc.mont_enter(a, h(ctx.R_square, i), 1, *mont)
+            orc.ntt(a, psi, 1, logN, h(ctx.q_double, i), *mont)
+            want = rec[name][r]
+            assert [int(v) for v in a[0, :4]] == want["head"] and [int(v) for v in a[0, -4:]] == want["tail"], (name, i)
+            assert hashlib.sha256(a[0].tobytes()).hexdigest() == want["sha256"], (name, i)
+        # definition: output k of the plain transform is the polynomial evaluated at psi^(2 brev(k) + 1)
+        root = int(ctx.psi_root[i])
+        coeffs = [int(v) for v in x[r]]
+        b = np.ascontiguousarray(x[r:r + 1].copy())
+        orc.ntt(b, psi, 1, logN, h(ctx.q_double, i), *mont)    # Montgomery-form twiddles: plain input -> plain (lazy) output
+        for k in (0, 1, N - 1):
+            pt = pow(root, 2 * int(brev[k]) + 1, q)
+            acc = 0
+            for c in reversed(coeffs):
+                acc = (acc * pt + c) % q
+            assert int(b[0, k]) % q == acc, (i, k)
