@@ -54,6 +54,9 @@ int lf_limits(int which);
  *                             column kernel (one register step per column, no LDS); above it the LDS-tiled form.
  *   (knob 0 was the one-launch key-switch transform of round 3: slower at every preset size on MI355X, removed.) */
 #define LF_TUNE_KS_EXT_COLS_MAX 1
+/*   LF_TUNE_KS_PIVOT_FOLD     1 (default): a key-switch tail given an lf_ks_pivot_fold eliminates the special primes inside
+ *                             its last inverse pass; 0: it launches the pivots kernel behind that pass instead. */
+#define LF_TUNE_KS_PIVOT_FOLD 2
 int lf_tune(int which, int value);
 
 /* Measurement entry (not one of the reference's ops; the engine never calls it): ONE wave, launched on `stream`, takes
@@ -211,6 +214,20 @@ int lf_ks_moddown(const int64_t *s, int64_t *out, const int64_t *addend, int ell
                   const int64_t *PiR, const double *PiP, const int64_t *Rs, const int64_t *ql, const int64_t *qh, const int64_t *kl,
                   const int64_t *kh, int device, void *stream);
 
+/* Optional argument of the fused key-switch entries below (NULL: off).  The mod-down (lf_ks_moddown_ws) starts with the
+ * elimination of the K special rows of the sums among themselves — the "pivots", once per coefficient, ckks_engine.py:850-901.
+ * With a pivot fold the last inverse pass of the key switch does that for the special limbs it has just transformed and
+ * leaves the pivots (and the per-row constants) in the mod-down workspace `ws`; the special rows of `s` are then NOT written,
+ * and the caller finishes with lf_ks_moddown_piv (the mod-down's second launch alone) on the same workspace.  One launch and
+ * one round trip of the special rows less per key switch; every output word is the same. */
+typedef struct lf_ks_pivot_fold {
+    int64_t *ws;            /* device, >= lf_ks_moddown_ws_words(2 * nct, ell, K, N) words */
+    int64_t ws_words;
+    const int64_t *PiR;     /* [K][ell + K], as lf_ks_moddown */
+    const double *PiP;      /* [K][ell + K] or NULL, as lf_ks_moddown */
+    int32_t ell, K;         /* ordinary limbs and special primes of the `rows` = ell + K limbs */
+} lf_ks_pivot_fold;
+
 /* Fused key-switch core for two-pass ring degrees (logN >= 13): extend + NTT + inner product with the key +
  * sum over digits + inverse NTT to canonical coefficients, i.e. lf_ks_extend -> lf_ntt -> lf_ks_inner ->
  * lf_intt(tail 2) (ckks_engine.py:707-743, 919, 931-934, 832-848) without materialising the extended digits.
@@ -224,24 +241,28 @@ int lf_ks_moddown(const int64_t *s, int64_t *out, const int64_t *addend, int ell
 int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,
                const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
                int key_format, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
-               const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
-               const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+               const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const lf_ks_pivot_fold *piv,
+               const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+               void *stream);
 
 /* Key formats of the fused key-switch entries (`key_format`).  The inner product with the key is the one launch of a key
  * switch that runs at the HBM rate, and most of what it reads is the key (gold: 450 of 687 MB), read once per call and never
  * modified: a binding may therefore keep a second, smaller copy of a key for these entries.
  *   LF_KEY_RAW     the reference's layout: 64-bit words, ksk[p*part_stride + comp*comp_stride + (row_off + r)*N + j];
- *   LF_KEY_PLANES  what lf_key_planes writes: same strides and row slots, but a row whose prime is below 2^41 holds,
- *                  in the first 6 N bytes of its slot, N 32-bit low words followed by N 16-bit high words of the
- *                  CANONICAL residues; rows of larger primes are raw.  N % 1024 == 0, 16-byte aligned base and strides.
+ *   LF_KEY_PLANES  what lf_key_planes writes: same strides and row slots, but for a row r whose prime is below 2^41 the
+ *                  slot of component 0 holds N / 2 groups of 16 bytes { lo32 b[j], lo32 b[j+1], lo32 a[j], lo32 a[j+1] } and
+ *                  the first 4 N bytes of the slot of component 1 hold N / 2 groups of 8 bytes { hi16 b[j], hi16 b[j+1],
+ *                  hi16 a[j], hi16 a[j+1] } (j even) of the CANONICAL residues of both components: 12 N instead of 16 N
+ *                  bytes, and one 16-byte + one 8-byte load per thread and digit instead of two 16-byte ones.  Rows of
+ *                  larger primes are raw words in their own slots.  16-byte aligned base and strides.
  * The sums are the same residues either way, so every output word of the entries below is identical.
- * lf_key_planes converts one block of `rows` rows (any lazy / signed-lazy words) from src to dst (dst != src, both 16-byte
- * aligned; ql / qh: DEVICE 31-bit halves of the rows' primes as everywhere in this header); a key is converted block by
- * block — one call per (part, component) — into a tensor of the raw key's shape. */
+ * lf_key_planes converts the `rows` rows of ONE key part (src_b / src_a: its two components, any lazy / signed-lazy words;
+ * dst_b / dst_a: the part's two slots in a tensor of the raw key's shape, distinct from the sources; ql / qh: DEVICE 31-bit
+ * halves of the rows' primes as everywhere in this header); a key is converted part by part. */
 #define LF_KEY_RAW 0
 #define LF_KEY_PLANES 1
-int lf_key_planes(const int64_t *src, int64_t *dst, int rows, int64_t N, const int64_t *ql, const int64_t *qh, int device,
-                  void *stream);
+int lf_key_planes(const int64_t *src_b, const int64_t *src_a, int64_t *dst_b, int64_t *dst_a, int rows, int64_t N,
+                  const int64_t *ql, const int64_t *qh, int device, void *stream);
 
 /* lf_ks_digits(_galois) of `count` (<= 8) polynomials in one launch: a / state are HOST arrays of device pointers
  * (gal_pinv = 0: no Galois map). */
@@ -256,8 +277,9 @@ int lf_ks_digits_batch(const int64_t *const *a, int64_t *const *state, int count
 int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int nparts, int rows, int logN, const int64_t *desc,
                      const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
                      int64_t row_off, int key_format, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
-                     const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
-                     const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+                     const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const lf_ks_pivot_fold *piv,
+                     const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+                     void *stream);
 
 /* The two halves of lf_ks_core as separate calls (single ciphertext), so that a limb-sharded engine can start on the
  * digits that have already arrived while the others are still travelling over xGMI (ckks_engine.py:778-829 stages
@@ -271,8 +293,8 @@ int lf_ks_fwd(const int64_t *state, int nparts, int rows, int logN, const int64_
               const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 int lf_ks_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
                int key_format, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
-               const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
-               void *stream);
+               const lf_ks_pivot_fold *piv, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+               const int64_t *kh, int device, void *stream);
 
 /* Relinearisation inside cc_mult (ckks_engine.py:1095-1101, 1117-1151) without inverse transforms of d0 and d1:
  * dividing by P is linear and P * d vanishes modulo every special prime, so moddown(s) + d == moddown(s + P * d on the
@@ -286,8 +308,8 @@ int lf_relin_core_batch(const int64_t *state, int64_t state_stride, int nct, int
                         const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
                         int64_t row_off, int key_format, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
                         const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *x, int64_t x_ct_stride,
-                        const int64_t *PR, int ell, const uint8_t *own, const int64_t *q_host, const int64_t *ql, const int64_t *qh,
-                        const int64_t *kl, const int64_t *kh, int device, void *stream);
+                        const int64_t *PR, int ell, const uint8_t *own, const lf_ks_pivot_fold *piv, const int64_t *q_host,
+                        const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 /* own (optional DEVICE table of `rows` bytes, may be NULL): own[r] = the digit (storage order) whose primes include limb
  * r, 255 for the special limbs.  The extension of a digit's mixed-radix form to one of its own primes is the residue it
  * was built from, i.e. the switched polynomial x1 * y1 itself: those (digit, limb) pairs are neither extended nor
@@ -299,8 +321,9 @@ int lf_relin_fwd(const int64_t *state, int first, int nparts, int rows, int logN
                  void *stream);
 int lf_relin_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
                   int key_format, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
-                  const int64_t *x, const int64_t *PR, int ell, const uint8_t *own, const int64_t *q_host, const int64_t *ql,
-                  const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+                  const int64_t *x, const int64_t *PR, int ell, const uint8_t *own, const lf_ks_pivot_fold *piv,
+                  const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+                  void *stream);
 
 /* Batched forms: `count` (<= 8) independent operand sets in ONE launch — the two components of a ciphertext, the
  * four polynomials cc_mult rescales.  The arrays of pointers are HOST arrays of device pointers; constants are
@@ -322,6 +345,16 @@ int lf_ks_moddown_ws(const int64_t *const *s, int64_t *const *out, const int64_t
                      int64_t N, int64_t *ws, int64_t ws_words, const int64_t *PiR, const double *PiP, const int64_t *Rs,
                      int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl,
                      const int64_t *kh, int device, void *stream);
+/* Its two launches as separate entries: lf_ks_pivots fills the workspace (pivots of the `count` polynomials + per-row
+ * constants), lf_ks_moddown_piv finishes from a filled workspace — what a caller runs after a key-switch tail that was given
+ * an lf_ks_pivot_fold (the tail then has filled the workspace itself).  lf_ks_pivots; lf_ks_moddown_piv == lf_ks_moddown_ws. */
+int lf_ks_pivots(const int64_t *const *s, int count, int ell, int K, int64_t N, int64_t *ws, int64_t ws_words, const int64_t *PiR,
+                 const double *PiP, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+                 void *stream);
+int lf_ks_moddown_piv(const int64_t *const *s, int64_t *const *out, const int64_t *const *addend, int count, int ell, int K,
+                      int64_t N, const int64_t *ws, int64_t ws_words, const int64_t *PiR, const double *PiP, const int64_t *Rs,
+                      int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+                      const int64_t *kh, int device, void *stream);
 
 /* Galois permutation in gather form, so that rotate / conjugate need no permutation pass of their own
  * (switch_key / rotate_single, ckks_engine.py:939-961, 1180-1206; encdec.py:224-270):

@@ -578,22 +578,37 @@ int lf_ks_moddown_batch(const int64_t *const *s, int64_t *const *out, const int6
     return (int)hipGetLastError();
 }
 
-int lf_ks_moddown_ws(const int64_t *const *s, int64_t *const *out, const int64_t *const *addend, int count, int ell, int K,
-                     int64_t N, int64_t *ws, int64_t ws_words, const int64_t *PiR, const double *PiP, const int64_t *Rs,
-                     int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl,
-                     const int64_t *kh, int device, void *stream) {
-    if (count < 0 || count > LF_BATCH_MAX || ell < 0 || K < 1 || K > KS_MAX_K || N < 2 || (N & 1)) return LF_ERR_ARG;
-    if (gal_pinv < 0 || gal_pinv >= 2 * N || (gal_pinv && (!(gal_pinv & 1) || (N & (N - 1))))) return LF_ERR_ARG;
-    if (!ws || ws_words < lf_ks_moddown_ws_words(count, ell, K, N)) return LF_ERR_ARG;
+static int moddown_args_ok(int count, int ell, int K, int64_t N, const int64_t *ws, int64_t ws_words, int64_t gal_pinv) {
+    if (count < 0 || count > LF_BATCH_MAX || ell < 0 || K < 1 || K > KS_MAX_K || N < 2 || (N & 1)) return 0;
+    if (gal_pinv < 0 || gal_pinv >= 2 * N || (gal_pinv && (!(gal_pinv & 1) || (N & (N - 1))))) return 0;
+    return ws && ws_words >= lf_ks_moddown_ws_words(count, ell, K, N);
+}
+
+int lf_ks_pivots(const int64_t *const *s, int count, int ell, int K, int64_t N, int64_t *ws, int64_t ws_words, const int64_t *PiR,
+                 const double *PiP, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+                 void *stream) {
+    if (!moddown_args_ok(count, ell, K, N, ws, ws_words, 0)) return LF_ERR_ARG;
+    if (count == 0 || ell == 0) return 0;
+    if (int e = lf_set_device(device)) return e;
+    PtrBatch pb;
+    for (int i = 0; i < count; ++i) pb.in[i] = (const i64 *)s[i], pb.aux[i] = nullptr, pb.out[i] = nullptr;
+    dim3 g1((unsigned)((N + 255) / 256), (unsigned)count + 1u);
+    hipLaunchKernelGGL(ks_pivots_kernel, g1, dim3(256), 0, (hipStream_t)stream, pb, count, ell, K, (i64)N, (i64 *)ws, (const i64 *)PiR,
+                       PiP, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+    return (int)hipGetLastError();
+}
+
+int lf_ks_moddown_piv(const int64_t *const *s, int64_t *const *out, const int64_t *const *addend, int count, int ell, int K,
+                      int64_t N, const int64_t *ws, int64_t ws_words, const int64_t *PiR, const double *PiP, const int64_t *Rs,
+                      int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+                      const int64_t *kh, int device, void *stream) {
+    if (!moddown_args_ok(count, ell, K, N, ws, ws_words, gal_pinv)) return LF_ERR_ARG;
     if (count == 0 || ell == 0) return 0;
     if (int e = lf_set_device(device)) return e;
     PtrBatch pb;
     for (int i = 0; i < count; ++i)
         pb.in[i] = (const i64 *)s[i], pb.aux[i] = addend ? (const i64 *)addend[i] : nullptr, pb.out[i] = (i64 *)out[i];
     hipStream_t st = (hipStream_t)stream;
-    dim3 g1((unsigned)((N + 255) / 256), (unsigned)count + 1u);
-    hipLaunchKernelGGL(ks_pivots_kernel, g1, dim3(256), 0, st, pb, count, ell, K, (i64)N, (i64 *)ws, (const i64 *)PiR, PiP,
-                       (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     dim3 g2((unsigned)((N / 2 + 255) / 256), (unsigned)((ell + MD3_ROWS - 1) / MD3_ROWS), (unsigned)count);
 #define LF_MD_CASE(KK)                                                                                               \
     case KK:                                                                                                         \
@@ -607,6 +622,15 @@ int lf_ks_moddown_ws(const int64_t *const *s, int64_t *const *out, const int64_t
     }
 #undef LF_MD_CASE
     return (int)hipGetLastError();
+}
+
+int lf_ks_moddown_ws(const int64_t *const *s, int64_t *const *out, const int64_t *const *addend, int count, int ell, int K,
+                     int64_t N, int64_t *ws, int64_t ws_words, const int64_t *PiR, const double *PiP, const int64_t *Rs,
+                     int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+                     const int64_t *kh, int device, void *stream) {
+    if (int e = lf_ks_pivots(s, count, ell, K, N, ws, ws_words, PiR, PiP, ql, qh, kl, kh, device, stream)) return e;
+    return lf_ks_moddown_piv(s, out, addend, count, ell, K, N, ws, ws_words, PiR, PiP, Rs, gal_pinv, gal_2q, ql, qh, kl, kh, device,
+                             stream);
 }
 
 int lf_ks_moddown(const int64_t *s, int64_t *out, const int64_t *addend, int ell, int K, int64_t N, const int64_t *PiR,

@@ -351,6 +351,54 @@ __global__ void __launch_bounds__(NTT_COL_THREADS) ks_ext_cols_mixed(const i64 *
     }
 }
 
+// ---- the key in PLANES format (lf_key_planes): the HBM-bound launch reads fewer key bytes ------------------------------
+// ks_inner2_kernel streams the key at the rate HBM delivers (gold cc_mult: 687 MB in 112 us, 450 MB of them key words), so
+// only fewer BYTES make it shorter.  A word of an fp64-class key row is a residue below 2^41.  lf_key_planes stores the two
+// components (b, a) of such a row, once per key, as
+//     slot of component 0 (8 N bytes):         N / 2 groups of 16 bytes  { lo32 b[j], lo32 b[j+1], lo32 a[j], lo32 a[j+1] }
+//     slot of component 1, first 4 N bytes:    N / 2 groups of  8 bytes  { hi16 b[j], hi16 b[j+1], hi16 a[j], hi16 a[j+1] }
+// of the CANONICAL residues — 12 N bytes per row pair instead of 16 N; integer-class rows stay raw words in their slots.
+// A thread of the inner product (two coefficients) then issues, per digit, ONE 16-byte and ONE 8-byte key load for both
+// components where the raw layout needs two 16-byte loads: fewer bytes AND no more load instructions, at the register
+// count of the raw kernel (a first version with four coefficients per thread and per-component planes read 25 % fewer key
+// bytes at 96 .. 256 VGPRs and was no faster).  The double is assembled in registers — exponent | high word in the upper
+// dword, the low word below, minus 2^52 — for the price of the raw word's conversion.  Same sums modulo q: same outputs.
+__device__ __forceinline__ double dp_from_planes(unsigned lo, unsigned hi16) {
+    return __longlong_as_double((i64)(((u64)(0x43300000u | hi16) << 32) | (u64)lo)) - DP_MAGIC;
+}
+typedef unsigned lf_u4_t __attribute__((ext_vector_type(4)));
+typedef unsigned lf_u2_t __attribute__((ext_vector_type(2)));
+
+// lf_key_planes: one row pair per blockIdx.y, two coefficients per thread
+__global__ void __launch_bounds__(256) key_planes_kernel(const i64 *__restrict__ src_b, const i64 *__restrict__ src_a,
+                                                         i64 *__restrict__ dst_b, i64 *__restrict__ dst_a, i64 N,
+                                                         const i64 *__restrict__ ql, const i64 *__restrict__ qh) {
+    const int r = blockIdx.y;
+    const i64 j = ((i64)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (j >= N) return;
+    const i64 q = (qh[r] << 31) | ql[r];
+    const longlong2 b = *reinterpret_cast<const longlong2 *>(src_b + (i64)r * N + j);
+    const longlong2 a = *reinterpret_cast<const longlong2 *>(src_a + (i64)r * N + j);
+    if ((u64)q >= SMALL_PRIME_LIMIT) {
+        *reinterpret_cast<longlong2 *>(dst_b + (i64)r * N + j) = b;
+        *reinterpret_cast<longlong2 *>(dst_a + (i64)r * N + j) = a;
+        return;
+    }
+    const i64 w[4] = {b.x, b.y, a.x, a.y};
+    unsigned lo[4], hi[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        i64 c = w[v] % q;            // any word (lazy, signed-lazy): its canonical residue; once per key
+        c = c < 0 ? c + q : c;
+        lo[v] = (unsigned)c;
+        hi[v] = (unsigned)(c >> 32);
+    }
+    const lf_u4_t l = {lo[0], lo[1], lo[2], lo[3]};
+    const lf_u2_t h = {hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16)};
+    *reinterpret_cast<lf_u4_t *>(reinterpret_cast<unsigned *>(dst_b + (i64)r * N) + 2 * j) = l;
+    *reinterpret_cast<lf_u2_t *>(reinterpret_cast<unsigned *>(dst_a + (i64)r * N) + j) = h;
+}
+
 // The key (gold: 429 MB per key switch) is read exactly once: nontemporal loads (global_load_dwordx4 .. nt) keep it
 // from displacing the digits, which the forward pass has just written, out of L2 / Infinity Cache
 // (measured at gold: 124.8 -> 96.2 us together with one 16-byte column per thread instead of two).
@@ -385,7 +433,7 @@ struct RelinFold {
     const unsigned char *own;
 };
 
-template <int NCT, bool FOLD>
+template <int NCT, bool FOLD, bool PLANES>
 __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ ext, const i64 *__restrict__ ksk,
                                                         i64 part_stride, i64 comp_stride, i64 row_off, i64 *__restrict__ s,
                                                         int nparts, int rows, i64 N, RelinFold fold, const i64 *__restrict__ ql,
@@ -424,9 +472,18 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
 #pragma unroll
             for (int t = 0; t < NCT; ++t)
                 x[t] = p == p_own ? xo[t] : *reinterpret_cast<const longlong2 *>(e + t * ct_ext + (i64)p * rows * N);
-            const longlong2 k0 = ld_nt(k + (i64)p * part_stride);
-            const longlong2 k1 = ld_nt(k + (i64)p * part_stride + comp_stride);
-            const double k0x = dp_from_word(k0.x), k0y = dp_from_word(k0.y), k1x = dp_from_word(k1.x), k1y = dp_from_word(k1.y);
+            double k0x, k0y, k1x, k1y;
+            if (PLANES) {   // 16 + 8 bytes for both components (see lf_key_planes)
+                const i64 *kr = k - j0 + (i64)p * part_stride;
+                const lf_u4_t l = __builtin_nontemporal_load(reinterpret_cast<const lf_u4_t *>(reinterpret_cast<const unsigned *>(kr) + 2 * j0));
+                const lf_u2_t h = __builtin_nontemporal_load(reinterpret_cast<const lf_u2_t *>(reinterpret_cast<const unsigned *>(kr + comp_stride) + j0));
+                k0x = dp_from_planes(l.x, h.x & 0xffffu), k0y = dp_from_planes(l.y, h.x >> 16);
+                k1x = dp_from_planes(l.z, h.y & 0xffffu), k1y = dp_from_planes(l.w, h.y >> 16);
+            } else {
+                const longlong2 k0 = ld_nt(k + (i64)p * part_stride);
+                const longlong2 k1 = ld_nt(k + (i64)p * part_stride + comp_stride);
+                k0x = dp_from_word(k0.x), k0y = dp_from_word(k0.y), k1x = dp_from_word(k1.x), k1y = dp_from_word(k1.y);
+            }
 #pragma unroll
             for (int t = 0; t < NCT; ++t) {
                 const double x0 = dp_from_word(x[t].x), x1 = dp_from_word(x[t].y);
@@ -522,230 +579,14 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
     }
 }
 
-// ---- K3 on a key in PLANES format (lf_key_planes): the HBM-bound launch reads fewer key bytes ----------------------
-// ks_inner2_kernel streams the key at the HBM rate (gold cc_mult: 687 MB in 112 us, of which 450 MB are key words), so only
-// fewer BYTES make it shorter.  A word of an fp64-class key row is a residue below 2^41: lf_key_planes stores such a row, once
-// per key, as a plane of N 32-bit low words followed by a plane of N 16-bit high words (6 N bytes in the row's 8 N-byte
-// slot, canonical residues; integer-class rows stay raw words).  Here a thread owns FOUR consecutive coefficients: per
-// digit and key component one 16-byte load (four low words) and one 8-byte load (four high words); the double is
-// assembled in registers — exponent | high word in the upper dword, low word in the lower, minus 2^52 — for the price
-// of the raw word's conversion.  Same sums modulo q as ks_inner2_kernel, so the same canonical words leave the launch.
-__device__ __forceinline__ double dp_from_planes(unsigned lo, unsigned hi16) {
-    return __longlong_as_double((i64)(((u64)(0x43300000u | hi16) << 32) | (u64)lo)) - DP_MAGIC;
-}
-
-struct KeyQuad {   // four consecutive key words of an fp64-class row as doubles
-    double v[4];
-};
-__device__ __forceinline__ KeyQuad ld_key_planes(const i64 *row, i64 N, i64 j0) {
-    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-    const unsigned *lo = reinterpret_cast<const unsigned *>(row) + j0;
-    const unsigned short *hi = reinterpret_cast<const unsigned short *>(reinterpret_cast<const unsigned *>(row) + N) + j0;
-    const u4_t l = __builtin_nontemporal_load(reinterpret_cast<const u4_t *>(lo));
-    const u2_t h = __builtin_nontemporal_load(reinterpret_cast<const u2_t *>(hi));
-    KeyQuad k;
-    k.v[0] = dp_from_planes(l.x, h.x & 0xffffu);
-    k.v[1] = dp_from_planes(l.y, h.x >> 16);
-    k.v[2] = dp_from_planes(l.z, h.y & 0xffffu);
-    k.v[3] = dp_from_planes(l.w, h.y >> 16);
-    return k;
-}
-
-template <int NCT, bool FOLD>
-__global__ void __launch_bounds__(256) ks_inner4_kernel(const i64 *__restrict__ ext, const i64 *__restrict__ ksk,
-                                                        i64 part_stride, i64 comp_stride, i64 row_off, i64 *__restrict__ s,
-                                                        int nparts, int rows, i64 N, RelinFold fold, const i64 *__restrict__ ql,
-                                                        const i64 *__restrict__ qh, const i64 *__restrict__ kl,
-                                                        const i64 *__restrict__ kh) {
-    const int r = blockIdx.y;
-    const i64 j0 = (i64)blockIdx.x * 1024 + threadIdx.x * 4;
-    if (j0 >= N) return;
-    const RowMod m = load_mod(ql, qh, kl, kh, r);
-    const RowDp d = make_dp(m);
-    const i64 *e = ext + (i64)r * N + j0;
-    const i64 *krow = ksk + (row_off + r) * N;
-    const i64 ct_ext = (i64)nparts * rows * N;   // words between the ciphertexts' extended digits
-    const i64 ct_s = 2 * (i64)rows * N;          // .. and between their output pairs
-    const int p_own = (FOLD && fold.own != nullptr && r < fold.ell) ? (int)fold.own[r] : -1;
-    if (m.q < SMALL_PRIME_LIMIT) {
-        double acc[NCT][2][4];
-#pragma unroll
-        for (int t = 0; t < NCT; ++t)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[t][c][v] = 0.0;
-        double xo[NCT][4];   // the own digit's words: x1 * y1, plain canonical
-        if (p_own >= 0) {
-#pragma unroll
-            for (int t = 0; t < NCT; ++t) {
-                const i64 *xs = fold.x + t * fold.ct_stride + (i64)r * N + j0 + (i64)fold.ell * N;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const longlong2 X1 = *reinterpret_cast<const longlong2 *>(xs + 2 * h);
-                    const longlong2 Y1 = *reinterpret_cast<const longlong2 *>(xs + 2 * h + 2 * (i64)fold.ell * N);
-                    xo[t][2 * h] = dp_mulmod(dp_from_word(X1.x), dp_from_word(Y1.x), d);
-                    xo[t][2 * h + 1] = dp_mulmod(dp_from_word(X1.y), dp_from_word(Y1.y), d);
-                }
-            }
-        }
-#pragma unroll 2
-        for (int p = 0; p < nparts; ++p) {
-            double x[NCT][4];
-#pragma unroll
-            for (int t = 0; t < NCT; ++t) {
-                if (p == p_own) {
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) x[t][v] = xo[t][v];
-                } else {
-                    const i64 *ep = e + t * ct_ext + (i64)p * rows * N;
-                    const longlong2 a = *reinterpret_cast<const longlong2 *>(ep), b = *reinterpret_cast<const longlong2 *>(ep + 2);
-                    x[t][0] = dp_from_word(a.x), x[t][1] = dp_from_word(a.y), x[t][2] = dp_from_word(b.x), x[t][3] = dp_from_word(b.y);
-                }
-            }
-            const KeyQuad k0 = ld_key_planes(krow + (i64)p * part_stride, N, j0);
-            const KeyQuad k1 = ld_key_planes(krow + (i64)p * part_stride + comp_stride, N, j0);
-#pragma unroll
-            for (int t = 0; t < NCT; ++t)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    acc[t][0][v] += dp_mulmod_bal(x[t][v], k0.v[v], d);
-                    acc[t][1][v] += dp_mulmod_bal(x[t][v], k1.v[v], d);
-                }
-        }
-        if (FOLD && r < fold.ell) {
-            const double pr = dp_from_word(fold.PR[r]);
-            const i64 pstride = (i64)fold.ell * N;
-#pragma unroll
-            for (int t = 0; t < NCT; ++t) {
-                const i64 *xs = fold.x + t * fold.ct_stride + (i64)r * N + j0;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const longlong2 X0 = *reinterpret_cast<const longlong2 *>(xs + 2 * h), X1 = *reinterpret_cast<const longlong2 *>(xs + 2 * h + pstride);
-                    const longlong2 Y0 = *reinterpret_cast<const longlong2 *>(xs + 2 * h + 2 * pstride), Y1 = *reinterpret_cast<const longlong2 *>(xs + 2 * h + 3 * pstride);
-                    const double x0[2] = {dp_from_word(X0.x), dp_from_word(X0.y)}, x1[2] = {dp_from_word(X1.x), dp_from_word(X1.y)};
-                    const double y0[2] = {dp_from_word(Y0.x), dp_from_word(Y0.y)}, y1[2] = {dp_from_word(Y1.x), dp_from_word(Y1.y)};
-#pragma unroll
-                    for (int w = 0; w < 2; ++w) {   // balanced terms: |d0| <= q / 2, |d1| <= q
-                        const double d0 = dp_mulmod_bal(x0[w], y0[w], d);
-                        const double d1 = dp_mulmod_bal(x0[w], y1[w], d) + dp_mulmod_bal(x1[w], y0[w], d);
-                        acc[t][0][2 * h + w] += dp_mulmod_bal(d0, pr, d);
-                        acc[t][1][2 * h + w] += dp_mulmod_bal(d1, pr, d);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NCT; ++t)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    longlong2 o;
-                    o.x = dp_to_word(dp_reduce(acc[t][c][2 * h], d.q, d.qinv));
-                    o.y = dp_to_word(dp_reduce(acc[t][c][2 * h + 1], d.q, d.qinv));
-                    *reinterpret_cast<longlong2 *>(s + t * ct_s + ((i64)c * rows + r) * N + j0 + 2 * h) = o;
-                }
-    } else {
-        // integer-class rows stay raw 64-bit words in a planes-format key: ks_inner2_kernel's arithmetic, two 16-byte columns per thread
-        const i64 *k = krow + j0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            i64 acc[NCT][2][2];
-#pragma unroll
-            for (int t = 0; t < NCT; ++t) acc[t][0][0] = acc[t][0][1] = acc[t][1][0] = acc[t][1][1] = 0;
-            longlong2 xo[NCT];   // the own digit's words: REDC62(x1 * y1), Montgomery form below 2q
-            if (p_own >= 0) {
-#pragma unroll
-                for (int t = 0; t < NCT; ++t) {
-                    const i64 *xs = fold.x + t * fold.ct_stride + (i64)r * N + j0 + 2 * h + (i64)fold.ell * N;
-                    const longlong2 X1 = *reinterpret_cast<const longlong2 *>(xs), Y1 = *reinterpret_cast<const longlong2 *>(xs + 2 * (i64)fold.ell * N);
-                    xo[t].x = mm62u((u64)X1.x, (u64)Y1.x, m.q, m.k);
-                    xo[t].y = mm62u((u64)X1.y, (u64)Y1.y, m.q, m.k);
-                }
-            }
-            for (int p = 0; p < nparts; ++p) {
-                const longlong2 k0 = ld_nt(k + 2 * h + (i64)p * part_stride);
-                const longlong2 k1 = ld_nt(k + 2 * h + (i64)p * part_stride + comp_stride);
-#pragma unroll
-                for (int t = 0; t < NCT; ++t) {
-                    const longlong2 x = p == p_own ? xo[t] : *reinterpret_cast<const longlong2 *>(e + 2 * h + t * ct_ext + (i64)p * rows * N);
-                    acc[t][0][0] = csub(acc[t][0][0] + mm62u((u64)x.x, (u64)k0.x, m.q, m.k), m.q2);
-                    acc[t][0][1] = csub(acc[t][0][1] + mm62u((u64)x.y, (u64)k0.y, m.q, m.k), m.q2);
-                    acc[t][1][0] = csub(acc[t][1][0] + mm62u((u64)x.x, (u64)k1.x, m.q, m.k), m.q2);
-                    acc[t][1][1] = csub(acc[t][1][1] + mm62u((u64)x.y, (u64)k1.y, m.q, m.k), m.q2);
-                }
-            }
-            if (FOLD && r < fold.ell) {
-                const u64 pr = (u64)fold.PR[r];
-                const i64 pstride = (i64)fold.ell * N;
-#pragma unroll
-                for (int t = 0; t < NCT; ++t) {
-                    const i64 *xs = fold.x + t * fold.ct_stride + (i64)r * N + j0 + 2 * h;
-                    const longlong2 X0 = *reinterpret_cast<const longlong2 *>(xs), X1 = *reinterpret_cast<const longlong2 *>(xs + pstride);
-                    const longlong2 Y0 = *reinterpret_cast<const longlong2 *>(xs + 2 * pstride), Y1 = *reinterpret_cast<const longlong2 *>(xs + 3 * pstride);
-                    const u64 x0[2] = {(u64)X0.x, (u64)X0.y}, x1[2] = {(u64)X1.x, (u64)X1.y};
-                    const u64 y0[2] = {(u64)Y0.x, (u64)Y0.y}, y1[2] = {(u64)Y1.x, (u64)Y1.y};
-#pragma unroll
-                    for (int w = 0; w < 2; ++w) {
-                        const i64 d0 = mm62u(x0[w], y0[w], m.q, m.k);
-                        const i64 d1 = csub(mm62u(x0[w], y1[w], m.q, m.k) + mm62u(x1[w], y0[w], m.q, m.k), m.q2);
-                        acc[t][0][w] = csub(acc[t][0][w] + mm62u((u64)d0, pr, m.q, m.k), m.q2);
-                        acc[t][1][w] = csub(acc[t][1][w] + mm62u((u64)d1, pr, m.q, m.k), m.q2);
-                    }
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < NCT; ++t)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    longlong2 o;
-                    o.x = acc[t][c][0];
-                    o.y = acc[t][c][1];
-                    *reinterpret_cast<longlong2 *>(s + t * ct_s + ((i64)c * rows + r) * N + j0 + 2 * h) = o;
-                }
-        }
-    }
-}
-
-// lf_key_planes: one row per blockIdx.y, four words per thread
-__global__ void __launch_bounds__(256) key_planes_kernel(const i64 *__restrict__ src, i64 *__restrict__ dst, i64 N,
-                                                         const i64 *__restrict__ ql, const i64 *__restrict__ qh) {
-    const int r = blockIdx.y;
-    const i64 j0 = (i64)blockIdx.x * 1024 + threadIdx.x * 4;
-    if (j0 >= N) return;
-    const i64 *in = src + (i64)r * N;
-    i64 *out = dst + (i64)r * N;
-    const i64 q = (qh[r] << 31) | ql[r];
-    const longlong2 a = *reinterpret_cast<const longlong2 *>(in + j0), b = *reinterpret_cast<const longlong2 *>(in + j0 + 2);
-    if ((u64)q >= SMALL_PRIME_LIMIT) {
-        *reinterpret_cast<longlong2 *>(out + j0) = a;
-        *reinterpret_cast<longlong2 *>(out + j0 + 2) = b;
-        return;
-    }
-    i64 w[4] = {a.x, a.y, b.x, b.y};
-    unsigned lo[4], hi[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        i64 c = w[v] % q;            // any word (lazy, signed-lazy): its canonical residue; once per key
-        c = c < 0 ? c + q : c;
-        lo[v] = (unsigned)c;
-        hi[v] = (unsigned)(c >> 32);
-    }
-    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-    u4_t l = {lo[0], lo[1], lo[2], lo[3]};
-    u2_t h = {hi[0] | (hi[1] << 16), hi[2] | (hi[3] << 16)};
-    *reinterpret_cast<u4_t *>(reinterpret_cast<unsigned *>(out) + j0) = l;
-    *reinterpret_cast<u2_t *>(reinterpret_cast<unsigned short *>(reinterpret_cast<unsigned *>(out) + N) + j0) = h;
-}
-
 // largest number of leading stages (logN - 12) whose extension + strided pass runs as the column kernel (lf_tune).
 // With the digit loop as a runtime loop (R loads in flight, 100 VGPRs at R = 16) the column form also wins at logN 16:
 // gold cc_mult 2 104-2 130 -> 2 168-2 183 ops/s, rotate 2 653-2 695 -> 2 733-2 763, 64 rotations under one key
 // 3 110 -> 3 300 /s (tools/eo.py --ext-cols-max 3 | 4, one box); round 2's fully unrolled form had lost there (116 vs 95 us).
 int g_ks_ext_cols_max = 4;
+// 1: a key-switch tail that is given an lf_ks_pivot_fold eliminates the special primes inside its last inverse pass; 0: it
+// launches the pivots kernel after that pass instead (lf_tune; A/B of the fold, same workspace contents either way)
+int g_ks_pivot_fold = 1;
 
 void classify_rows(int rows, const int64_t *q_host, RowList &dp, RowList &in) {
     dp.n = in.n = 0;
@@ -808,53 +649,50 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
 int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
             int64_t row_off, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp,
             const int64_t *Ninv, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
-            const int64_t *kh, hipStream_t st, const RelinFold *fold = nullptr, int key_format = LF_KEY_RAW) {
+            const int64_t *kh, hipStream_t st, const RelinFold *fold = nullptr, int key_format = LF_KEY_RAW,
+            const lf_ks_pivot_fold *piv = nullptr) {
     if (!ipsi_dp || (key_format != LF_KEY_RAW && key_format != LF_KEY_PLANES)) return LF_ERR_ARG;
-    if (key_format == LF_KEY_PLANES && ((((int64_t)1 << logN) & 1023) || (((uintptr_t)ksk | (uintptr_t)(part_stride * 8) | (uintptr_t)(comp_stride * 8)) & 15)))
+    if (key_format == LF_KEY_PLANES && ((((uintptr_t)ksk | (uintptr_t)(part_stride * 8) | (uintptr_t)(comp_stride * 8)) & 15)))
         return LF_ERR_ARG;
     const int tl = NTT_TILE_LOG_MAX, S1 = logN - tl;
     RowList dp, in;
     classify_rows(rows, q_host, dp, in);
     const bool mixed = dp.n && in.n;
+    // the mod-down's special-prime elimination inside the last inverse pass (PivFold, ckks_ntt_core.h): needs that pass as
+    // a column kernel and the special primes in the integer class (they are 60-bit primes in every context this package
+    // builds); otherwise the pivots get their own launch at the end, as lf_ks_moddown_ws would do
+    PivFold pf{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+    bool fold_piv = false;
+    if (piv != nullptr) {
+        if (!piv->ws || !piv->PiR || piv->K < 1 || piv->K > KS_MAX_K || piv->ell < 1 || piv->ell + piv->K != rows ||
+            piv->ws_words < lf_ks_moddown_ws_words(2 * nct, piv->ell, piv->K, (int64_t)1 << logN))
+            return LF_ERR_ARG;
+        fold_piv = S1 <= 4 && g_ks_pivot_fold != 0;
+        for (int r = piv->ell; r < rows; ++r) fold_piv = fold_piv && (uint64_t)q_host[r] >= SMALL_PRIME_LIMIT;
+        if (fold_piv) pf.ws = (i64 *)piv->ws, pf.PiR = (const i64 *)piv->PiR, pf.PiP = piv->PiP, pf.ell = piv->ell, pf.Ksp = piv->K;
+    }
     // K3: inner product with the key, summed over the digits
     {
         const i64 N = (i64)1 << logN;
         dim3 grid((unsigned)((N + 512 * KI_COLS - 1) / (512 * KI_COLS)), (unsigned)rows);
         const RelinFold nofold{nullptr, 0, nullptr, 0, nullptr};
-        if (key_format == LF_KEY_PLANES) {
-            const dim3 grid4((unsigned)(N / 1024), (unsigned)rows);
-#define LF_INNER4_CASE(NCT)                                                                                            \
-    case NCT:                                                                                                          \
-        if (fold)                                                                                                      \
-            hipLaunchKernelGGL((ks_inner4_kernel<NCT, true>), grid4, dim3(256), 0, st, (const i64 *)tmp, (const i64 *)ksk, \
-                               (i64)part_stride, (i64)comp_stride, (i64)row_off, (i64 *)s, nparts, rows, N, *fold,     \
-                               (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);                    \
-        else                                                                                                           \
-            hipLaunchKernelGGL((ks_inner4_kernel<NCT, false>), grid4, dim3(256), 0, st, (const i64 *)tmp, (const i64 *)ksk, \
-                               (i64)part_stride, (i64)comp_stride, (i64)row_off, (i64 *)s, nparts, rows, N, nofold,    \
-                               (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);                    \
-        break;
-            switch (nct) {
-                LF_INNER4_CASE(1) LF_INNER4_CASE(2) LF_INNER4_CASE(4)
-            }
-#undef LF_INNER4_CASE
-        } else {
+#define LF_INNER_LAUNCH(NCT, FOLDB, PL, FOLDV)                                                                         \
+    hipLaunchKernelGGL((ks_inner2_kernel<NCT, FOLDB, PL>), grid, dim3(256), 0, st, (const i64 *)tmp, (const i64 *)ksk,     \
+                       (i64)part_stride, (i64)comp_stride, (i64)row_off, (i64 *)s, nparts, rows, N, FOLDV, (const i64 *)ql, \
+                       (const i64 *)qh, (const i64 *)kl, (const i64 *)kh)
 #define LF_INNER_CASE(NCT)                                                                                             \
     case NCT:                                                                                                          \
-        if (fold)                                                                                                      \
-            hipLaunchKernelGGL((ks_inner2_kernel<NCT, true>), grid, dim3(256), 0, st, (const i64 *)tmp, (const i64 *)ksk, \
-                               (i64)part_stride, (i64)comp_stride, (i64)row_off, (i64 *)s, nparts, rows, N, *fold,     \
-                               (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);                    \
-        else                                                                                                           \
-            hipLaunchKernelGGL((ks_inner2_kernel<NCT, false>), grid, dim3(256), 0, st, (const i64 *)tmp, (const i64 *)ksk, \
-                               (i64)part_stride, (i64)comp_stride, (i64)row_off, (i64 *)s, nparts, rows, N, nofold,    \
-                               (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);                    \
+        if (fold && planes) LF_INNER_LAUNCH(NCT, true, true, *fold);                                                   \
+        else if (fold) LF_INNER_LAUNCH(NCT, true, false, *fold);                                                       \
+        else if (planes) LF_INNER_LAUNCH(NCT, false, true, nofold);                                                    \
+        else LF_INNER_LAUNCH(NCT, false, false, nofold);                                                               \
         break;
+        const bool planes = key_format == LF_KEY_PLANES;
         switch (nct) {
             LF_INNER_CASE(1) LF_INNER_CASE(2) LF_INNER_CASE(4)
         }
+#undef LF_INNER_LAUNCH
 #undef LF_INNER_CASE
-        }
     }
     // K4: inverse transform -> canonical coefficients (relaxed, tail 2), in place on s
     const int inv_polys = 2 * nct;
@@ -868,9 +706,9 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
             continue;
         }
         if (pass == 1 && S1 <= 4) {
-            if (mixed) {
+            if (mixed || fold_piv) {
                 launch_inv_cols_mixed(S1, inv_polys, st, (i64 *)s, g, in, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,
-                                      (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+                                      (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh, fold_piv ? &pf : nullptr);
                 continue;
             }
             if (dp.n)
@@ -897,6 +735,13 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
                                g, in, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, pass == 1 ? 2 : TAIL_NONE,
                                (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     }
+    if (piv != nullptr && !fold_piv) {   // the pivots as their own launch
+        const int64_t *ss[LF_BATCH_MAX];
+        if (inv_polys > LF_BATCH_MAX) return LF_ERR_ARG;
+        for (int i = 0; i < inv_polys; ++i) ss[i] = s + (((int64_t)i * rows) << logN);
+        return lf_ks_pivots(ss, inv_polys, piv->ell, piv->K, (int64_t)1 << logN, piv->ws, piv->ws_words, piv->PiR, piv->PiP, ql, qh, kl, kh,
+                            -1, (void *)st);
+    }
     return (int)hipGetLastError();
 }
 
@@ -905,30 +750,32 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
 extern "C" {
 
 int lf_tune(int which, int value) {
-    int *knob = which == LF_TUNE_KS_EXT_COLS_MAX ? &g_ks_ext_cols_max : nullptr;
+    int *knob = which == LF_TUNE_KS_EXT_COLS_MAX ? &g_ks_ext_cols_max : which == LF_TUNE_KS_PIVOT_FOLD ? &g_ks_pivot_fold : nullptr;
     if (!knob) return -1;
     const int old = *knob;
     if (value >= 0 && !(which == LF_TUNE_KS_EXT_COLS_MAX && value > 4)) *knob = value;
     return old;
 }
 
-int lf_key_planes(const int64_t *src, int64_t *dst, int rows, int64_t N, const int64_t *ql, const int64_t *qh, int device,
-                  void *stream) {
-    if (rows < 0 || rows > 65535 || N < 1024 || (N & 1023) || !src || !dst || src == dst || !ql || !qh ||
-        (((uintptr_t)src | (uintptr_t)dst) & 15))
+int lf_key_planes(const int64_t *src_b, const int64_t *src_a, int64_t *dst_b, int64_t *dst_a, int rows, int64_t N,
+                  const int64_t *ql, const int64_t *qh, int device, void *stream) {
+    if (rows < 0 || rows > 65535 || N < 2 || (N & 1) || !src_b || !src_a || !dst_b || !dst_a || dst_b == dst_a || src_b == dst_b ||
+        src_a == dst_a || src_a == dst_b || src_b == dst_a || !ql || !qh ||
+        (((uintptr_t)src_b | (uintptr_t)src_a | (uintptr_t)dst_b | (uintptr_t)dst_a) & 15))
         return LF_ERR_ARG;
     if (rows == 0) return 0;
     if (int e = lf_set_device(device)) return e;
-    hipLaunchKernelGGL(key_planes_kernel, dim3((unsigned)(N / 1024), (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
-                       (const i64 *)src, (i64 *)dst, (i64)N, (const i64 *)ql, (const i64 *)qh);
+    hipLaunchKernelGGL(key_planes_kernel, dim3((unsigned)((N / 2 + 255) / 256), (unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                       (const i64 *)src_b, (const i64 *)src_a, (i64 *)dst_b, (i64 *)dst_a, (i64)N, (const i64 *)ql, (const i64 *)qh);
     return (int)hipGetLastError();
 }
 
 int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int nparts, int rows, int logN, const int64_t *desc,
                      const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
                      int64_t row_off, int key_format, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
-                     const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
-                     const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+                     const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const lf_ks_pivot_fold *piv,
+                     const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+                     void *stream) {
     if (nparts < 1 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
         !q_host || !psi_dp || !ipsi_dp || !Ed || (nct != 1 && nct != 2 && nct != 4))
         return LF_ERR_ARG;
@@ -937,7 +784,7 @@ int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int np
     if (int e = ks_forward(state, state_stride, nct, nparts, rows, logN, desc, E, Ed, tmp, psi_br, psi_dp, q_host, ql, qh, kl, kh, st))
         return e;
     return ks_tail(nct, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh,
-                   kl, kh, st, nullptr, key_format);
+                   kl, kh, st, nullptr, key_format, piv);
 }
 
 /* The two halves of lf_ks_core as separate calls, so that a limb-sharded engine can start on the digits that have
@@ -958,14 +805,14 @@ int lf_ks_fwd(const int64_t *state, int nparts, int rows, int logN, const int64_
 
 int lf_ks_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
                int key_format, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
-               const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
-               void *stream) {
+               const lf_ks_pivot_fold *piv, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+               const int64_t *kh, int device, void *stream) {
     if (nparts < 1 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
         !q_host || !ipsi_dp)
         return LF_ERR_ARG;
     if (int e = lf_set_device(device)) return e;
     return ks_tail(1, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh, kl,
-                   kh, (hipStream_t)stream, nullptr, key_format);
+                   kh, (hipStream_t)stream, nullptr, key_format, piv);
 }
 
 /* Relinearisation inside cc_mult (see RelinFold): lf_ks_core_batch / lf_ks_fwd / lf_ks_tail whose sums additionally
@@ -975,8 +822,8 @@ int lf_relin_core_batch(const int64_t *state, int64_t state_stride, int nct, int
                         const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
                         int64_t row_off, int key_format, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
                         const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *x, int64_t x_ct_stride,
-                        const int64_t *PR, int ell, const uint8_t *own, const int64_t *q_host, const int64_t *ql, const int64_t *qh,
-                        const int64_t *kl, const int64_t *kh, int device, void *stream) {
+                        const int64_t *PR, int ell, const uint8_t *own, const lf_ks_pivot_fold *piv, const int64_t *q_host,
+                        const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
     if (nparts < 1 || nparts > 254 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
         !q_host || !psi_dp || !ipsi_dp || !Ed || (nct != 1 && nct != 2 && nct != 4) || !x || !PR || ell < 0 || ell > rows)
         return LF_ERR_ARG;
@@ -987,7 +834,7 @@ int lf_relin_core_batch(const int64_t *state, int64_t state_stride, int nct, int
         return e;
     const RelinFold fold{(const i64 *)x, (i64)x_ct_stride, (const i64 *)PR, ell, (const unsigned char *)own};
     return ks_tail(nct, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh,
-                   kl, kh, st, &fold, key_format);
+                   kl, kh, st, &fold, key_format, piv);
 }
 
 int lf_relin_fwd(const int64_t *state, int first, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,
@@ -1005,24 +852,26 @@ int lf_relin_fwd(const int64_t *state, int first, int nparts, int rows, int logN
 
 int lf_relin_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
                   int key_format, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
-                  const int64_t *x, const int64_t *PR, int ell, const uint8_t *own, const int64_t *q_host, const int64_t *ql,
-                  const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+                  const int64_t *x, const int64_t *PR, int ell, const uint8_t *own, const lf_ks_pivot_fold *piv,
+                  const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+                  void *stream) {
     if (nparts < 1 || nparts > 254 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
         !q_host || !ipsi_dp || !x || !PR || ell < 0 || ell > rows)
         return LF_ERR_ARG;
     if (int e = lf_set_device(device)) return e;
     const RelinFold fold{(const i64 *)x, 0, (const i64 *)PR, ell, (const unsigned char *)own};
     return ks_tail(1, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh, kl,
-                   kh, (hipStream_t)stream, &fold, key_format);
+                   kh, (hipStream_t)stream, &fold, key_format, piv);
 }
 
 int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,
                const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
                int key_format, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
-               const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host,
-               const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+               const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const lf_ks_pivot_fold *piv,
+               const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+               void *stream) {
     return lf_ks_core_batch(state, 0, 1, nparts, rows, logN, desc, E, Ed, ksk, part_stride, comp_stride, row_off, key_format, tmp, s, psi_br,
-                            psi_dp, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh, kl, kh, device, stream);
+                            psi_dp, ipsi_br, ipsi_dp, Ninv, piv, q_host, ql, qh, kl, kh, device, stream);
 }
 
 }  // extern "C"

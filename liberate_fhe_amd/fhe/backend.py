@@ -11,7 +11,7 @@ import ctypes
 
 import torch
 
-from .._native import lib, check, KsPlan, LF_KEY_PLANES
+from .._native import lib, check, KsPlan, KsPivotFold, LF_KEY_PLANES
 from ..ntt import ntt_cuda, twiddles
 
 
@@ -55,6 +55,11 @@ def _pd(t):
     if not t.is_contiguous():
         raise ValueError("HipBackend: contiguous tensor required")
     return t.data_ptr()
+
+
+def _pv(piv):
+    """lf_ks_pivot_fold pointer (None -> NULL)."""
+    return None if piv is None else ctypes.byref(piv)
 
 
 def _parr(tensors):
@@ -154,14 +159,26 @@ class HipBackend:
                                       _pd(PiP), _p(Rs), pinv, _p(g2q), *c.mont(), dev, st),
               "lf_ks_moddown_batch")
 
-    def ks_moddown_ws(self, ss, outs, addends, ell, K, ws, PiR, Rs, c: Consts, PiP=None, galois=None):
+    def ks_moddown_ws(self, ss, outs, addends, ell, K, ws, PiR, Rs, c: Consts, PiP=None, galois=None, pivots_ready=False):
         """ks_moddown_batch with a workspace tensor `ws` (int64, >= moddown_ws_words(..) words): the special-prime
-        chain is evaluated once per coefficient by a first launch."""
+        chain is evaluated once per coefficient by a first launch — or, pivots_ready: by the key-switch tail that was
+        given pivot_fold(ws, ..) (lf_ks_moddown_piv: the second launch alone)."""
         dev, st = _ds(outs[0])
         pinv, g2q = (0, None) if galois is None else galois
-        check(lib.lf_ks_moddown_ws(_parr(ss), _parr(outs), _parr(addends), len(ss), ell, K, outs[0].size(-1), _p(ws),
-                                   ws.numel(), _p(PiR), _pd(PiP), _p(Rs), pinv, _p(g2q),
-                                   *c.mont(), dev, st), "lf_ks_moddown_ws")
+        fn, what = (lib.lf_ks_moddown_piv, "lf_ks_moddown_piv") if pivots_ready else (lib.lf_ks_moddown_ws, "lf_ks_moddown_ws")
+        check(fn(_parr(ss), _parr(outs), _parr(addends), len(ss), ell, K, outs[0].size(-1), _p(ws), ws.numel(), _p(PiR), _pd(PiP),
+                 _p(Rs), pinv, _p(g2q), *c.mont(), dev, st), what)
+
+    pivot_fold_min_K = 2     # with one special prime there is no elimination to fold (the single-launch mod-down wins)
+
+    @staticmethod
+    def pivot_fold(ws, PiR, PiP, ell, K):
+        """lf_ks_pivot_fold for the key-switch tails (ks_core / ks_core_batch / ks_tail `piv=`): the mod-down's
+        special-prime elimination runs inside the tail's last inverse pass and fills `ws`; finish with
+        ks_moddown_ws(.., pivots_ready=True).  The struct only borrows the tensors: the caller keeps them alive."""
+        pf = KsPivotFold()
+        pf.ws, pf.ws_words, pf.PiR, pf.PiP, pf.ell, pf.K = _p(ws), ws.numel(), _p(PiR), _pd(PiP), ell, K
+        return pf
 
     @staticmethod
     def moddown_ws_words(count, ell, K, N):
@@ -213,11 +230,13 @@ class HipBackend:
         """Format of a packed key tensor (LF_KEY_RAW unless key_planes() made it)."""
         return getattr(key, "lf_key_format", 0)
 
-    def key_planes(self, src, dst, c: Consts):
-        """One [rows, N] block of a key (any lazy words) -> the planes format the fused key-switch entries read with
-        key_format = LF_KEY_PLANES (include/ckks_hip.h): fp64-class rows as 32-bit + 16-bit planes of canonical residues."""
-        dev, st = _ds(dst)
-        check(lib.lf_key_planes(_p(src), _p(dst), src.size(0), src.size(1), _p(c.ql), _p(c.qh), dev, st), "lf_key_planes")
+    def key_planes(self, src_b, src_a, dst_b, dst_a, c: Consts):
+        """The two [rows, N] components of one key part (any lazy words) -> the planes format the fused key-switch entries
+        read with key_format = LF_KEY_PLANES (include/ckks_hip.h): fp64-class rows as interleaved 32-bit + 16-bit planes of
+        the canonical residues of both components, integer-class rows raw."""
+        dev, st = _ds(dst_b)
+        check(lib.lf_key_planes(_p(src_b), _p(src_a), _p(dst_b), _p(dst_a), src_b.size(0), src_b.size(1), _p(c.ql), _p(c.qh), dev, st),
+              "lf_key_planes")
 
     @staticmethod
     def mark_planes(t):
@@ -228,7 +247,7 @@ class HipBackend:
     relin_fold = True        # cc_mult's d0 / d1 folded into the key-switch sums (lf_intt_mul, lf_relin_*)
 
     def ks_core(self, state, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv,
-                c: Consts, fold=None):
+                c: Consts, fold=None, piv=None):
         """extend + NTT + key inner product + inverse NTT in three fused launches per arithmetic class.
         fold = (x stack [4, ell, N], PR [ell], own [rows] uint8 or None): cc_mult's d0 / d1 enter the sums in the NTT domain and
         the digits' own limbs come from x1 * y1 instead of an extension (lf_relin_core_batch)."""
@@ -241,12 +260,12 @@ class HipBackend:
             x, PR, own = fold
             check(lib.lf_relin_core_batch(_p(state), 0, 1, nparts, rows, logN, _p(desc), _p(E), _pd(Ed), base, part_stride,
                                           comp_stride, row_off, self._kfmt(key), _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
-                                          _p(x), 0, _p(PR), x.size(1), _pb(own), c.qptr(), *c.mont(), dev, st),
+                                          _p(x), 0, _p(PR), x.size(1), _pb(own), _pv(piv), c.qptr(), *c.mont(), dev, st),
                   "lf_relin_core_batch")
             return
         check(lib.lf_ks_core(_p(state), nparts, rows, logN, _p(desc), _p(E), _pd(Ed), base, part_stride, comp_stride,
                              row_off, self._kfmt(key), _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
-                             c.qptr(), *c.mont(), dev, st), "lf_ks_core")
+                             _pv(piv), c.qptr(), *c.mont(), dev, st), "lf_ks_core")
 
     def ks_fwd(self, state, first, count, rows, logN, desc, E, Ed, tmp, psi, c: Consts, own=None):
         """Extension + forward NTT of digits first .. first + count - 1 into tmp[first:first + count] (lf_ks_fwd; with
@@ -261,7 +280,7 @@ class HipBackend:
         check(lib.lf_ks_fwd(_p(state), count, rows, logN, _p(desc) + first * 3 * 8, _p(E), _pd(Ed),
                             _p(tmp) + first * rows * N * 8, _p(psi), psi_dp, c.qptr(), *c.mont(), dev, st), "lf_ks_fwd")
 
-    def ks_tail(self, nparts, rows, logN, key, first_part, row_off, tmp, s, ipsi, Ninv, c: Consts, fold=None):
+    def ks_tail(self, nparts, rows, logN, key, first_part, row_off, tmp, s, ipsi, Ninv, c: Consts, fold=None, piv=None):
         """Inner product of all extended digits with the key + inverse NTT (lf_ks_tail; fold: lf_relin_tail, see ks_core)."""
         dev, st = _ds(s)
         part_stride, comp_stride = key.stride(0), key.stride(1)
@@ -270,10 +289,10 @@ class HipBackend:
         if fold is not None:
             x, PR, own = fold
             check(lib.lf_relin_tail(nparts, rows, logN, base, part_stride, comp_stride, row_off, self._kfmt(key), _p(tmp), _p(s), _p(ipsi), ipsi_dp,
-                                    _p(Ninv), _p(x), _p(PR), x.size(1), _pb(own), c.qptr(), *c.mont(), dev, st), "lf_relin_tail")
+                                    _p(Ninv), _p(x), _p(PR), x.size(1), _pb(own), _pv(piv), c.qptr(), *c.mont(), dev, st), "lf_relin_tail")
             return
         check(lib.lf_ks_tail(nparts, rows, logN, base, part_stride, comp_stride, row_off, self._kfmt(key), _p(tmp), _p(s), _p(ipsi), ipsi_dp,
-                             _p(Ninv), c.qptr(), *c.mont(), dev, st), "lf_ks_tail")
+                             _p(Ninv), _pv(piv), c.qptr(), *c.mont(), dev, st), "lf_ks_tail")
 
     # ---- whole ops behind one native call (lf_cc_mult_evk / lf_switch_key over an lf_ks_plan) ------------------------
     native_ops = True
@@ -327,7 +346,7 @@ class HipBackend:
     ks_batch_sizes = (4, 2)   # ciphertexts per lf_ks_core_batch call (largest first)
 
     def ks_core_batch(self, states, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv,
-                      c: Consts, fold=None):
+                      c: Consts, fold=None, piv=None):
         """ks_core for len(states) in (2, 4) ciphertexts under one key: states = [nct, state_rows, N] tensor,
         tmp [nct, nparts, rows, N], s [nct, 2, rows, N].  fold = (x [nct, 4, ell, N], PR [ell]), see ks_core."""
         dev, st = _ds(s)
@@ -339,12 +358,12 @@ class HipBackend:
             x, PR, own = fold
             check(lib.lf_relin_core_batch(_p(states), states.stride(0), states.size(0), nparts, rows, logN, _p(desc), _p(E),
                                           _pd(Ed), base, part_stride, comp_stride, row_off, self._kfmt(key), _p(tmp), _p(s), _p(psi), psi_dp,
-                                          _p(ipsi), ipsi_dp, _p(Ninv), _p(x), x.stride(0), _p(PR), x.size(2), _pb(own), c.qptr(),
+                                          _p(ipsi), ipsi_dp, _p(Ninv), _p(x), x.stride(0), _p(PR), x.size(2), _pb(own), _pv(piv), c.qptr(),
                                           *c.mont(), dev, st), "lf_relin_core_batch")
             return
         check(lib.lf_ks_core_batch(_p(states), states.stride(0), states.size(0), nparts, rows, logN, _p(desc), _p(E),
                                    _pd(Ed), base, part_stride, comp_stride, row_off, self._kfmt(key), _p(tmp), _p(s), _p(psi), psi_dp,
-                                   _p(ipsi), ipsi_dp, _p(Ninv), c.qptr(), *c.mont(), dev, st), "lf_ks_core_batch")
+                                   _p(ipsi), ipsi_dp, _p(Ninv), _pv(piv), c.qptr(), *c.mont(), dev, st), "lf_ks_core_batch")
 
     def ks_moddown(self, s, out, addend, ell, K, PiR, Rs, c: Consts, PiP=None):
         dev, st = _ds(out)

@@ -432,9 +432,8 @@ class ckks_engine(EvaluatorOps):
     def _planes_wanted(self):
         """Fused key switches (two-pass ring degrees) read the key in the planes format (include/ckks_hip.h LF_KEY_PLANES:
         the inner product with the key runs at the HBM rate and most of its bytes are key words; fp64-class rows shrink to
-        6 of 8 bytes per word).  The unfused path (logN <= 12) and checker backends read raw words."""
-        return (getattr(self.backend, "key_planes", None) is not None and self.ctx.logN >= self.backend.fused_ks_min_logN
-                and self.ctx.N % 1024 == 0)
+        12 instead of 16 bytes per word pair).  The unfused path (logN <= 12) and checker backends read raw words."""
+        return getattr(self.backend, "key_planes", None) is not None and self.ctx.logN >= self.backend.fused_ks_min_logN
 
     def _planes_of(self, blocks_of_part, i, d):
         """Planes-format tensor [parts, 2, rows, N] of local device index i from per-part (b rows, a rows) tensors."""
@@ -442,8 +441,7 @@ class ckks_engine(EvaluatorOps):
         nparts = len(blocks_of_part)
         out = torch.empty((nparts, 2, self.ntt.stops[0][d], self.ctx.N), dtype=torch.int64, device=self.ntt.devices[d])
         for p_, (b_rows, a_rows) in enumerate(blocks_of_part):
-            for comp, rows in enumerate((b_rows, a_rows)):
-                self.backend.key_planes(rows if rows.is_contiguous() else rows.contiguous(), out[p_, comp], c)
+            self.backend.key_planes(b_rows.contiguous(), a_rows.contiguous(), out[p_, 0], out[p_, 1], c)
         return self.backend.mark_planes(out)
 
     def _key_pack(self, ksk):
@@ -1075,6 +1073,12 @@ class ckks_engine(EvaluatorOps):
             ninv = self._vec("Ninv", d, level, True)
             dig, ready = digits[d]
             fused = logN >= self.backend.fused_ks_min_logN
+            # the mod-down's special-prime elimination inside the key switch's last inverse pass (lf_ks_pivot_fold)
+            ws = self._ws("ks_moddown", (self.backend.moddown_ws_words(2, ell, K, N),), d)
+            piv = None
+            if fused and K >= getattr(self.backend, "pivot_fold_min_K", 1 << 30):
+                piv = self.backend.pivot_fold(ws, tabs[("pir", d)], tabs[("pip", d)], ell, K)
+            pkw = {} if piv is None else {"piv": piv}
             if fused and len(ready) > 1 and hasattr(self.backend, "ks_fwd"):
                 # 3. extend + forward NTT of this rank's own digits while the others are on the wire, then of the
                 # foreign runs; 4. once all are in: key inner product over all digits + inverse NTT
@@ -1085,7 +1089,7 @@ class ckks_engine(EvaluatorOps):
                     self.backend.ks_fwd(dig, first, count, rows, logN, desc, E, Ed, ext, tw, cs, **okw)
                 fkw = {} if fold is None else {"fold": fold[d]}
                 self.backend.ks_tail(nparts, rows, logN, key, tabs["first_part"], self.ntt.starts[level][d], ext, s, itw,
-                                     ninv, cs, **fkw)
+                                     ninv, cs, **fkw, **pkw)
                 ready = []
             for handle, _, _ in ready:
                 if handle is not None:
@@ -1095,7 +1099,7 @@ class ckks_engine(EvaluatorOps):
                 # leave the chip in coefficient form
                 fkw = {} if fold is None else {"fold": fold[d]}
                 self.backend.ks_core(dig, nparts, rows, logN, desc, E, Ed, key, tabs["first_part"],
-                                     self.ntt.starts[level][d], ext, s, tw, itw, ninv, cs, **fkw)
+                                     self.ntt.starts[level][d], ext, s, tw, itw, ninv, cs, **fkw, **pkw)
             elif not fused:
                 assert fold is None
                 # 3. extend every digit to this device's rows, forward NTT
@@ -1114,9 +1118,9 @@ class ckks_engine(EvaluatorOps):
                     add = add.contiguous()
                 adds.append(add)
             gal = None if galois is None else (galois[0], self._vec("_2q", d, level, False) if galois[1] else None)
-            ws = self._ws("ks_moddown", (self.backend.moddown_ws_words(2, ell, K, N),), d)
+            mkw = {} if piv is None else {"pivots_ready": True}
             self.backend.ks_moddown_ws([s[0], s[1]], [out[0], out[1]], adds, ell, K, ws, tabs[("pir", d)], rs, cs,
-                                       PiP=tabs[("pip", d)], galois=gal)
+                                       PiP=tabs[("pip", d)], galois=gal, **mkw)
             c0.append(out[0]); c1.append(out[1])
         return c0, c1
 
@@ -1362,6 +1366,11 @@ class ckks_engine(EvaluatorOps):
         packs = self._key_pack(key)
         kpack = packs[self._loc(0, special=True).index(d)]
         fkw = {} if fold is None else {"fold": fold}
+        ws = self._ws("ks_moddown_batch", (self.backend.moddown_ws_words(2 * nct, ell, K, N),), d)
+        piv = None
+        if K >= getattr(self.backend, "pivot_fold_min_K", 1 << 30):
+            piv = self.backend.pivot_fold(ws, tabs[("pir", d)], tabs[("pip", d)], ell, K)
+            fkw["piv"] = piv
         self.backend.ks_core_batch(states, nparts, rows, logN, desc, E, Ed, kpack, tabs["first_part"],
                                    self.ntt.starts[level][d], ext, s, self._tw(d, level, True),
                                    self._tw(d, level, True, True), self._vec("Ninv", d, level, True), cs, **fkw)
@@ -1373,9 +1382,9 @@ class ckks_engine(EvaluatorOps):
         for pair in addends:
             for a in pair:
                 adds.append(a if a is None or a.is_contiguous() else a.contiguous())
-        ws = self._ws("ks_moddown_batch", (self.backend.moddown_ws_words(2 * nct, ell, K, N),), d)
+        mkw = {} if piv is None else {"pivots_ready": True}
         self.backend.ks_moddown_ws(ss, outs, adds, ell, K, ws, tabs[("pir", d)], self._vec("Rs", d, level, True), cs,
-                                   PiP=tabs[("pip", d)], galois=gal)
+                                   PiP=tabs[("pip", d)], galois=gal, **mkw)
         return out
 
     def cc_mult_batch(self, pairs: list, evk: data_struct) -> list:

@@ -23,6 +23,22 @@ def test_every_declared_symbol_is_exported():
     assert _native.lib.lf_abi_version() == 10     # pure host call, no HIP runtime use
 
 
+def test_python_binding_passes_as_many_arguments_as_the_header_declares():
+    """ctypes does not check arity against the library: a signature that drifts from include/ckks_hip.h would shift every
+    following argument.  Parameter counts (and pointer / integer kind) of the binding table against the header."""
+    from liberate_fhe_amd import _native
+    text = open(os.path.join(ROOT, "include", "ckks_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for name, params in re.findall(r"\bint(?:64_t)?\s+(lf_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        params = [p.strip() for p in params.split(",")] if params.strip() not in ("", "void") else []
+        sig = _native._SIGNATURES[name]
+        assert len(sig) == len(params), f"{name}: header has {len(params)} parameters, binding {len(sig)}"
+        for i, (decl, ct) in enumerate(zip(params, sig)):
+            is_ptr = "*" in decl
+            bound_ptr = ct is ctypes.c_void_p or (isinstance(ct, type) and issubclass(ct, ctypes._Pointer))
+            assert is_ptr == bound_ptr, f"{name} parameter {i} ({decl}): pointer-ness differs from the binding ({ct})"
+
+
 def test_shim_exposes_the_fifteen_reference_functions():
     from liberate_fhe_amd.ntt import ntt_cuda
     expected = {"mont_mult", "mont_enter", "ntt", "enter_ntt", "intt", "mont_redc", "intt_exit", "intt_exit_reduce",

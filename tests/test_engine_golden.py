@@ -430,8 +430,8 @@ def test_hip_native_op_entries_equal_the_step_by_step_engine(name):
 
 @pytest.mark.gpu
 def test_key_planes_format_words_and_results():
-    """lf_key_planes: fp64-class rows become a 32-bit plane + a 16-bit plane of the CANONICAL residues, integer-class rows
-    stay raw — checked word for word against numpy on lazy and signed-lazy inputs; and the engine gives the same digests
+    """lf_key_planes: the two components of an fp64-class row become one interleaved 32-bit plane + one 16-bit plane of
+    the CANONICAL residues, integer-class rows stay raw — checked word for word against numpy on lazy and signed-lazy inputs; and the engine gives the same digests
     whether its key switch reads the key in the planes format (the default for two-pass ring degrees) or raw, for a key
     the engine made, a foreign key, and a key edited in place after its first use."""
     from liberate_fhe_amd.fhe import ckks_engine
@@ -441,19 +441,21 @@ def test_key_planes_format_words_and_results():
     N, c = eng.ctx.N, eng._consts(0, 0, True)
     q = c.q_host
     rng = np.random.default_rng(11)
-    src = np.stack([rng.integers(-int(p) + 1, 2 * int(p), size=N, dtype=np.int64) for p in q])     # signed-lazy and lazy words
-    dst = torch.full((len(q), N), -1, dtype=torch.int64, device="cuda:0")
-    eng.backend.key_planes(torch.from_numpy(src).cuda(), dst, c)
+    src = [np.stack([rng.integers(-int(p) + 1, 2 * int(p), size=N, dtype=np.int64) for p in q]) for _ in range(2)]   # signed-lazy and lazy words
+    dst = torch.full((2, len(q), N), -1, dtype=torch.int64, device="cuda:0")
+    eng.backend.key_planes(torch.from_numpy(src[0]).cuda(), torch.from_numpy(src[1]).cuda(), dst[0], dst[1], c)
     got = dst.cpu().numpy()
     for r, p in enumerate(q):
-        canon = src[r] % int(p)
         if int(p) >= (1 << 41):
-            assert (got[r] == src[r]).all()
+            assert (got[0, r] == src[0][r]).all() and (got[1, r] == src[1][r]).all()
             continue
-        raw = got[r].view(np.uint32)
-        assert (raw[:N] == (canon & 0xffffffff).astype(np.uint32)).all()
-        assert (raw[N:N + N // 2].view(np.uint16) == (canon >> 32).astype(np.uint16)).all()
-        assert (got[r].view(np.uint32)[N + N // 2:] == 0xffffffff).all()          # the rest of the slot is not written
+        cb, ca = src[0][r] % int(p), src[1][r] % int(p)
+        lo = got[0, r].view(np.uint32).reshape(N // 2, 4)           # { lo b[j], lo b[j+1], lo a[j], lo a[j+1] }
+        hi = got[1, r].view(np.uint16)[:2 * N].reshape(N // 2, 4)   # { hi b[j], hi b[j+1], hi a[j], hi a[j+1] }
+        for col, canon in ((0, cb[0::2]), (1, cb[1::2]), (2, ca[0::2]), (3, ca[1::2])):
+            assert (lo[:, col] == (canon & 0xffffffff).astype(np.uint32)).all()
+            assert (hi[:, col] == (canon >> 32).astype(np.uint16)).all()
+        assert (got[1, r].view(np.uint32)[N:] == 0xffffffff).all()          # the rest of the second slot is not written
 
     def run(e):
         evk, rotk = synth.key_switch_key(e, 5), synth.key_switch_key(e, 6, origin="rotation key:3")     # foreign (unpacked) keys

@@ -1,0 +1,43 @@
+"""A/B of an lf_tune knob in ONE process, alternating settings:  python tools/ab_tune.py <knob> <value A> <value B> [gold|silver] [rounds]
+   knob 1 = LF_TUNE_KS_EXT_COLS_MAX, 2 = LF_TUNE_KS_PIVOT_FOLD (include/ckks_hip.h)."""
+import os, sys, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+warnings.filterwarnings("ignore")
+import torch
+from liberate_fhe_amd._native import lib
+from liberate_fhe_amd.fhe import ckks_engine, presets
+from liberate_fhe_amd.utils import synth
+
+knob, va, vb = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+name = sys.argv[4] if len(sys.argv) > 4 else "gold"
+rounds = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+e = ckks_engine(**{**presets.params[name], "devices": ["cuda:0"]})
+a, b = synth.ciphertext(e, 3, 0), synth.ciphertext(e, 4, 0)
+evk, rotk = synth.key_switch_key(e, 5), synth.key_switch_key(e, 6, origin="rotation key:1")
+cts = [synth.ciphertext(e, 100 + i, 0) for i in range(16)]
+
+
+def timed(fn, n):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+n = 60 if name == "gold" else 100
+for v in (va, vb):
+    lib.lf_tune(knob, v)
+    for _ in range(40):
+        e.cc_mult(a, b, evk); e.rotate_single(a, rotk)
+    e.rotate_single_batch(cts, rotk)
+torch.cuda.synchronize()
+for r in range(rounds):
+    for v in (va, vb):
+        lib.lf_tune(knob, v)
+        us_m = timed(lambda: e.cc_mult(a, b, evk), n)
+        us_r = timed(lambda: e.rotate_single(a, rotk), n)
+        us_b = timed(lambda: e.rotate_single_batch(cts, rotk), 3) / 16
+        print(f"{name} knob {knob} = {v}: cc_mult {us_m:7.1f} us  rotate {us_r:7.1f} us  rotate batch16 {us_b:7.1f} us/ct", flush=True)
