@@ -54,9 +54,6 @@ int lf_limits(int which);
  *                             column kernel (one register step per column, no LDS); above it the LDS-tiled form.
  *   (knob 0 was the one-launch key-switch transform of round 3: slower at every preset size on MI355X, removed.) */
 #define LF_TUNE_KS_EXT_COLS_MAX 1
-/*   LF_TUNE_KS_PIVOT_FOLD     1 (default): a key-switch tail given an lf_ks_pivot_fold eliminates the special primes inside
- *                             its last inverse pass; 0: it launches the pivots kernel behind that pass instead. */
-#define LF_TUNE_KS_PIVOT_FOLD 2
 int lf_tune(int which, int value);
 
 /* Measurement entry (not one of the reference's ops; the engine never calls it): ONE wave, launched on `stream`, takes
@@ -214,20 +211,6 @@ int lf_ks_moddown(const int64_t *s, int64_t *out, const int64_t *addend, int ell
                   const int64_t *PiR, const double *PiP, const int64_t *Rs, const int64_t *ql, const int64_t *qh, const int64_t *kl,
                   const int64_t *kh, int device, void *stream);
 
-/* Optional argument of the fused key-switch entries below (NULL: off).  The mod-down (lf_ks_moddown_ws) starts with the
- * elimination of the K special rows of the sums among themselves — the "pivots", once per coefficient, ckks_engine.py:850-901.
- * With a pivot fold the last inverse pass of the key switch does that for the special limbs it has just transformed and
- * leaves the pivots (and the per-row constants) in the mod-down workspace `ws`; the special rows of `s` are then NOT written,
- * and the caller finishes with lf_ks_moddown_piv (the mod-down's second launch alone) on the same workspace.  One launch and
- * one round trip of the special rows less per key switch; every output word is the same. */
-typedef struct lf_ks_pivot_fold {
-    int64_t *ws;            /* device, >= lf_ks_moddown_ws_words(2 * nct, ell, K, N) words */
-    int64_t ws_words;
-    const int64_t *PiR;     /* [K][ell + K], as lf_ks_moddown */
-    const double *PiP;      /* [K][ell + K] or NULL, as lf_ks_moddown */
-    int32_t ell, K;         /* ordinary limbs and special primes of the `rows` = ell + K limbs */
-} lf_ks_pivot_fold;
-
 /* Fused key-switch core for two-pass ring degrees (logN >= 13): extend + NTT + inner product with the key +
  * sum over digits + inverse NTT to canonical coefficients, i.e. lf_ks_extend -> lf_ntt -> lf_ks_inner ->
  * lf_intt(tail 2) (ckks_engine.py:707-743, 919, 931-934, 832-848) without materialising the extended digits.
@@ -241,8 +224,7 @@ typedef struct lf_ks_pivot_fold {
 int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,
                const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
                int key_format, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
-               const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const lf_ks_pivot_fold *piv,
-               const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+               const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
                void *stream);
 
 /* Key formats of the fused key-switch entries (`key_format`).  The inner product with the key is the one launch of a key
@@ -277,8 +259,7 @@ int lf_ks_digits_batch(const int64_t *const *a, int64_t *const *state, int count
 int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int nparts, int rows, int logN, const int64_t *desc,
                      const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
                      int64_t row_off, int key_format, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
-                     const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const lf_ks_pivot_fold *piv,
-                     const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+                     const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
                      void *stream);
 
 /* The two halves of lf_ks_core as separate calls (single ciphertext), so that a limb-sharded engine can start on the
@@ -293,7 +274,7 @@ int lf_ks_fwd(const int64_t *state, int nparts, int rows, int logN, const int64_
               const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 int lf_ks_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
                int key_format, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
-               const lf_ks_pivot_fold *piv, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+               const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
                const int64_t *kh, int device, void *stream);
 
 /* Relinearisation inside cc_mult (ckks_engine.py:1095-1101, 1117-1151) without inverse transforms of d0 and d1:
@@ -308,7 +289,7 @@ int lf_relin_core_batch(const int64_t *state, int64_t state_stride, int nct, int
                         const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
                         int64_t row_off, int key_format, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
                         const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *x, int64_t x_ct_stride,
-                        const int64_t *PR, int ell, const uint8_t *own, const lf_ks_pivot_fold *piv, const int64_t *q_host,
+                        const int64_t *PR, int ell, const uint8_t *own, const int64_t *q_host,
                         const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 /* own (optional DEVICE table of `rows` bytes, may be NULL): own[r] = the digit (storage order) whose primes include limb
  * r, 255 for the special limbs.  The extension of a digit's mixed-radix form to one of its own primes is the residue it
@@ -321,8 +302,7 @@ int lf_relin_fwd(const int64_t *state, int first, int nparts, int rows, int logN
                  void *stream);
 int lf_relin_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
                   int key_format, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
-                  const int64_t *x, const int64_t *PR, int ell, const uint8_t *own, const lf_ks_pivot_fold *piv,
-                  const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+                  const int64_t *x, const int64_t *PR, int ell, const uint8_t *own, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
                   void *stream);
 
 /* Batched forms: `count` (<= 8) independent operand sets in ONE launch — the two components of a ciphertext, the
@@ -345,13 +325,14 @@ int lf_ks_moddown_ws(const int64_t *const *s, int64_t *const *out, const int64_t
                      int64_t N, int64_t *ws, int64_t ws_words, const int64_t *PiR, const double *PiP, const int64_t *Rs,
                      int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl,
                      const int64_t *kh, int device, void *stream);
-/* Its two launches as separate entries: lf_ks_pivots fills the workspace (pivots of the `count` polynomials + per-row
- * constants), lf_ks_moddown_piv finishes from a filled workspace — what a caller runs after a key-switch tail that was given
- * an lf_ks_pivot_fold (the tail then has filled the workspace itself).  lf_ks_pivots; lf_ks_moddown_piv == lf_ks_moddown_ws. */
-int lf_ks_pivots(const int64_t *const *s, int count, int ell, int K, int64_t N, int64_t *ws, int64_t ws_words, const int64_t *PiR,
-                 const double *PiP, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
-                 void *stream);
-int lf_ks_moddown_piv(const int64_t *const *s, int64_t *const *out, const int64_t *const *addend, int count, int ell, int K,
+/* The same in ONE launch for K <= LF_MODDOWN_ONE_MAX_K special primes: every block eliminates the special rows for its own
+ * coefficients (K = 2: one REDC product per coefficient and row chunk — cheaper than a launch).  The per-row constants that
+ * lf_ks_moddown_ws writes behind the pivots on every call are level constants: lf_ks_moddown_consts writes them ONCE into a
+ * workspace, lf_ks_moddown_one only reads them (the pivot part of the workspace is not used).  Same outputs. */
+#define LF_MODDOWN_ONE_MAX_K 2
+int lf_ks_moddown_consts(int64_t *ws, int64_t ws_words, int count, int ell, int K, int64_t N, const double *PiP, const int64_t *ql,
+                         const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+int lf_ks_moddown_one(const int64_t *const *s, int64_t *const *out, const int64_t *const *addend, int count, int ell, int K,
                       int64_t N, const int64_t *ws, int64_t ws_words, const int64_t *PiR, const double *PiP, const int64_t *Rs,
                       int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl,
                       const int64_t *kh, int device, void *stream);

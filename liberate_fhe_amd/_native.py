@@ -54,8 +54,8 @@ _SIGNATURES = {
     "lf_ks_moddown_batch": [_P, _P, _P, _I, _I, _I, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _P],
     "lf_ks_moddown_ws": [_P, _P, _P, _I, _I, _I, _L, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _P],
     "lf_ks_moddown_ws_words": [_I, _I, _I, _L],
-    "lf_ks_pivots": [_P, _I, _I, _I, _L, _P, _L, _P, _P, _P, _P, _P, _P, _I, _P],
-    "lf_ks_moddown_piv": [_P, _P, _P, _I, _I, _I, _L, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _P],
+    "lf_ks_moddown_consts": [_P, _L, _I, _I, _I, _L, _P, _P, _P, _P, _P, _I, _P],
+    "lf_ks_moddown_one": [_P, _P, _P, _I, _I, _I, _L, _P, _L, _P, _P, _P, _L, _P, _P, _P, _P, _P, _I, _P],
     "lf_ks_digits_batch": [_P, _P, _I, _I, _P, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P],
     "lf_ks_digits_galois": [_P, _P, _I, _P, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P],
     "lf_galois_batch": [_P, _P, _I, _I, _I, _L, _P, _I, _P],
@@ -67,21 +67,16 @@ _SIGNATURES = {
     "lf_discrete_gaussian": [_P, _L, _P, _I, _I, _I, _P],
     "lf_randround": [_P, _P, _L, _I, _P],
     "lf_key_planes": [_P, _P, _P, _P, _I, _L, _P, _P, _I, _P],
-    "lf_ks_core_batch": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lf_ks_core_batch": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_ks_fwd": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
-    "lf_ks_tail": [_I, _I, _I, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lf_ks_tail": [_I, _I, _I, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_intt_mul": [_P, _P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
-    "lf_relin_core_batch": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lf_relin_core_batch": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_relin_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
-    "lf_relin_tail": [_I, _I, _I, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
-    "lf_ks_core": [_P, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lf_relin_tail": [_I, _I, _I, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lf_ks_core": [_P, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
 }
 
-
-
-class KsPivotFold(ctypes.Structure):
-    """lf_ks_pivot_fold (include/ckks_hip.h)."""
-    _fields_ = [("ws", _P), ("ws_words", _L), ("PiR", _P), ("PiP", _P), ("ell", ctypes.c_int32), ("K", ctypes.c_int32)]
 
 
 class KsPlan(ctypes.Structure):

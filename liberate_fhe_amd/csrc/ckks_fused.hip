@@ -319,6 +319,40 @@ __global__ void __launch_bounds__(256) ks_moddown_kernel(PtrBatch pb, int ell, i
 // in front of every block.)
 #define MD3_ROWS 4
 
+// the (2K + 1) x ell plain constants of the fp64 rows (one block of 256 threads): B_j, A_j = 2^31 B_j, Pinv — level constants
+__device__ __forceinline__ void md_row_constants(double *cst, int ell, int K, const double *__restrict__ PiP,
+                                                 const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                 const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    const int rows = ell + K;
+    const double two31 = 2147483648.0;
+    for (int r = threadIdx.x; r < ell; r += 256) {
+        const RowMod m = load_mod(ql, qh, kl, kh, r);
+        const bool dp = m.q < (1ull << 41);
+        const double q = (double)m.q, qinv = 1.0 / q;
+        double B = 1.0, pinv = 1.0;
+        for (int pi = 0; pi < K; ++pi) {
+            cst[(2 * pi) * ell + r] = dp ? dp_mulmod_q(B, two31, q, qinv) : 0.0;   // A_pi
+            cst[(2 * pi + 1) * ell + r] = dp ? B : 0.0;                             // B_pi
+            if (dp) {
+                // P_pi mod q_r from its 31-bit halves, then the running product
+                const int t = ell + K - 1 - pi;
+                double Pm = dp_mulmod_q((double)qh[t], two31, q, qinv) + (double)ql[t];
+                Pm = Pm >= q ? Pm - q : Pm;
+                Pm = Pm >= q ? Pm - q : Pm;
+                B = dp_mulmod_q(B, Pm, q, qinv);
+                pinv = dp_mulmod_q(pinv, PiP[(i64)pi * rows + r], q, qinv);
+            }
+        }
+        cst[(2 * K) * ell + r] = dp ? pinv : 0.0;
+    }
+}
+
+__global__ void __launch_bounds__(256) ks_md_consts_kernel(double *cst, int ell, int K, const double *__restrict__ PiP,
+                                                           const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                           const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    md_row_constants(cst, ell, K, PiP, ql, qh, kl, kh);
+}
+
 // workspace layout (words): [count][K][N] pivots, then (2K + 1) x ell doubles
 __global__ void __launch_bounds__(256) ks_pivots_kernel(PtrBatch pb, int count, int ell, int K, i64 N, i64 *__restrict__ ws,
                                                         const i64 *__restrict__ PiR, const double *__restrict__ PiP,
@@ -327,29 +361,7 @@ __global__ void __launch_bounds__(256) ks_pivots_kernel(PtrBatch pb, int count, 
     const int rows = ell + K;
     if ((int)blockIdx.y == count) {
         // constants of the ordinary rows (one block)
-        if (blockIdx.x != 0 || PiP == nullptr) return;
-        double *cst = reinterpret_cast<double *>(ws + (i64)count * K * N);
-        const double two31 = 2147483648.0;
-        for (int r = threadIdx.x; r < ell; r += 256) {
-            const RowMod m = load_mod(ql, qh, kl, kh, r);
-            const bool dp = m.q < (1ull << 41);
-            const double q = (double)m.q, qinv = 1.0 / q;
-            double B = 1.0, pinv = 1.0;
-            for (int pi = 0; pi < K; ++pi) {
-                cst[(2 * pi) * ell + r] = dp ? dp_mulmod_q(B, two31, q, qinv) : 0.0;   // A_pi
-                cst[(2 * pi + 1) * ell + r] = dp ? B : 0.0;                             // B_pi
-                if (dp) {
-                    // P_pi mod q_r from its 31-bit halves, then the running product
-                    const int t = ell + K - 1 - pi;
-                    double Pm = dp_mulmod_q((double)qh[t], two31, q, qinv) + (double)ql[t];
-                    Pm = Pm >= q ? Pm - q : Pm;
-                    Pm = Pm >= q ? Pm - q : Pm;
-                    B = dp_mulmod_q(B, Pm, q, qinv);
-                    pinv = dp_mulmod_q(pinv, PiP[(i64)pi * rows + r], q, qinv);
-                }
-            }
-            cst[(2 * K) * ell + r] = dp ? pinv : 0.0;
-        }
+        if (blockIdx.x == 0 && PiP != nullptr) md_row_constants(reinterpret_cast<double *>(ws + (i64)count * K * N), ell, K, PiP, ql, qh, kl, kh);
         return;
     }
     const i64 *__restrict__ s = pb.in[blockIdx.y];
@@ -384,7 +396,11 @@ __global__ void __launch_bounds__(256) ks_pivots_kernel(PtrBatch pb, int count, 
 
 // KK = K as a compile-time constant: the pivot halves live in 4 K doubles per thread, nothing is reserved for
 // the K the call does not have (8 slots cost 142 VGPRs = 3 waves per SIMD)
-template <int KK>
+// INLINE: the pivots are not read from the workspace but eliminated here, from the special rows of s, by every block for its
+// own two coefficients per thread (KK (KK - 1) / 2 REDC products per coefficient, redone by each of the ceil(ell / 4) row
+// chunks): for KK <= 2 — one product — cheaper than the pivots launch it replaces (silver: 4.9 us + a launch gap of a
+// 150 us op); the constants behind the pivots in the workspace must have been written once (lf_ks_moddown_consts).
+template <int KK, bool INLINE>
 __global__ void __launch_bounds__(256) ks_moddown_ws_kernel(PtrBatch pb, int count, int ell, i64 N, i64 gal_pinv,
                                                             const i64 *__restrict__ gal_2q, const i64 *__restrict__ ws,
                                                             const i64 *__restrict__ PiR, const i64 *__restrict__ Rs,
@@ -400,9 +416,33 @@ __global__ void __launch_bounds__(256) ks_moddown_ws_kernel(PtrBatch pb, int cou
     const double *__restrict__ cst = reinterpret_cast<const double *>(ws + (i64)count * KK * N);
     const i64 *__restrict__ piv = ws + (i64)blockIdx.z * KK * N + j;
     double ph[KK][2], pl[KK][2];
+    longlong2 pvr[INLINE ? KK : 1];   // INLINE: the pivots themselves, for the integer-class rows
+    if (INLINE) {
+        // the reference's elimination among the special rows, last prime first (ks_pivots_kernel, two coefficients)
+        longlong2 sp[KK];
+#pragma unroll
+        for (int t = 0; t < KK; ++t) sp[t] = *reinterpret_cast<const longlong2 *>(s + (i64)(ell + t) * N + j);
+#pragma unroll
+        for (int pi = 0; pi < KK; ++pi) {
+            const int t = KK - 1 - pi;
+            const longlong2 P = sp[t];
+            pvr[pi] = P;
+#pragma unroll
+            for (int u = 0; u < KK; ++u) {
+                if (u < t) {
+                    const RowMod m = load_mod(ql, qh, kl, kh, ell + u);
+                    const i64 pir = PiR[(i64)pi * rows + ell + u];
+                    i64 d = mm62s(csub(sp[u].x + m.q2 - P.x, m.q2), pir, m.q, m.k);
+                    sp[u].x = d < (i64)m.q ? d : d - (i64)m.q;
+                    d = mm62s(csub(sp[u].y + m.q2 - P.y, m.q2), pir, m.q, m.k);
+                    sp[u].y = d < (i64)m.q ? d : d - (i64)m.q;
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int pi = 0; pi < KK; ++pi) {
-        const longlong2 pv = *reinterpret_cast<const longlong2 *>(piv + (i64)pi * N);
+        const longlong2 pv = INLINE ? pvr[INLINE ? pi : 0] : *reinterpret_cast<const longlong2 *>(piv + (i64)pi * N);
         ph[pi][0] = (double)(unsigned)(pv.x >> 31); pl[pi][0] = (double)(unsigned)(pv.x & 0x7fffffffll);
         ph[pi][1] = (double)(unsigned)(pv.y >> 31); pl[pi][1] = (double)(unsigned)(pv.y & 0x7fffffffll);
     }
@@ -439,7 +479,7 @@ __global__ void __launch_bounds__(256) ks_moddown_ws_kernel(PtrBatch pb, int cou
             d[0] = mm62s(sv.x, rs, m.q, m.k);
             d[1] = mm62s(sv.y, rs, m.q, m.k);
             for (int pi = 0; pi < KK; ++pi) {
-                const longlong2 pv = *reinterpret_cast<const longlong2 *>(piv + (i64)pi * N);   // rare rows: re-read
+                const longlong2 pv = INLINE ? pvr[INLINE ? pi : 0] : *reinterpret_cast<const longlong2 *>(piv + (i64)pi * N);   // rare rows: re-read
                 const i64 pir = PiR[(i64)pi * rows + r];
                 const i64 Q0 = mm62s(pv.x, rs, m.q, m.k), Q1 = mm62s(pv.y, rs, m.q, m.k);
                 d[0] = mm62s(csub(d[0] + m.q2 - Q0, m.q2), pir, m.q, m.k);
@@ -578,49 +618,43 @@ int lf_ks_moddown_batch(const int64_t *const *s, int64_t *const *out, const int6
     return (int)hipGetLastError();
 }
 
-static int moddown_args_ok(int count, int ell, int K, int64_t N, const int64_t *ws, int64_t ws_words, int64_t gal_pinv) {
-    if (count < 0 || count > LF_BATCH_MAX || ell < 0 || K < 1 || K > KS_MAX_K || N < 2 || (N & 1)) return 0;
-    if (gal_pinv < 0 || gal_pinv >= 2 * N || (gal_pinv && (!(gal_pinv & 1) || (N & (N - 1))))) return 0;
-    return ws && ws_words >= lf_ks_moddown_ws_words(count, ell, K, N);
-}
-
-int lf_ks_pivots(const int64_t *const *s, int count, int ell, int K, int64_t N, int64_t *ws, int64_t ws_words, const int64_t *PiR,
-                 const double *PiP, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
-                 void *stream) {
-    if (!moddown_args_ok(count, ell, K, N, ws, ws_words, 0)) return LF_ERR_ARG;
-    if (count == 0 || ell == 0) return 0;
-    if (int e = lf_set_device(device)) return e;
-    PtrBatch pb;
-    for (int i = 0; i < count; ++i) pb.in[i] = (const i64 *)s[i], pb.aux[i] = nullptr, pb.out[i] = nullptr;
-    dim3 g1((unsigned)((N + 255) / 256), (unsigned)count + 1u);
-    hipLaunchKernelGGL(ks_pivots_kernel, g1, dim3(256), 0, (hipStream_t)stream, pb, count, ell, K, (i64)N, (i64 *)ws, (const i64 *)PiR,
-                       PiP, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
-    return (int)hipGetLastError();
-}
-
-int lf_ks_moddown_piv(const int64_t *const *s, int64_t *const *out, const int64_t *const *addend, int count, int ell, int K,
-                      int64_t N, const int64_t *ws, int64_t ws_words, const int64_t *PiR, const double *PiP, const int64_t *Rs,
-                      int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl,
-                      const int64_t *kh, int device, void *stream) {
-    if (!moddown_args_ok(count, ell, K, N, ws, ws_words, gal_pinv)) return LF_ERR_ARG;
+static int moddown_ws_launch(bool one, const int64_t *const *s, int64_t *const *out, const int64_t *const *addend, int count, int ell,
+                            int K, int64_t N, int64_t *ws, int64_t ws_words, const int64_t *PiR, const double *PiP, const int64_t *Rs,
+                            int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+                            const int64_t *kh, int device, void *stream) {
+    if (count < 0 || count > LF_BATCH_MAX || ell < 0 || K < 1 || K > KS_MAX_K || N < 2 || (N & 1)) return LF_ERR_ARG;
+    if (gal_pinv < 0 || gal_pinv >= 2 * N || (gal_pinv && (!(gal_pinv & 1) || (N & (N - 1))))) return LF_ERR_ARG;
+    if (!ws || ws_words < lf_ks_moddown_ws_words(count, ell, K, N)) return LF_ERR_ARG;
+    if (one && K > LF_MODDOWN_ONE_MAX_K) return LF_ERR_ARG;
     if (count == 0 || ell == 0) return 0;
     if (int e = lf_set_device(device)) return e;
     PtrBatch pb;
     for (int i = 0; i < count; ++i)
         pb.in[i] = (const i64 *)s[i], pb.aux[i] = addend ? (const i64 *)addend[i] : nullptr, pb.out[i] = (i64 *)out[i];
     hipStream_t st = (hipStream_t)stream;
+    if (!one) {
+        dim3 g1((unsigned)((N + 255) / 256), (unsigned)count + 1u);
+        hipLaunchKernelGGL(ks_pivots_kernel, g1, dim3(256), 0, st, pb, count, ell, K, (i64)N, (i64 *)ws, (const i64 *)PiR, PiP,
+                           (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+    }
     dim3 g2((unsigned)((N / 2 + 255) / 256), (unsigned)((ell + MD3_ROWS - 1) / MD3_ROWS), (unsigned)count);
-#define LF_MD_CASE(KK)                                                                                               \
-    case KK:                                                                                                         \
-        hipLaunchKernelGGL((ks_moddown_ws_kernel<KK>), g2, dim3(256), 0, st, pb, count, ell, (i64)N, (i64)gal_pinv,  \
-                           (const i64 *)gal_2q, (const i64 *)ws, (const i64 *)PiR, (const i64 *)Rs,                  \
-                           PiP != nullptr ? 1 : 0, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl,                \
-                           (const i64 *)kh);                                                                         \
+#define LF_MD_ARGS                                                                                                        \
+    g2, dim3(256), 0, st, pb, count, ell, (i64)N, (i64)gal_pinv, (const i64 *)gal_2q, (const i64 *)ws, (const i64 *)PiR,  \
+        (const i64 *)Rs, PiP != nullptr ? 1 : 0, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh
+#define LF_MD_CASE(KK)                                                        \
+    case KK:                                                                  \
+        hipLaunchKernelGGL((ks_moddown_ws_kernel<KK, false>), LF_MD_ARGS);    \
         break;
-    switch (K) {
-        LF_MD_CASE(1) LF_MD_CASE(2) LF_MD_CASE(3) LF_MD_CASE(4) LF_MD_CASE(5) LF_MD_CASE(6) LF_MD_CASE(7) LF_MD_CASE(8)
+    if (one) {
+        if (K == 1) hipLaunchKernelGGL((ks_moddown_ws_kernel<1, true>), LF_MD_ARGS);
+        else hipLaunchKernelGGL((ks_moddown_ws_kernel<2, true>), LF_MD_ARGS);
+    } else {
+        switch (K) {
+            LF_MD_CASE(1) LF_MD_CASE(2) LF_MD_CASE(3) LF_MD_CASE(4) LF_MD_CASE(5) LF_MD_CASE(6) LF_MD_CASE(7) LF_MD_CASE(8)
+        }
     }
 #undef LF_MD_CASE
+#undef LF_MD_ARGS
     return (int)hipGetLastError();
 }
 
@@ -628,9 +662,28 @@ int lf_ks_moddown_ws(const int64_t *const *s, int64_t *const *out, const int64_t
                      int64_t N, int64_t *ws, int64_t ws_words, const int64_t *PiR, const double *PiP, const int64_t *Rs,
                      int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl,
                      const int64_t *kh, int device, void *stream) {
-    if (int e = lf_ks_pivots(s, count, ell, K, N, ws, ws_words, PiR, PiP, ql, qh, kl, kh, device, stream)) return e;
-    return lf_ks_moddown_piv(s, out, addend, count, ell, K, N, ws, ws_words, PiR, PiP, Rs, gal_pinv, gal_2q, ql, qh, kl, kh, device,
-                             stream);
+    return moddown_ws_launch(false, s, out, addend, count, ell, K, N, ws, ws_words, PiR, PiP, Rs, gal_pinv, gal_2q, ql, qh, kl, kh,
+                             device, stream);
+}
+
+int lf_ks_moddown_one(const int64_t *const *s, int64_t *const *out, const int64_t *const *addend, int count, int ell, int K,
+                      int64_t N, const int64_t *ws, int64_t ws_words, const int64_t *PiR, const double *PiP, const int64_t *Rs,
+                      int64_t gal_pinv, const int64_t *gal_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+                      const int64_t *kh, int device, void *stream) {
+    return moddown_ws_launch(true, s, out, addend, count, ell, K, N, (int64_t *)ws, ws_words, PiR, PiP, Rs, gal_pinv, gal_2q, ql, qh,
+                             kl, kh, device, stream);
+}
+
+int lf_ks_moddown_consts(int64_t *ws, int64_t ws_words, int count, int ell, int K, int64_t N, const double *PiP, const int64_t *ql,
+                         const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (count < 0 || count > LF_BATCH_MAX || ell < 0 || K < 1 || K > KS_MAX_K || N < 2 || (N & 1) || !ws ||
+        ws_words < lf_ks_moddown_ws_words(count, ell, K, N))
+        return LF_ERR_ARG;
+    if (ell == 0 || PiP == nullptr) return 0;
+    if (int e = lf_set_device(device)) return e;
+    hipLaunchKernelGGL(ks_md_consts_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<double *>(ws + (int64_t)count * K * N),
+                       ell, K, PiP, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+    return (int)hipGetLastError();
 }
 
 int lf_ks_moddown(const int64_t *s, int64_t *out, const int64_t *addend, int ell, int K, int64_t N, const int64_t *PiR,

@@ -584,9 +584,6 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
 // gold cc_mult 2 104-2 130 -> 2 168-2 183 ops/s, rotate 2 653-2 695 -> 2 733-2 763, 64 rotations under one key
 // 3 110 -> 3 300 /s (tools/eo.py --ext-cols-max 3 | 4, one box); round 2's fully unrolled form had lost there (116 vs 95 us).
 int g_ks_ext_cols_max = 4;
-// 1: a key-switch tail that is given an lf_ks_pivot_fold eliminates the special primes inside its last inverse pass; 0: it
-// launches the pivots kernel after that pass instead (lf_tune; A/B of the fold, same workspace contents either way)
-int g_ks_pivot_fold = 1;
 
 void classify_rows(int rows, const int64_t *q_host, RowList &dp, RowList &in) {
     dp.n = in.n = 0;
@@ -649,8 +646,7 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
 int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
             int64_t row_off, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp,
             const int64_t *Ninv, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
-            const int64_t *kh, hipStream_t st, const RelinFold *fold = nullptr, int key_format = LF_KEY_RAW,
-            const lf_ks_pivot_fold *piv = nullptr) {
+            const int64_t *kh, hipStream_t st, const RelinFold *fold = nullptr, int key_format = LF_KEY_RAW) {
     if (!ipsi_dp || (key_format != LF_KEY_RAW && key_format != LF_KEY_PLANES)) return LF_ERR_ARG;
     if (key_format == LF_KEY_PLANES && ((((uintptr_t)ksk | (uintptr_t)(part_stride * 8) | (uintptr_t)(comp_stride * 8)) & 15)))
         return LF_ERR_ARG;
@@ -658,19 +654,6 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
     RowList dp, in;
     classify_rows(rows, q_host, dp, in);
     const bool mixed = dp.n && in.n;
-    // the mod-down's special-prime elimination inside the last inverse pass (PivFold, ckks_ntt_core.h): needs that pass as
-    // a column kernel and the special primes in the integer class (they are 60-bit primes in every context this package
-    // builds); otherwise the pivots get their own launch at the end, as lf_ks_moddown_ws would do
-    PivFold pf{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
-    bool fold_piv = false;
-    if (piv != nullptr) {
-        if (!piv->ws || !piv->PiR || piv->K < 1 || piv->K > KS_MAX_K || piv->ell < 1 || piv->ell + piv->K != rows ||
-            piv->ws_words < lf_ks_moddown_ws_words(2 * nct, piv->ell, piv->K, (int64_t)1 << logN))
-            return LF_ERR_ARG;
-        fold_piv = S1 <= 4 && g_ks_pivot_fold != 0;
-        for (int r = piv->ell; r < rows; ++r) fold_piv = fold_piv && (uint64_t)q_host[r] >= SMALL_PRIME_LIMIT;
-        if (fold_piv) pf.ws = (i64 *)piv->ws, pf.PiR = (const i64 *)piv->PiR, pf.PiP = piv->PiP, pf.ell = piv->ell, pf.Ksp = piv->K;
-    }
     // K3: inner product with the key, summed over the digits
     {
         const i64 N = (i64)1 << logN;
@@ -706,9 +689,9 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
             continue;
         }
         if (pass == 1 && S1 <= 4) {
-            if (mixed || fold_piv) {
+            if (mixed) {
                 launch_inv_cols_mixed(S1, inv_polys, st, (i64 *)s, g, in, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,
-                                      (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh, fold_piv ? &pf : nullptr);
+                                      (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
                 continue;
             }
             if (dp.n)
@@ -735,13 +718,6 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
                                g, in, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, pass == 1 ? 2 : TAIL_NONE,
                                (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
     }
-    if (piv != nullptr && !fold_piv) {   // the pivots as their own launch
-        const int64_t *ss[LF_BATCH_MAX];
-        if (inv_polys > LF_BATCH_MAX) return LF_ERR_ARG;
-        for (int i = 0; i < inv_polys; ++i) ss[i] = s + (((int64_t)i * rows) << logN);
-        return lf_ks_pivots(ss, inv_polys, piv->ell, piv->K, (int64_t)1 << logN, piv->ws, piv->ws_words, piv->PiR, piv->PiP, ql, qh, kl, kh,
-                            -1, (void *)st);
-    }
     return (int)hipGetLastError();
 }
 
@@ -750,7 +726,7 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
 extern "C" {
 
 int lf_tune(int which, int value) {
-    int *knob = which == LF_TUNE_KS_EXT_COLS_MAX ? &g_ks_ext_cols_max : which == LF_TUNE_KS_PIVOT_FOLD ? &g_ks_pivot_fold : nullptr;
+    int *knob = which == LF_TUNE_KS_EXT_COLS_MAX ? &g_ks_ext_cols_max : nullptr;
     if (!knob) return -1;
     const int old = *knob;
     if (value >= 0 && !(which == LF_TUNE_KS_EXT_COLS_MAX && value > 4)) *knob = value;
@@ -773,8 +749,7 @@ int lf_key_planes(const int64_t *src_b, const int64_t *src_a, int64_t *dst_b, in
 int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int nparts, int rows, int logN, const int64_t *desc,
                      const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
                      int64_t row_off, int key_format, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
-                     const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const lf_ks_pivot_fold *piv,
-                     const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+                     const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
                      void *stream) {
     if (nparts < 1 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
         !q_host || !psi_dp || !ipsi_dp || !Ed || (nct != 1 && nct != 2 && nct != 4))
@@ -784,7 +759,7 @@ int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int np
     if (int e = ks_forward(state, state_stride, nct, nparts, rows, logN, desc, E, Ed, tmp, psi_br, psi_dp, q_host, ql, qh, kl, kh, st))
         return e;
     return ks_tail(nct, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh,
-                   kl, kh, st, nullptr, key_format, piv);
+                   kl, kh, st, nullptr, key_format);
 }
 
 /* The two halves of lf_ks_core as separate calls, so that a limb-sharded engine can start on the digits that have
@@ -805,14 +780,14 @@ int lf_ks_fwd(const int64_t *state, int nparts, int rows, int logN, const int64_
 
 int lf_ks_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
                int key_format, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
-               const lf_ks_pivot_fold *piv, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+               const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
                const int64_t *kh, int device, void *stream) {
     if (nparts < 1 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
         !q_host || !ipsi_dp)
         return LF_ERR_ARG;
     if (int e = lf_set_device(device)) return e;
     return ks_tail(1, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh, kl,
-                   kh, (hipStream_t)stream, nullptr, key_format, piv);
+                   kh, (hipStream_t)stream, nullptr, key_format);
 }
 
 /* Relinearisation inside cc_mult (see RelinFold): lf_ks_core_batch / lf_ks_fwd / lf_ks_tail whose sums additionally
@@ -822,7 +797,7 @@ int lf_relin_core_batch(const int64_t *state, int64_t state_stride, int nct, int
                         const int64_t *E, const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
                         int64_t row_off, int key_format, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
                         const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *x, int64_t x_ct_stride,
-                        const int64_t *PR, int ell, const uint8_t *own, const lf_ks_pivot_fold *piv, const int64_t *q_host,
+                        const int64_t *PR, int ell, const uint8_t *own, const int64_t *q_host,
                         const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
     if (nparts < 1 || nparts > 254 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
         !q_host || !psi_dp || !ipsi_dp || !Ed || (nct != 1 && nct != 2 && nct != 4) || !x || !PR || ell < 0 || ell > rows)
@@ -834,7 +809,7 @@ int lf_relin_core_batch(const int64_t *state, int64_t state_stride, int nct, int
         return e;
     const RelinFold fold{(const i64 *)x, (i64)x_ct_stride, (const i64 *)PR, ell, (const unsigned char *)own};
     return ks_tail(nct, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh,
-                   kl, kh, st, &fold, key_format, piv);
+                   kl, kh, st, &fold, key_format);
 }
 
 int lf_relin_fwd(const int64_t *state, int first, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,
@@ -852,8 +827,7 @@ int lf_relin_fwd(const int64_t *state, int first, int nparts, int rows, int logN
 
 int lf_relin_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
                   int key_format, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
-                  const int64_t *x, const int64_t *PR, int ell, const uint8_t *own, const lf_ks_pivot_fold *piv,
-                  const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+                  const int64_t *x, const int64_t *PR, int ell, const uint8_t *own, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
                   void *stream) {
     if (nparts < 1 || nparts > 254 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
         !q_host || !ipsi_dp || !x || !PR || ell < 0 || ell > rows)
@@ -861,17 +835,16 @@ int lf_relin_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t pa
     if (int e = lf_set_device(device)) return e;
     const RelinFold fold{(const i64 *)x, 0, (const i64 *)PR, ell, (const unsigned char *)own};
     return ks_tail(1, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh, kl,
-                   kh, (hipStream_t)stream, &fold, key_format, piv);
+                   kh, (hipStream_t)stream, &fold, key_format);
 }
 
 int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,
                const double *Ed, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
                int key_format, int64_t *tmp, int64_t *s, const int64_t *psi_br, const double *psi_dp,
-               const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const lf_ks_pivot_fold *piv,
-               const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
+               const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
                void *stream) {
     return lf_ks_core_batch(state, 0, 1, nparts, rows, logN, desc, E, Ed, ksk, part_stride, comp_stride, row_off, key_format, tmp, s, psi_br,
-                            psi_dp, ipsi_br, ipsi_dp, Ninv, piv, q_host, ql, qh, kl, kh, device, stream);
+                            psi_dp, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh, kl, kh, device, stream);
 }
 
 }  // extern "C"

@@ -1522,113 +1522,6 @@ __device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const 
     }
 }
 
-// ---- the mod-down's special-prime elimination inside the last inverse pass of a key switch -----------------------------
-// The mod-down (ckks_engine.py:850-901) first eliminates the K special rows of the sums among themselves, last prime
-// first — the mixed-radix digits ("pivots") of the special part, once per coefficient — and then uses the pivots on every
-// ordinary row.  The first half used to be its own launch (ks_pivots_kernel: 5 - 8 us plus a launch gap, re-reading the K
-// rows the inverse pass had just written).  Here the blocks of the inverse column pass that own the special limbs do it:
-// one block per (polynomial, column chunk) walks the K special limbs from the last to the first; limb t is transformed,
-// reduced to canonical coefficients, put through the eliminations by the pivots p_0 .. p_{K-2-t} already in the
-// workspace (this thread's own earlier stores, re-read from L2), and stored as pivot p_{K-1-t}.  The special rows of the
-// sums themselves are never written.  Same integer operations in the same order as ks_pivots_kernel.
-struct PivFold {
-    i64 *ws;            // lf_ks_moddown_ws workspace: [count][Ksp][N] pivots, then (2 Ksp + 1) x ell doubles; nullptr: off
-    const i64 *PiR;     // [Ksp][rows]  P_j^-1 R mod q_row
-    const double *PiP;  // [Ksp][rows]  plain P_j^-1 mod q_row (fp64 rows of the mod-down); may be nullptr
-    int ell, Ksp;       // ordinary limbs, special primes (the last Ksp of the `rows` limbs)
-    int count;          // polynomials of the launch (= g.batch)
-    int sp_blocks;      // blocks at the front of the grid that own the special limbs (a multiple of 8)
-    int sp_real;        // .. of which exist (count x column chunks)
-};
-
-__device__ __forceinline__ double piv_mulmod_q(double a, double w, double q, double qinv) {
-    const double hi = a * w;
-    const double lo = __builtin_fma(a, w, -hi);
-    const double quo = __builtin_rint(hi * qinv);
-    const double r = __builtin_fma(-quo, q, hi) + lo;
-    return r < 0.0 ? r + q : r;
-}
-
-template <int K>
-__device__ __forceinline__ void inv_cols_pivots(int b, const i64 *__restrict__ a, const PassGeom &g, const PivFold &pf,
-                                                const i64 *__restrict__ ipsi_br, const double *__restrict__ ipsi_dp,
-                                                const i64 *__restrict__ Ninv, int tail, const i64 *__restrict__ ql,
-                                                const i64 *__restrict__ qh, const i64 *__restrict__ kl,
-                                                const i64 *__restrict__ kh) {
-    constexpr int R = 1 << K;
-    const int logC = g.logN - K;
-    const int chunks = (1 << logC) / NTT_COL_THREADS;
-    const int chunk = __builtin_amdgcn_readfirstlane(b % chunks), poly = __builtin_amdgcn_readfirstlane(b / chunks);
-    const i64 N = (i64)1 << g.logN;
-    const unsigned lane = threadIdx.x;
-    const i64 col = (i64)chunk * NTT_COL_THREADS + lane;
-    i64 *piv = pf.ws + (i64)poly * pf.Ksp * N + col;
-    for (int t = pf.Ksp - 1; t >= 0; --t) {
-        const int crow = pf.ell + t;
-        Ctx c;
-        c.m = load_mod(ql, qh, kl, kh, crow);
-        c.tw_mont = ipsi_br + ((i64)crow << g.logN);
-        set_aux<false>(c, ipsi_dp, crow, g.logN);
-        c.d = make_dp(c.m);
-        c.relaxed = g.relaxed;
-        c.inv_reduce = 0;
-        const i64 ninv_mont = (tail != TAIL_NONE) ? Ninv[crow] : 0;
-        const i64 *colu = a + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS;
-        i64 w[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k) w[k] = INV_LD(colu + ((i64)k << logC) + lane);
-        if (g.relaxed) {
-            cols_inv_stages<ArithShoup, K>(w, c);
-#pragma unroll
-            for (int k = 0; k < R; ++k) w[k] = inv_tail_int(ArithShoup::canon(c, w[k]), tail, ninv_mont, c);
-        } else {
-            cols_inv_stages<ArithInt<true>, K>(w, c);
-#pragma unroll
-            for (int k = 0; k < R; ++k) w[k] = inv_tail_int(w[k], tail, ninv_mont, c);
-        }
-        const int done = pf.Ksp - 1 - t;      // pivots already in the workspace
-        for (int pi = 0; pi < done; ++pi) {
-            const i64 pir = pf.PiR[(i64)pi * g.rows + crow];
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const i64 P = piv[(i64)pi * N + ((i64)k << logC)];
-                i64 d = csub(w[k] + c.m.q2 - P, c.m.q2);
-                d = mm62s(d, pir, c.m.q, c.m.k);
-                w[k] = d < (i64)c.m.q ? d : d - (i64)c.m.q;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < R; ++k) piv[(i64)done * N + ((i64)k << logC)] = w[k];
-        // the next limb re-reads these words: complete the stores first (a wave's loads may overtake its stores)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    // the per-row constants of the mod-down's fp64 rows (ks_moddown_ws_kernel): block 0, once per launch
-    if (b == 0 && pf.PiP != nullptr) {
-        double *cst = reinterpret_cast<double *>(pf.ws + (i64)pf.count * pf.Ksp * N);
-        const double two31 = 2147483648.0;
-        for (int r = threadIdx.x; r < pf.ell; r += NTT_COL_THREADS) {
-            const RowMod m = load_mod(ql, qh, kl, kh, r);
-            const bool dp = m.q < SMALL_PRIME_LIMIT;
-            const double q = (double)m.q, qinv = 1.0 / q;
-            double B = 1.0, pinv = 1.0;
-            for (int pi = 0; pi < pf.Ksp; ++pi) {
-                cst[(2 * pi) * pf.ell + r] = dp ? piv_mulmod_q(B, two31, q, qinv) : 0.0;   // A_pi
-                cst[(2 * pi + 1) * pf.ell + r] = dp ? B : 0.0;                             // B_pi
-                if (dp) {
-                    const int t = pf.ell + pf.Ksp - 1 - pi;   // P_pi mod q_r from its 31-bit halves, then the running product
-                    double Pm = piv_mulmod_q((double)qh[t], two31, q, qinv) + (double)ql[t];
-                    Pm = Pm >= q ? Pm - q : Pm;
-                    Pm = Pm >= q ? Pm - q : Pm;
-                    B = piv_mulmod_q(B, Pm, q, qinv);
-                    pinv = piv_mulmod_q(pinv, pf.PiP[(i64)pi * g.rows + r], q, qinv);
-                }
-            }
-            cst[(2 * pf.Ksp) * pf.ell + r] = dp ? pinv : 0.0;
-        }
-    }
-}
-
 template <bool DP, int K>
 __global__ void __launch_bounds__(NTT_COL_THREADS) ntt_inv_cols(i64 *__restrict__ a, PassGeom g, RowList rl,
                                                                const i64 *__restrict__ ipsi_br,
@@ -1644,14 +1537,8 @@ __global__ void __launch_bounds__(NTT_COL_THREADS) ntt_inv_cols_mixed(i64 *__res
                                                                      const double *__restrict__ ipsi_dp,
                                                                      const i64 *__restrict__ Ninv, int tail,
                                                                      const i64 *__restrict__ ql, const i64 *__restrict__ qh,
-                                                                     const i64 *__restrict__ kl, const i64 *__restrict__ kh,
-                                                                     PivFold pf) {
-    int b = blockIdx.x;
-    if (b < pf.sp_blocks) {   // (0 without the fold) the special limbs: transform + elimination, pivots into the workspace
-        if (b < pf.sp_real) inv_cols_pivots<K>(b, a, g, pf, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh);
-        return;
-    }
-    b -= pf.sp_blocks;
+                                                                     const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    const int b = blockIdx.x;
     if (b < cl.in_blocks) {
         if (b < cl.in_real) inv_cols_body<false, K>(b, a, g, cl.in, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh);
     } else {
@@ -1693,36 +1580,23 @@ inline ClassLists class_lists(const RowList &in, const RowList &dp, unsigned in_
 template <int K>
 inline void launch_inv_cols_mixed_k(unsigned blocks, hipStream_t st, i64 *base, const PassGeom &g, const ClassLists &cl,
                                     const i64 *ipsi_br, const double *ipsi_dp, const i64 *Ninv, int tail, const i64 *ql,
-                                    const i64 *qh, const i64 *kl, const i64 *kh, const PivFold &pf) {
+                                    const i64 *qh, const i64 *kl, const i64 *kh) {
     hipLaunchKernelGGL((ntt_inv_cols_mixed<K>), dim3(blocks), dim3(NTT_COL_THREADS), 0, st, base, g, cl, ipsi_br, ipsi_dp, Ninv,
-                       tail, ql, qh, kl, kh, pf);
+                       tail, ql, qh, kl, kh);
 }
 
-// host: inverse column pass, both classes in one launch (either list may be empty).  With `piv` (a PivFold whose ws, PiR,
-// PiP, ell, Ksp are set) the last Ksp limbs are taken out of the integer-class list and handled by the pivot blocks.
-inline void launch_inv_cols_mixed(int K, int polys, hipStream_t st, i64 *base, const PassGeom &g, const RowList &in_all,
+// host: inverse column pass, both classes in one launch
+inline void launch_inv_cols_mixed(int K, int polys, hipStream_t st, i64 *base, const PassGeom &g, const RowList &in,
                                   const RowList &dp, const i64 *ipsi_br, const double *ipsi_dp, const i64 *Ninv, int tail,
-                                  const i64 *ql, const i64 *qh, const i64 *kl, const i64 *kh, const PivFold *piv = nullptr) {
-    const unsigned chunks = (1u << (g.logN - K)) / NTT_COL_THREADS;
-    const unsigned per_limb = (unsigned)polys * chunks;
-    RowList in = in_all;
-    PivFold pf{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
-    if (piv != nullptr && piv->ws != nullptr) {
-        pf = *piv;
-        in.n = 0;
-        for (int i = 0; i < in_all.n; ++i)
-            if ((int)in_all.id[i] < pf.ell) in.id[in.n++] = in_all.id[i];
-        pf.count = polys;
-        pf.sp_real = (int)per_limb;
-        pf.sp_blocks = (int)((per_limb + 7u) & ~7u);
-    }
+                                  const i64 *ql, const i64 *qh, const i64 *kl, const i64 *kh) {
+    const unsigned per_limb = (unsigned)polys * ((1u << (g.logN - K)) / NTT_COL_THREADS);
     const ClassLists cl = class_lists(in, dp, per_limb * (unsigned)in.n);
-    const unsigned blocks = (unsigned)pf.sp_blocks + (unsigned)cl.in_blocks + per_limb * (unsigned)dp.n;
+    const unsigned blocks = (unsigned)cl.in_blocks + per_limb * (unsigned)dp.n;
     switch (K) {
-        case 1: launch_inv_cols_mixed_k<1>(blocks, st, base, g, cl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh, pf); break;
-        case 2: launch_inv_cols_mixed_k<2>(blocks, st, base, g, cl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh, pf); break;
-        case 3: launch_inv_cols_mixed_k<3>(blocks, st, base, g, cl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh, pf); break;
-        case 4: launch_inv_cols_mixed_k<4>(blocks, st, base, g, cl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh, pf); break;
+        case 1: launch_inv_cols_mixed_k<1>(blocks, st, base, g, cl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh); break;
+        case 2: launch_inv_cols_mixed_k<2>(blocks, st, base, g, cl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh); break;
+        case 3: launch_inv_cols_mixed_k<3>(blocks, st, base, g, cl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh); break;
+        case 4: launch_inv_cols_mixed_k<4>(blocks, st, base, g, cl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh); break;
     }
 }
 

@@ -37,20 +37,19 @@ int lf_cc_mult_evk(const lf_ks_plan *p, const int64_t *const *in, const int64_t 
     // key switch of d2 with d0, d1 folded into its sums (654-961, 1117-1151)
     if (int e = lf_ks_digits(p->d2, p->state, p->dig_nparts, p->dig_desc, p->dig_tab, N, p->ql, p->qh, p->kl, p->kh, dev, stream))
         return e;
-    // K >= 2: the special-prime elimination of the mod-down runs inside the key switch's last inverse pass (lf_ks_pivot_fold)
-    const lf_ks_pivot_fold pv{p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->ell, p->K};
     if (int e = lf_relin_core_batch(p->state, 0, 1, p->nparts, rows, logN, p->ext_desc, p->E, p->Ed, ksk, part_stride, comp_stride,
                                     row_off, key_format, p->ext, p->sum, p->psi, p->psi_dp, p->ipsi, p->ipsi_dp, p->Ninv, p->x4, 0, p->PR, ell,
-                                    p->own, p->K == 1 ? nullptr : &pv, p->q_host, p->ql, p->qh, p->kl, p->kh, dev, stream))
+                                    p->own, p->q_host, p->ql, p->qh, p->kl, p->kh, dev, stream))
         return e;
     const int64_t *ss[2] = {p->sum, p->sum + (int64_t)rows * N};
     int64_t *outs[2] = {out0, out1};
-    // ONE special prime (bronze): no elimination among special rows to share, so the single-launch form saves the pivot
-    // launch (bronze cc_mult 98.5-99.4 -> 96.4-97.6 us, rotate 73 -> 71.6; with two primes — silver — it measured no faster)
-    if (p->K == 1)
-        return lf_ks_moddown_batch(ss, outs, nullptr, 2, ell, p->K, N, p->PiR, p->PiP, p->Rs, 0, nullptr, p->ql, p->qh, p->kl, p->kh, dev, stream);
-    return lf_ks_moddown_piv(ss, outs, nullptr, 2, ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, 0, nullptr, p->ql,
-                             p->qh, p->kl, p->kh, dev, stream);
+    // up to two special primes (bronze, silver): the elimination among the special rows is at most one product per
+    // coefficient — done inside the mod-down launch (lf_ks_moddown_one; the plan's workspace holds the constants)
+    if (p->K <= LF_MODDOWN_ONE_MAX_K)
+        return lf_ks_moddown_one(ss, outs, nullptr, 2, ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, 0, nullptr, p->ql,
+                                 p->qh, p->kl, p->kh, dev, stream);
+    return lf_ks_moddown_ws(ss, outs, nullptr, 2, ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, 0, nullptr, p->ql,
+                            p->qh, p->kl, p->kh, dev, stream);
 }
 
 int lf_switch_key(const lf_ks_plan *p, const int64_t *c0, const int64_t *c1, int64_t gal_pinv, int gal_canonical,
@@ -63,18 +62,17 @@ int lf_switch_key(const lf_ks_plan *p, const int64_t *c0, const int64_t *c1, int
     if (int e = lf_ks_digits_galois(c1, p->state, p->dig_nparts, p->dig_desc, p->dig_tab, N, gal_pinv, g2q, p->ql, p->qh, p->kl, p->kh,
                                     dev, stream))
         return e;
-    const lf_ks_pivot_fold pv{p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->ell, p->K};   // see lf_cc_mult_evk
     if (int e = lf_ks_core(p->state, p->nparts, rows, logN, p->ext_desc, p->E, p->Ed, ksk, part_stride, comp_stride, row_off, key_format, p->ext,
-                           p->sum, p->psi, p->psi_dp, p->ipsi, p->ipsi_dp, p->Ninv, p->K == 1 ? nullptr : &pv, p->q_host, p->ql, p->qh,
-                           p->kl, p->kh, dev, stream))
+                           p->sum, p->psi, p->psi_dp, p->ipsi, p->ipsi_dp, p->Ninv, p->q_host, p->ql, p->qh, p->kl, p->kh, dev, stream))
         return e;
     const int64_t *ss[2] = {p->sum, p->sum + (int64_t)rows * N};
     int64_t *outs[2] = {out0, out1};
     const int64_t *adds[2] = {c0, nullptr};
-    if (p->K == 1)   // see lf_cc_mult_evk
-        return lf_ks_moddown_batch(ss, outs, adds, 2, ell, p->K, N, p->PiR, p->PiP, p->Rs, gal_pinv, g2q, p->ql, p->qh, p->kl, p->kh, dev, stream);
-    return lf_ks_moddown_piv(ss, outs, adds, 2, ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, gal_pinv, g2q, p->ql,
-                             p->qh, p->kl, p->kh, dev, stream);
+    if (p->K <= LF_MODDOWN_ONE_MAX_K)   // see lf_cc_mult_evk
+        return lf_ks_moddown_one(ss, outs, adds, 2, ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, gal_pinv, g2q, p->ql,
+                                 p->qh, p->kl, p->kh, dev, stream);
+    return lf_ks_moddown_ws(ss, outs, adds, 2, ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, gal_pinv, g2q, p->ql,
+                            p->qh, p->kl, p->kh, dev, stream);
 }
 
 }  // extern "C"

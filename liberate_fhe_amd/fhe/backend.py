@@ -11,7 +11,7 @@ import ctypes
 
 import torch
 
-from .._native import lib, check, KsPlan, KsPivotFold, LF_KEY_PLANES
+from .._native import lib, check, KsPlan, LF_KEY_PLANES
 from ..ntt import ntt_cuda, twiddles
 
 
@@ -55,11 +55,6 @@ def _pd(t):
     if not t.is_contiguous():
         raise ValueError("HipBackend: contiguous tensor required")
     return t.data_ptr()
-
-
-def _pv(piv):
-    """lf_ks_pivot_fold pointer (None -> NULL)."""
-    return None if piv is None else ctypes.byref(piv)
 
 
 def _parr(tensors):
@@ -159,26 +154,23 @@ class HipBackend:
                                       _pd(PiP), _p(Rs), pinv, _p(g2q), *c.mont(), dev, st),
               "lf_ks_moddown_batch")
 
-    def ks_moddown_ws(self, ss, outs, addends, ell, K, ws, PiR, Rs, c: Consts, PiP=None, galois=None, pivots_ready=False):
+    def ks_moddown_ws(self, ss, outs, addends, ell, K, ws, PiR, Rs, c: Consts, PiP=None, galois=None, one_launch=False):
         """ks_moddown_batch with a workspace tensor `ws` (int64, >= moddown_ws_words(..) words): the special-prime
-        chain is evaluated once per coefficient by a first launch — or, pivots_ready: by the key-switch tail that was
-        given pivot_fold(ws, ..) (lf_ks_moddown_piv: the second launch alone)."""
+        chain is evaluated once per coefficient by a first launch — or, one_launch (K <= moddown_one_max_K, constants
+        already in `ws` through moddown_consts): inside the single mod-down launch."""
         dev, st = _ds(outs[0])
         pinv, g2q = (0, None) if galois is None else galois
-        fn, what = (lib.lf_ks_moddown_piv, "lf_ks_moddown_piv") if pivots_ready else (lib.lf_ks_moddown_ws, "lf_ks_moddown_ws")
+        fn, what = (lib.lf_ks_moddown_one, "lf_ks_moddown_one") if one_launch else (lib.lf_ks_moddown_ws, "lf_ks_moddown_ws")
         check(fn(_parr(ss), _parr(outs), _parr(addends), len(ss), ell, K, outs[0].size(-1), _p(ws), ws.numel(), _p(PiR), _pd(PiP),
                  _p(Rs), pinv, _p(g2q), *c.mont(), dev, st), what)
 
-    pivot_fold_min_K = 2     # with one special prime there is no elimination to fold (the single-launch mod-down wins)
+    moddown_one_max_K = 2    # LF_MODDOWN_ONE_MAX_K: up to here the mod-down is ONE launch (pivots eliminated inside it)
 
-    @staticmethod
-    def pivot_fold(ws, PiR, PiP, ell, K):
-        """lf_ks_pivot_fold for the key-switch tails (ks_core / ks_core_batch / ks_tail `piv=`): the mod-down's
-        special-prime elimination runs inside the tail's last inverse pass and fills `ws`; finish with
-        ks_moddown_ws(.., pivots_ready=True).  The struct only borrows the tensors: the caller keeps them alive."""
-        pf = KsPivotFold()
-        pf.ws, pf.ws_words, pf.PiR, pf.PiP, pf.ell, pf.K = _p(ws), ws.numel(), _p(PiR), _pd(PiP), ell, K
-        return pf
+    def moddown_consts(self, ws, count, ell, K, N, PiP, c: Consts):
+        """Write the level constants of the mod-down's fp64 rows into workspace `ws`, ONCE per workspace (needed by
+        ks_moddown_ws(.., one_launch=True); the two-launch form rewrites them on every call)."""
+        dev, st = _ds(ws)
+        check(lib.lf_ks_moddown_consts(_p(ws), ws.numel(), count, ell, K, N, _pd(PiP), *c.mont(), dev, st), "lf_ks_moddown_consts")
 
     @staticmethod
     def moddown_ws_words(count, ell, K, N):
@@ -247,7 +239,7 @@ class HipBackend:
     relin_fold = True        # cc_mult's d0 / d1 folded into the key-switch sums (lf_intt_mul, lf_relin_*)
 
     def ks_core(self, state, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv,
-                c: Consts, fold=None, piv=None):
+                c: Consts, fold=None):
         """extend + NTT + key inner product + inverse NTT in three fused launches per arithmetic class.
         fold = (x stack [4, ell, N], PR [ell], own [rows] uint8 or None): cc_mult's d0 / d1 enter the sums in the NTT domain and
         the digits' own limbs come from x1 * y1 instead of an extension (lf_relin_core_batch)."""
@@ -260,12 +252,12 @@ class HipBackend:
             x, PR, own = fold
             check(lib.lf_relin_core_batch(_p(state), 0, 1, nparts, rows, logN, _p(desc), _p(E), _pd(Ed), base, part_stride,
                                           comp_stride, row_off, self._kfmt(key), _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
-                                          _p(x), 0, _p(PR), x.size(1), _pb(own), _pv(piv), c.qptr(), *c.mont(), dev, st),
+                                          _p(x), 0, _p(PR), x.size(1), _pb(own), c.qptr(), *c.mont(), dev, st),
                   "lf_relin_core_batch")
             return
         check(lib.lf_ks_core(_p(state), nparts, rows, logN, _p(desc), _p(E), _pd(Ed), base, part_stride, comp_stride,
                              row_off, self._kfmt(key), _p(tmp), _p(s), _p(psi), psi_dp, _p(ipsi), ipsi_dp, _p(Ninv),
-                             _pv(piv), c.qptr(), *c.mont(), dev, st), "lf_ks_core")
+                             c.qptr(), *c.mont(), dev, st), "lf_ks_core")
 
     def ks_fwd(self, state, first, count, rows, logN, desc, E, Ed, tmp, psi, c: Consts, own=None):
         """Extension + forward NTT of digits first .. first + count - 1 into tmp[first:first + count] (lf_ks_fwd; with
@@ -280,7 +272,7 @@ class HipBackend:
         check(lib.lf_ks_fwd(_p(state), count, rows, logN, _p(desc) + first * 3 * 8, _p(E), _pd(Ed),
                             _p(tmp) + first * rows * N * 8, _p(psi), psi_dp, c.qptr(), *c.mont(), dev, st), "lf_ks_fwd")
 
-    def ks_tail(self, nparts, rows, logN, key, first_part, row_off, tmp, s, ipsi, Ninv, c: Consts, fold=None, piv=None):
+    def ks_tail(self, nparts, rows, logN, key, first_part, row_off, tmp, s, ipsi, Ninv, c: Consts, fold=None):
         """Inner product of all extended digits with the key + inverse NTT (lf_ks_tail; fold: lf_relin_tail, see ks_core)."""
         dev, st = _ds(s)
         part_stride, comp_stride = key.stride(0), key.stride(1)
@@ -289,10 +281,10 @@ class HipBackend:
         if fold is not None:
             x, PR, own = fold
             check(lib.lf_relin_tail(nparts, rows, logN, base, part_stride, comp_stride, row_off, self._kfmt(key), _p(tmp), _p(s), _p(ipsi), ipsi_dp,
-                                    _p(Ninv), _p(x), _p(PR), x.size(1), _pb(own), _pv(piv), c.qptr(), *c.mont(), dev, st), "lf_relin_tail")
+                                    _p(Ninv), _p(x), _p(PR), x.size(1), _pb(own), c.qptr(), *c.mont(), dev, st), "lf_relin_tail")
             return
         check(lib.lf_ks_tail(nparts, rows, logN, base, part_stride, comp_stride, row_off, self._kfmt(key), _p(tmp), _p(s), _p(ipsi), ipsi_dp,
-                             _p(Ninv), _pv(piv), c.qptr(), *c.mont(), dev, st), "lf_ks_tail")
+                             _p(Ninv), c.qptr(), *c.mont(), dev, st), "lf_ks_tail")
 
     # ---- whole ops behind one native call (lf_cc_mult_evk / lf_switch_key over an lf_ks_plan) ------------------------
     native_ops = True
@@ -324,6 +316,9 @@ class HipBackend:
         # the plan outlives this call (the engine caches it per level): it holds the auxiliary twins its two raw
         # addresses point into, so a rebuilt twin (new table version) can never leave the plan reading freed memory
         keep += [twiddles.twin_of(psi), twiddles.twin_of(ipsi)]
+        if plan.K <= self.moddown_one_max_K:   # the ops then run the one-launch mod-down: its level constants, once
+            check(lib.lf_ks_moddown_consts(plan.md_ws, plan.md_ws_words, 2, plan.ell, plan.K, 1 << plan.logN, plan.PiP, *c.mont(), dev, st),
+                  "lf_ks_moddown_consts")
         return plan, keep
 
     def cc_mult_evk(self, plan, ins, row0s, key, first_part, row_off, out):
@@ -346,7 +341,7 @@ class HipBackend:
     ks_batch_sizes = (4, 2)   # ciphertexts per lf_ks_core_batch call (largest first)
 
     def ks_core_batch(self, states, nparts, rows, logN, desc, E, Ed, key, first_part, row_off, tmp, s, psi, ipsi, Ninv,
-                      c: Consts, fold=None, piv=None):
+                      c: Consts, fold=None):
         """ks_core for len(states) in (2, 4) ciphertexts under one key: states = [nct, state_rows, N] tensor,
         tmp [nct, nparts, rows, N], s [nct, 2, rows, N].  fold = (x [nct, 4, ell, N], PR [ell]), see ks_core."""
         dev, st = _ds(s)
@@ -358,12 +353,12 @@ class HipBackend:
             x, PR, own = fold
             check(lib.lf_relin_core_batch(_p(states), states.stride(0), states.size(0), nparts, rows, logN, _p(desc), _p(E),
                                           _pd(Ed), base, part_stride, comp_stride, row_off, self._kfmt(key), _p(tmp), _p(s), _p(psi), psi_dp,
-                                          _p(ipsi), ipsi_dp, _p(Ninv), _p(x), x.stride(0), _p(PR), x.size(2), _pb(own), _pv(piv), c.qptr(),
+                                          _p(ipsi), ipsi_dp, _p(Ninv), _p(x), x.stride(0), _p(PR), x.size(2), _pb(own), c.qptr(),
                                           *c.mont(), dev, st), "lf_relin_core_batch")
             return
         check(lib.lf_ks_core_batch(_p(states), states.stride(0), states.size(0), nparts, rows, logN, _p(desc), _p(E),
                                    _pd(Ed), base, part_stride, comp_stride, row_off, self._kfmt(key), _p(tmp), _p(s), _p(psi), psi_dp,
-                                   _p(ipsi), ipsi_dp, _p(Ninv), _pv(piv), c.qptr(), *c.mont(), dev, st), "lf_ks_core_batch")
+                                   _p(ipsi), ipsi_dp, _p(Ninv), c.qptr(), *c.mont(), dev, st), "lf_ks_core_batch")
 
     def ks_moddown(self, s, out, addend, ell, K, PiR, Rs, c: Consts, PiP=None):
         dev, st = _ds(out)

@@ -89,6 +89,7 @@ class ckks_engine(EvaluatorOps):
         self._tables = {}
         self._key_packs = {}
         self._workspace = {}
+        self._md_ready = set()
         self._lane = 0          # pipeline lane whose workspaces / stream the batched ops currently use
         self._lane_streams = {}
         self._check_kernel_limits()
@@ -149,6 +150,17 @@ class ckks_engine(EvaluatorOps):
             a, b = self.ntt.starts[level][dev], self.ntt.stops[0 if special else 1][dev]
             t = self._tables[key] = getattr(self.ntt, name)[dev][a:b]
         return t
+
+    def _moddown_ws(self, key, count, ell, K, d, tabs, cs):
+        """(workspace, one_launch) of a mod-down of `count` polynomials on device d: with up to backend.moddown_one_max_K
+        special primes the mod-down is ONE launch that only reads the workspace's level constants, written here once."""
+        N = self.ctx.N
+        ws = self._ws(key, (self.backend.moddown_ws_words(count, ell, K, N),), d)
+        one = K <= getattr(self.backend, "moddown_one_max_K", 0) and tabs[("pip", d)] is not None
+        if one and id(ws) not in self._md_ready:
+            self.backend.moddown_consts(ws, count, ell, K, N, tabs[("pip", d)], cs)
+            self._md_ready.add(id(ws))      # (workspaces live as long as the engine: the id stays theirs)
+        return ws, one
 
     def _ws(self, key, shape, dev_id):
         """Reusable scratch tensor (never returned to the caller); one set per pipeline lane (see _lanes)."""
@@ -1073,12 +1085,6 @@ class ckks_engine(EvaluatorOps):
             ninv = self._vec("Ninv", d, level, True)
             dig, ready = digits[d]
             fused = logN >= self.backend.fused_ks_min_logN
-            # the mod-down's special-prime elimination inside the key switch's last inverse pass (lf_ks_pivot_fold)
-            ws = self._ws("ks_moddown", (self.backend.moddown_ws_words(2, ell, K, N),), d)
-            piv = None
-            if fused and K >= getattr(self.backend, "pivot_fold_min_K", 1 << 30):
-                piv = self.backend.pivot_fold(ws, tabs[("pir", d)], tabs[("pip", d)], ell, K)
-            pkw = {} if piv is None else {"piv": piv}
             if fused and len(ready) > 1 and hasattr(self.backend, "ks_fwd"):
                 # 3. extend + forward NTT of this rank's own digits while the others are on the wire, then of the
                 # foreign runs; 4. once all are in: key inner product over all digits + inverse NTT
@@ -1089,7 +1095,7 @@ class ckks_engine(EvaluatorOps):
                     self.backend.ks_fwd(dig, first, count, rows, logN, desc, E, Ed, ext, tw, cs, **okw)
                 fkw = {} if fold is None else {"fold": fold[d]}
                 self.backend.ks_tail(nparts, rows, logN, key, tabs["first_part"], self.ntt.starts[level][d], ext, s, itw,
-                                     ninv, cs, **fkw, **pkw)
+                                     ninv, cs, **fkw)
                 ready = []
             for handle, _, _ in ready:
                 if handle is not None:
@@ -1099,7 +1105,7 @@ class ckks_engine(EvaluatorOps):
                 # leave the chip in coefficient form
                 fkw = {} if fold is None else {"fold": fold[d]}
                 self.backend.ks_core(dig, nparts, rows, logN, desc, E, Ed, key, tabs["first_part"],
-                                     self.ntt.starts[level][d], ext, s, tw, itw, ninv, cs, **fkw, **pkw)
+                                     self.ntt.starts[level][d], ext, s, tw, itw, ninv, cs, **fkw)
             elif not fused:
                 assert fold is None
                 # 3. extend every digit to this device's rows, forward NTT
@@ -1118,7 +1124,8 @@ class ckks_engine(EvaluatorOps):
                     add = add.contiguous()
                 adds.append(add)
             gal = None if galois is None else (galois[0], self._vec("_2q", d, level, False) if galois[1] else None)
-            mkw = {} if piv is None else {"pivots_ready": True}
+            ws, one = self._moddown_ws("ks_moddown", 2, ell, K, d, tabs, cs)
+            mkw = {"one_launch": True} if one else {}
             self.backend.ks_moddown_ws([s[0], s[1]], [out[0], out[1]], adds, ell, K, ws, tabs[("pir", d)], rs, cs,
                                        PiP=tabs[("pip", d)], galois=gal, **mkw)
             c0.append(out[0]); c1.append(out[1])
@@ -1366,11 +1373,6 @@ class ckks_engine(EvaluatorOps):
         packs = self._key_pack(key)
         kpack = packs[self._loc(0, special=True).index(d)]
         fkw = {} if fold is None else {"fold": fold}
-        ws = self._ws("ks_moddown_batch", (self.backend.moddown_ws_words(2 * nct, ell, K, N),), d)
-        piv = None
-        if K >= getattr(self.backend, "pivot_fold_min_K", 1 << 30):
-            piv = self.backend.pivot_fold(ws, tabs[("pir", d)], tabs[("pip", d)], ell, K)
-            fkw["piv"] = piv
         self.backend.ks_core_batch(states, nparts, rows, logN, desc, E, Ed, kpack, tabs["first_part"],
                                    self.ntt.starts[level][d], ext, s, self._tw(d, level, True),
                                    self._tw(d, level, True, True), self._vec("Ninv", d, level, True), cs, **fkw)
@@ -1382,7 +1384,8 @@ class ckks_engine(EvaluatorOps):
         for pair in addends:
             for a in pair:
                 adds.append(a if a is None or a.is_contiguous() else a.contiguous())
-        mkw = {} if piv is None else {"pivots_ready": True}
+        ws, one = self._moddown_ws("ks_moddown_batch", 2 * nct, ell, K, d, tabs, cs)
+        mkw = {"one_launch": True} if one else {}
         self.backend.ks_moddown_ws(ss, outs, adds, ell, K, ws, tabs[("pir", d)], self._vec("Rs", d, level, True), cs,
                                    PiP=tabs[("pip", d)], galois=gal, **mkw)
         return out

@@ -486,6 +486,33 @@ def test_key_planes_format_words_and_results():
     assert outs[0] == outs[1]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("params", [dict(logN=13, num_scales=9, num_special_primes=2, is_secured=False),
+                                    dict(logN=14, num_special_primes=1), dict(logN=13, scale_bits=45, num_scales=6, num_special_primes=2, is_secured=False)])
+def test_one_launch_moddown_equals_the_two_launch_form(params):
+    """Up to two special primes the mod-down eliminates the special rows inside its single launch (lf_ks_moddown_one over
+    constants written once by lf_ks_moddown_consts) instead of a pivots launch in front of it (lf_ks_moddown_ws): same
+    words for cc_mult, rotate, conjugate (signed addend) and the batched forms, through the native op entries and through
+    the step-by-step orchestration, at two levels."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    from liberate_fhe_amd.fhe.backend import HipBackend
+    outs = []
+    for one_max, native in ((2, True), (0, False), (2, False)):
+        be = HipBackend()
+        be.moddown_one_max_K = one_max
+        be.native_ops = native            # (the native entries choose by K themselves: the first round is their one-launch path)
+        eng = ckks_engine(devices=["cuda:0"], backend=be, **params)
+        evk, rotk = synth.key_switch_key(eng, 5), synth.key_switch_key(eng, 6, origin="rotation key:3")
+        conjk = synth.key_switch_key(eng, 7, origin="conjugation key")
+        res = []
+        for level in (0, 2):
+            a, b = synth.ciphertext(eng, 50 + level, level), synth.ciphertext(eng, 60 + level, level)
+            res += [eng.cc_mult(a, b, evk), eng.rotate_single(a, rotk), eng.conjugate(a, conjk)]
+            res += eng.rotate_single_batch([a, b, a, b, a], rotk) + eng.cc_mult_batch([(a, b), (b, a), (a, a)], evk)
+        outs.append([digest(x) for x in res])
+    assert outs[0] == outs[1] == outs[2]
+
+
 def _reference_shaped_switcher(eng, a, ksk, level):
     """create_switcher as the reference composes it from its step methods (eng.py:746-904) on ONE device: digits per part,
     extension + NTT + key products per part, sums, inverse transform, division by P through the checker's chain."""

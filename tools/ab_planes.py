@@ -9,11 +9,7 @@ import torch
 from liberate_fhe_amd.fhe import ckks_engine, presets
 from liberate_fhe_amd.utils import synth
 
-from liberate_fhe_amd._native import lib
 name = sys.argv[1] if len(sys.argv) > 1 else "gold"
-if "--no-pivot-fold" in sys.argv:
-    sys.argv.remove("--no-pivot-fold")
-    lib.lf_tune(2, 0)
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 engs = {}
 for fmt in ("planes", "raw"):

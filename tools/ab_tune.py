@@ -1,5 +1,5 @@
 """A/B of an lf_tune knob in ONE process, alternating settings:  python tools/ab_tune.py <knob> <value A> <value B> [gold|silver] [rounds]
-   knob 1 = LF_TUNE_KS_EXT_COLS_MAX, 2 = LF_TUNE_KS_PIVOT_FOLD (include/ckks_hip.h)."""
+   knob 1 = LF_TUNE_KS_EXT_COLS_MAX (include/ckks_hip.h)."""
 import os, sys, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 warnings.filterwarnings("ignore")
