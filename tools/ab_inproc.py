@@ -63,6 +63,17 @@ def timed(fn, n):
     return e0.elapsed_time(e1) / n
 
 
+def timed_passes(L, n):
+    """(tiled pass ms, column pass ms) from per-launch events over n transforms issued as their two passes: every launch
+    sees the valid output of the other pass (the words between the two passes are in an internal format, PassGeom::f64mid —
+    a pass launched twice in a row would read garbage)."""
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n)]
+    for a, b, c in ev:
+        a.record(); one_pass(L, 1); b.record(); one_pass(L, 2); c.record()
+    torch.cuda.synchronize()
+    return sum(b.elapsed_time(c) for a, b, c in ev) / n, sum(a.elapsed_time(b) for a, b, c in ev) / n
+
+
 for L in libs:
     for _ in range(5):
         full(L)
@@ -71,8 +82,9 @@ res = {n: {"step": [], "tile": [], "cols": []} for n in names}
 for rnd in range(8):
     for n, L in zip(names, libs):
         res[n]["step"].append(timed(lambda: full(L), 10))
-        res[n]["tile"].append(timed(lambda: one_pass(L, 2), 20))
-        res[n]["cols"].append(timed(lambda: one_pass(L, 1), 20))
+        t, c = timed_passes(L, 20)
+        res[n]["tile"].append(t)
+        res[n]["cols"].append(c)
 ref = {k: float(np.median(v)) for k, v in res[names[0]].items()}
 for n in names:
     m = {k: float(np.median(v)) for k, v in res[n].items()}
