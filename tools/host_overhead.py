@@ -19,8 +19,12 @@ for preset in ("silver", "gold"):
     kp = eng._key_pack(rotk)[0]
     out = torch.empty((2, plan.ell, eng.ctx.N), dtype=torch.int64, device="cuda:0")
     raw = lambda: eng.backend.switch_key_native(plan, a.data[0][0], a.data[1][0], pinv, True, kp, fp, ro, out)
+    cts = [synth.ciphertext(eng, 100 + i, 0) for i in range(16)]
+    pairs = [(cts[i], cts[(i + 1) % 16]) for i in range(16)]
     for name, fn in (("cc_mult", lambda: eng.cc_mult(a, b, evk)), ("rotate", lambda: eng.rotate_single(a, rotk)),
-                     ("lf_switch_key alone", raw)):
+                     ("lf_switch_key alone", raw),
+                     ("rotate_single_batch of 16 (4 groups of 4, two lanes; per call)", lambda: eng.rotate_single_batch(cts, rotk)),
+                     ("cc_mult_batch of 16 (4 groups of 4, two lanes; per call)", lambda: eng.cc_mult_batch(pairs, evk))):
         for _ in range(40):
             fn()
         torch.cuda.synchronize()
