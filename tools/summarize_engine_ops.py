@@ -8,7 +8,7 @@ tables, warm-up).  The summary also records how many __amd_rocclr_copyBuffer dis
 import json, os, sqlite3, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 sys.path.insert(0, ROOT)
 import __graft_entry__ as _g   # noqa: E402
 src = os.path.join(ROOT, "gpurun_out")

@@ -13,7 +13,7 @@ import collections, json, os, sqlite3, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, out = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 sys.path.insert(0, ROOT)
 import __graft_entry__ as _g   # noqa: E402
 DIGEST = _g.library_digest()   # the sources these counters were taken at: bench.py drops the figures when the build differs
@@ -89,21 +89,37 @@ json.dump(traffic, open(os.path.join(out, f"traffic_{TAG}.json"), "w"), indent=1
 print("\n".join(pm))
 
 # ---- engine ops: PMC per kernel ------------------------------------------------------------------------------------
-eo = [f"# rocprofv3 --pmc <counters> --kernel-trace -- python3 tools/ccmult_profile.py <preset> cc_mult --mark   ({TAG}); FETCH / WRITE / SQ in separate runs",
-      "# averages over all dispatches of the run (3 warm-up + 10 timed ops); a kernel listed twice runs on two grids per op",
-      "# kernel/grid | us | read MB (2 x FETCH_SIZE) | write MB | moved TB/s | VALU wave-instr | VALU busy"]
+eo = [f"# rocprofv3 --pmc <counters> --kernel-trace -- python3 tools/ccmult_profile.py <preset> <op> --mark   ({TAG}); FETCH / WRITE / SQ in separate runs",
+      "# averages over all dispatches of the run (40 warm-up + 10 timed ops); a kernel listed twice runs on two grids per op",
+      "# kernel/grid | us | read MB (2 x FETCH_SIZE) | write MB | moved TB/s | VALU wave-instr | VALU busy | launches per op"]
+eo_json = {"library_digest": DIGEST,
+           "note": ("per kernel and grid: average launch (us), HBM bytes (reads = 2 x FETCH_SIZE KiB, the gfx950 correction; writes = WRITE_SIZE KiB), "
+                    "moved TB/s, VALU busy = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs over SQ_BUSY_CU_CYCLES / 256 CUs; bytes_per_op = sum over the "
+                    f"op's launches; source profiles/{TAG}_engine_ops_pmc.txt")}
 for preset in ("gold", "silver"):
-    try:
-        f, w, v = counters(f"{preset}_fetch"), counters(f"{preset}_write"), counters(f"{preset}_valu")
-    except Exception as e:
-        eo.append(f"## {preset}: missing ({e})")
-        continue
-    eo += ["", f"## {preset} cc_mult + relinearize"]
-    for key in sorted(v, key=lambda k: -v[k]["us"] * v[k]["n"]):
-        if not (key[0].startswith(("ntt_", "ks_", "tensor"))) or key not in f or key not in w:
+    for op, tag in (("cc_mult", preset), ("rotate", preset + "_rot")):
+        try:
+            f, w, v = counters(f"{tag}_fetch"), counters(f"{tag}_write"), counters(f"{tag}_valu")
+        except Exception as e:
+            eo.append(f"## {preset} {op}: missing ({e})")
             continue
-        rd, wr, us = 2 * f[key]["FETCH_SIZE"] * 1024, w[key]["WRITE_SIZE"] * 1024, v[key]["us"]
-        busy = v[key]["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (v[key]["SQ_BUSY_CU_CYCLES"] / 256)
-        eo.append(f"{key[0]}/g{key[1]} | {us:7.1f} | {rd / 1e6:7.1f} | {wr / 1e6:7.1f} | {(rd + wr) / us / 1e6:5.2f} | {v[key]['SQ_INSTS_VALU']:.4g} | {busy:5.3f}")
+        eo += ["", f"## {preset} {op}" + (" + relinearize" if op == "cc_mult" else "_single")]
+        ops = max((d["n"] for k, d in v.items() if k[0].startswith("ks_inner2_kernel")), default=0)   # one inner product per op
+        kernels, total_bytes = [], 0.0
+        for key in sorted(v, key=lambda k: -v[k]["us"] * v[k]["n"]):
+            if not (key[0].startswith(("ntt_", "ks_", "tensor", "rescale"))) or key not in f or key not in w:
+                continue
+            rd, wr, us = 2 * f[key]["FETCH_SIZE"] * 1024, w[key]["WRITE_SIZE"] * 1024, v[key]["us"]
+            busy = v[key]["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (v[key]["SQ_BUSY_CU_CYCLES"] / 256)
+            per_op = round(v[key]["n"] / ops) if ops else 1
+            if per_op < 1:
+                continue            # set-up launches (key conversion, table builds): not part of an op
+            eo.append(f"{key[0]}/g{key[1]} | {us:7.1f} | {rd / 1e6:7.1f} | {wr / 1e6:7.1f} | {(rd + wr) / us / 1e6:5.2f} | {v[key]['SQ_INSTS_VALU']:.4g} | {busy:5.3f} | {per_op}")
+            kernels.append({"kernel": key[0], "grid": key[1], "us": us, "per_op": per_op, "read_MB": rd / 1e6, "write_MB": wr / 1e6,
+                            "moved_TBps": (rd + wr) / us / 1e6, "valu_busy": busy, "valu_wave_instr": v[key]["SQ_INSTS_VALU"]})
+            total_bytes += (rd + wr) * per_op
+        eo.append(f"# HBM bytes per op (sum over its launches): {total_bytes / 1e6:.1f} MB")
+        eo_json[f"{preset}_{op}"] = {"kernels": kernels, "bytes_per_op": total_bytes}
 open(os.path.join(out, f"{TAG}_engine_ops_pmc.txt"), "w").write("\n".join(eo) + "\n")
+json.dump(eo_json, open(os.path.join(out, f"{TAG}_engine_ops_pmc.json"), "w"), indent=1)
 print("\n".join(eo))
