@@ -27,5 +27,5 @@ for P in gold silver; do
 done
 # kernel stats of the bench command itself (the file the roofline numbers are checked against)
 cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o stats -- python3 $REPO/bench.py --no-extra > $OUT/prof_$TAG.log 2>&1; cd $REPO
-python3 bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; tail -c 400 $OUT/bench_$TAG.json
+python3 bench.py --no-extra > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; tail -c 400 $OUT/bench_$TAG.json   # (round_profiles.sh replaces it by the full line)
 ls $OUT | grep pmc2 | head -20
