@@ -40,6 +40,9 @@ import warnings
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 warnings.filterwarnings("ignore")
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL / tensor sharing fail with the legacy mode); it has to be in
+# the environment before the HIP runtime starts, i.e. before anything below touches the GPU
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -355,9 +358,16 @@ def cpu_engine_baseline(preset="silver", budget_s=25.0, max_reps=10):
                       f"reference-shaped orchestration), after one warm-up op"}
 
 
+def _reduce_device(dev):
+    """Where the tensors of the default group's reductions live: the GPU with RCCL, the host when the group is gloo (the
+    rehearsal, or the fallback after a failed RCCL initialisation)."""
+    import torch.distributed as dist
+    return "cpu" if "gloo" in str(dist.get_backend()) and "nccl" not in str(dist.get_backend()) else dev
+
+
 def _max_over_ranks(ms, dev):
     import torch.distributed as dist
-    t = torch.tensor([ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([ms], dtype=torch.float64, device=_reduce_device(dev))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -599,6 +609,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
+    nccl_error = None
     if world > 1:
         import datetime
         import torch.distributed as dist
@@ -607,7 +618,17 @@ def main():
             from tests import gloo_device_p2p      # gloo moves host memory only: device messages are staged (test transport)
             gloo_device_p2p.install()
         else:
-            dist.init_process_group("nccl", device_id=torch.device(dev), timeout=datetime.timedelta(seconds=900))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device(dev), timeout=datetime.timedelta(seconds=900))
+            except Exception as e:
+                # RCCL did not come up: the replica headline needs only a barrier and a max over ranks — those run over gloo
+                # on host tensors; the limb-sharded legs (device point-to-point) are skipped and the line says why
+                print(f"[bench] rank {rank}: RCCL initialisation failed ({type(e).__name__}: {e}); falling back to gloo for the "
+                      "barriers, limb-sharded legs skipped", file=sys.stderr, flush=True)
+                nccl_error = f"{type(e).__name__}: {e}"[:300]
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
 
     import __graft_entry__ as g
     if rank == 0:
@@ -659,7 +680,7 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1) / args.steps
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall], dtype=torch.float64, device=_reduce_device(dev))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
     ms_per_step = wall / args.steps * 1e3
@@ -694,7 +715,7 @@ def main():
     except Exception as e:
         spot = f"ERROR: {type(e).__name__}: {e}"[:300]
     if world > 1:
-        t = torch.tensor([0 if spot == "ok" else 1], dtype=torch.int64, device=dev)
+        t = torch.tensor([0 if spot == "ok" else 1], dtype=torch.int64, device=_reduce_device(dev))
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         if int(t.item()) and spot == "ok":
             spot = f"MISMATCH on {int(t.item())} other rank(s)"
@@ -903,7 +924,9 @@ def main():
         import threading
         done = threading.Event()
         grp = comm_block = None
-        if not args.no_sharded:
+        if nccl_error is not None:
+            result["comm"] = {"error": "RCCL initialisation failed, barriers over gloo, limb-sharded legs skipped: " + nccl_error}
+        elif not args.no_sharded:
             try:
                 grp, comm_block = comm_prepare(dev, world, rank, local_rank)     # untimed channel set-up, before the watchdog
                 result["comm"] = comm_block

@@ -403,6 +403,9 @@ __global__ void __launch_bounds__(256) key_planes_kernel(const i64 *__restrict__
 // from displacing the digits, which the forward pass has just written, out of L2 / Infinity Cache
 // (measured at gold: 124.8 -> 96.2 us together with one 16-byte column per thread instead of two).
 #define KI_COLS 1
+#ifndef KI_UNROLL
+#define KI_UNROLL 2   // digits of the fp64-class inner product in flight per thread (measured: profiles / LAB_NOTES round 4)
+#endif
 __device__ __forceinline__ longlong2 ld_nt(const i64 *p) {
     longlong2 v;
     v.x = __builtin_nontemporal_load(p);
@@ -466,7 +469,7 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
                 xo[t].y = dp_to_word(dp_mulmod(dp_from_word(X1.y), dp_from_word(Y1.y), d));
             }
         }
-#pragma unroll 2
+#pragma unroll KI_UNROLL
         for (int p = 0; p < nparts; ++p) {
             longlong2 x[NCT];
 #pragma unroll
