@@ -369,6 +369,7 @@ int lf_rescale_ntt(const int64_t *const *in, const int64_t *const *row0, int cou
 typedef struct lf_ks_plan {
     int32_t logN, ell, K, nparts;        /* ring degree, ordinary limbs at the op's level, special primes, digits */
     int32_t dig_nparts, device;          /* digits lf_ks_digits builds here (= nparts on one device) */
+    int32_t max_nct, reserved_;          /* ciphertexts per batched call the scratch below is sized for (1, 2 or 4) */
     int64_t round_at;                    /* cc_mult: rescale rounding threshold q_l / 2 (lf_rescale) */
     int64_t md_ws_words;
     const int64_t *ql, *qh, *kl, *kh, *_2q, *Rs, *Ninv;      /* device, [rows] */
@@ -382,8 +383,8 @@ typedef struct lf_ks_plan {
     const double *PiP;
     const uint8_t *own;                                       /* lf_relin_*: may be NULL */
     const int64_t *rescale_scales, *PR;                       /* cc_mult only: [ell] q_l^-1 R and P R mod q_r */
-    int64_t *state, *ext, *sum, *md_ws;                       /* scratch: [ell][N], [nparts][rows][N], [2][rows][N], md_ws_words */
-    int64_t *x4, *d2;                                         /* cc_mult only: [4][ell][N], [ell][N] */
+    int64_t *state, *ext, *sum, *md_ws;                       /* scratch: max_nct x ([ell][N], [nparts][rows][N], [2][rows][N]); md_ws_words for 2 max_nct polynomials */
+    int64_t *x4, *d2;                                         /* cc_mult only: max_nct x ([4][ell][N], [ell][N]) */
 } lf_ks_plan;
 
 /* ckks_engine.cc_mult(a, b, evk) with relinearisation, level l -> l + 1 (ckks_engine.py:1072-1151): in[0..3] = first
@@ -399,6 +400,34 @@ int lf_cc_mult_evk(const lf_ks_plan *plan, const int64_t *const *in, const int64
 int lf_switch_key(const lf_ks_plan *plan, const int64_t *c0, const int64_t *c1, int64_t gal_pinv, int gal_canonical,
                   const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off, int key_format, int64_t *out0,
                   int64_t *out1, void *stream);
+
+/* The same ops for nct = 1, 2 or 4 ciphertexts under ONE key (plan->max_nct >= nct): every launch covers all of them and the
+ * inner product reads each key word once for the group (lf_ks_core_batch / lf_relin_core_batch).  c0 / c1 / out0 / out1: HOST
+ * arrays of nct device pointers; in / row0: 4 per ciphertext pair, in the order of lf_cc_mult_evk.  Results equal nct single calls. */
+int lf_switch_key_batch(const lf_ks_plan *plan, int nct, const int64_t *const *c0, const int64_t *const *c1, int64_t gal_pinv,
+                        int gal_canonical, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
+                        int key_format, int64_t *const *out0, int64_t *const *out1, void *stream);
+int lf_cc_mult_evk_batch(const lf_ks_plan *plan, int nct, const int64_t *const *in, const int64_t *const *row0, const int64_t *ksk,
+                         int64_t part_stride, int64_t comp_stride, int64_t row_off, int key_format, int64_t *const *out0,
+                         int64_t *const *out1, void *stream);
+
+/* The halves of an op around the digit exchange of a limb-sharded engine (one process per GPU; the reference gathers every
+ * digit on every GPU through the host before it extends any, ckks_engine.py:778-829).  The plan describes THIS rank's rows
+ * at the level (dig_nparts = the digits it owns, nparts = all digits, state = its own digit rows):
+ *   lf_cc_mult_evk_pre / lf_switch_key_pre   everything up to the digits this rank owns, into plan->state;
+ *   lf_ks_plan_fwd                           extension + forward NTT of digits first .. first + count - 1 of the gathered
+ *                                            storage-order buffer `digits` (own digits while the others travel, foreign runs
+ *                                            after the wait); relin != 0: inside cc_mult (own-limb pairs skipped);
+ *   lf_cc_mult_evk_post / lf_switch_key_post inner product over ALL digits + inverse NTT + mod-down (+ c0(X^p)).
+ * pre, fwd over every digit, post == lf_cc_mult_evk / lf_switch_key. */
+int lf_cc_mult_evk_pre(const lf_ks_plan *plan, const int64_t *const *in, const int64_t *const *row0, void *stream);
+int lf_switch_key_pre(const lf_ks_plan *plan, const int64_t *c1, int64_t gal_pinv, int gal_canonical, void *stream);
+int lf_ks_plan_fwd(const lf_ks_plan *plan, const int64_t *digits, int first, int count, int relin, void *stream);
+int lf_cc_mult_evk_post(const lf_ks_plan *plan, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
+                        int key_format, int64_t *out0, int64_t *out1, void *stream);
+int lf_switch_key_post(const lf_ks_plan *plan, const int64_t *c0, int64_t gal_pinv, int gal_canonical, const int64_t *ksk,
+                       int64_t part_stride, int64_t comp_stride, int64_t row_off, int key_format, int64_t *out0, int64_t *out1,
+                       void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Samplers: the reference's csprng extensions, src/liberate/csprng/.

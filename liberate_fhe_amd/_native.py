@@ -81,7 +81,7 @@ _SIGNATURES = {
 
 class KsPlan(ctypes.Structure):
     """lf_ks_plan (include/ckks_hip.h), field for field."""
-    _fields_ = ([(n, ctypes.c_int32) for n in ("logN", "ell", "K", "nparts", "dig_nparts", "device")]
+    _fields_ = ([(n, ctypes.c_int32) for n in ("logN", "ell", "K", "nparts", "dig_nparts", "device", "max_nct", "reserved_")]
                 + [("round_at", _L), ("md_ws_words", _L)]
                 + [(n, _P) for n in ("ql", "qh", "kl", "kh", "_2q", "Rs", "Ninv", "q_host", "psi", "ipsi", "psi_dp", "ipsi_dp",
                                      "dig_desc", "dig_tab", "ext_desc", "E", "Ed", "PiR", "PiP", "own", "rescale_scales", "PR",
@@ -90,6 +90,15 @@ class KsPlan(ctypes.Structure):
 
 _SIGNATURES["lf_cc_mult_evk"] = [ctypes.POINTER(KsPlan), _P, _P, _P, _L, _L, _L, _I, _P, _P, _P]
 _SIGNATURES["lf_switch_key"] = [ctypes.POINTER(KsPlan), _P, _P, _L, _I, _P, _L, _L, _L, _I, _P, _P, _P]
+
+_PL = ctypes.POINTER(KsPlan)
+_SIGNATURES["lf_switch_key_batch"] = [_PL, _I, _P, _P, _L, _I, _P, _L, _L, _L, _I, _P, _P, _P]
+_SIGNATURES["lf_cc_mult_evk_batch"] = [_PL, _I, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P]
+_SIGNATURES["lf_cc_mult_evk_pre"] = [_PL, _P, _P, _P]
+_SIGNATURES["lf_switch_key_pre"] = [_PL, _P, _L, _I, _P]
+_SIGNATURES["lf_ks_plan_fwd"] = [_PL, _P, _I, _I, _I, _P]
+_SIGNATURES["lf_cc_mult_evk_post"] = [_PL, _P, _L, _L, _L, _I, _P, _P, _P]
+_SIGNATURES["lf_switch_key_post"] = [_PL, _P, _L, _I, _P, _L, _L, _L, _I, _P, _P, _P]
 
 for _name, _args in _SIGNATURES.items():
     _fn = getattr(lib, _name)

@@ -317,9 +317,56 @@ class HipBackend:
         # addresses point into, so a rebuilt twin (new table version) can never leave the plan reading freed memory
         keep += [twiddles.twin_of(psi), twiddles.twin_of(ipsi)]
         if plan.K <= self.moddown_one_max_K:   # the ops then run the one-launch mod-down: its level constants, once
-            check(lib.lf_ks_moddown_consts(plan.md_ws, plan.md_ws_words, 2, plan.ell, plan.K, 1 << plan.logN, plan.PiP, *c.mont(), dev, st),
-                  "lf_ks_moddown_consts")
+            check(lib.lf_ks_moddown_consts(plan.md_ws, plan.md_ws_words, 2 * plan.max_nct, plan.ell, plan.K, 1 << plan.logN, plan.PiP,
+                                           *c.mont(), dev, st), "lf_ks_moddown_consts")
         return plan, keep
+
+    @staticmethod
+    def _key_args(key, first_part):
+        part_stride, comp_stride = key.stride(0), key.stride(1)
+        return key.data_ptr() + first_part * part_stride * 8, part_stride, comp_stride
+
+    def switch_key_batch_native(self, plan, c0s, c1s, pinv, canonical, key, first_part, row_off, out):
+        """len(c1s) in (1, 2, 4) == plan.max_nct ciphertexts under one key as ONE native call; out [nct, 2, ell, N]."""
+        dev, st = _ds(out)
+        base, ps, cs = self._key_args(key, first_part)
+        nct = len(c1s)
+        check(lib.lf_switch_key_batch(ctypes.byref(plan), nct, _parr(c0s), _parr(c1s), pinv, 1 if canonical else 0, base, ps, cs, row_off,
+                                      self._kfmt(key), _parr([out[t][0] for t in range(nct)]), _parr([out[t][1] for t in range(nct)]), st),
+              "lf_switch_key_batch")
+
+    def cc_mult_evk_batch_native(self, plan, ins, row0s, key, first_part, row_off, out):
+        """ins / row0s: 4 device tensors (or raw pointers) per ciphertext pair; out [nct, 2, ell, N]."""
+        dev, st = _ds(out)
+        base, ps, cs = self._key_args(key, first_part)
+        nct = out.size(0)
+        check(lib.lf_cc_mult_evk_batch(ctypes.byref(plan), nct, ins, row0s, base, ps, cs, row_off, self._kfmt(key),
+                                       _parr([out[t][0] for t in range(nct)]), _parr([out[t][1] for t in range(nct)]), st),
+              "lf_cc_mult_evk_batch")
+
+    # ---- the halves of an op around the digit exchange (one process per GPU) -----------------------------------------
+    def cc_mult_pre(self, plan, ins, row0s, st):
+        check(lib.lf_cc_mult_evk_pre(ctypes.byref(plan), ins, row0s, st), "lf_cc_mult_evk_pre")
+
+    def switch_key_pre(self, plan, c1, pinv, canonical):
+        dev, st = _ds(c1)
+        check(lib.lf_switch_key_pre(ctypes.byref(plan), _p(c1), pinv, 1 if canonical else 0, st), "lf_switch_key_pre")
+
+    def plan_fwd(self, plan, digits, first, count, relin):
+        dev, st = _ds(digits)
+        check(lib.lf_ks_plan_fwd(ctypes.byref(plan), _p(digits), first, count, 1 if relin else 0, st), "lf_ks_plan_fwd")
+
+    def cc_mult_post(self, plan, key, first_part, row_off, out):
+        dev, st = _ds(out)
+        base, ps, cs = self._key_args(key, first_part)
+        check(lib.lf_cc_mult_evk_post(ctypes.byref(plan), base, ps, cs, row_off, self._kfmt(key), out.data_ptr(),
+                                      out.data_ptr() + out.stride(0) * 8, st), "lf_cc_mult_evk_post")
+
+    def switch_key_post(self, plan, c0, pinv, canonical, key, first_part, row_off, out):
+        dev, st = _ds(out)
+        base, ps, cs = self._key_args(key, first_part)
+        check(lib.lf_switch_key_post(ctypes.byref(plan), _p(c0), pinv, 1 if canonical else 0, base, ps, cs, row_off, self._kfmt(key),
+                                     out.data_ptr(), out.data_ptr() + out.stride(0) * 8, st), "lf_switch_key_post")
 
     def cc_mult_evk(self, plan, ins, row0s, key, first_part, row_off, out):
         """ins / row0s: ctypes arrays of 4 device pointers; out [2, ell, N]."""

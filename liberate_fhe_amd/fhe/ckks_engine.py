@@ -765,10 +765,12 @@ class ckks_engine(EvaluatorOps):
         loc = self._loc(level)
         return loc[0] if len(loc) == 1 else None
 
-    def _op_plan(self, level, d):
+    def _op_plan(self, level, d, nct=1):
         """lf_ks_plan of (level, device): constants, tables and scratch of a key switch AT `level` and of a cc_mult INTO it,
-        resolved once (per pipeline lane: the scratch tensors are per lane)."""
-        key = ("plan", level, d, self._lane)
+        resolved once (per pipeline lane: the scratch tensors are per lane).  nct = ciphertexts per batched call the scratch
+        is sized for (1: the single-ciphertext workspaces the step-by-step path uses too).  `d` may be this rank's device of a
+        limb-sharded engine: the plan then describes its rows, `nparts` all digits, `dig_nparts` the digits it owns."""
+        key = ("plan", level, d, self._lane, nct)
         hit = self._tables.get(key)
         if hit is not None:
             return hit
@@ -779,15 +781,20 @@ class ckks_engine(EvaluatorOps):
         nparts = len(tabs["order"])
         dig_nparts, dig_desc, dig_tab = tabs[("digits", d)]
         desc, E, Ed = tabs[("extend", d)]
-        words = self.backend.moddown_ws_words(2, ell, K, N)
+        words = self.backend.moddown_ws_words(2 * nct, ell, K, N)
         ints = {"logN": self.ctx.logN, "ell": ell, "K": K, "nparts": nparts, "dig_nparts": dig_nparts, "md_ws_words": words,
-                "round_at": 0}
+                "round_at": 0, "max_nct": nct}
+        if nct == 1:
+            scratch = {"state": self._ws("ks_state", (ell, N), d), "ext": self._ws("ks_ext", (nparts, rows, N), d),
+                       "sum": self._ws("ks_sum", (2, rows, N), d), "md_ws": self._ws("ks_moddown_plan", (words,), d),
+                       "x4": self._ws("mult4", (4, ell, N), d), "d2": self._ws("mult_d2", (ell, N), d)}
+        else:
+            scratch = {"state": self._ws("ks_state_batch", (nct, ell, N), d), "ext": self._ws("ks_ext_batch", (nct, nparts, rows, N), d),
+                       "sum": self._ws("ks_sum_batch", (nct, 2, rows, N), d), "md_ws": self._ws("ks_moddown_plan", (words,), d),
+                       "x4": self._ws("multx", (nct, 4, ell, N), d), "d2": self._ws("multx_d2", (nct, ell, N), d)}
         tensors = {"Rs": self._vec("Rs", d, level, True), "Ninv": self._vec("Ninv", d, level, True), "dig_desc": dig_desc,
                    "dig_tab": dig_tab, "ext_desc": desc, "E": E, "Ed": Ed, "PiR": tabs[("pir", d)], "PiP": tabs[("pip", d)],
-                   "own": tabs[("own", d)], "rescale_scales": None, "PR": self._PR(d, level),
-                   "state": self._ws("ks_state", (ell, N), d), "ext": self._ws("ks_ext", (nparts, rows, N), d),
-                   "sum": self._ws("ks_sum", (2, rows, N), d), "md_ws": self._ws("ks_moddown", (words,), d),
-                   "x4": self._ws("mult4", (4, ell, N), d), "d2": self._ws("mult_d2", (ell, N), d)}
+                   "own": tabs[("own", d)], "rescale_scales": None, "PR": self._PR(d, level), **scratch}
         if level >= 1:
             owner = self.ntt.p.rescaler_loc[level - 1]
             ints["round_at"] = self.ctx.q[self.ntt.p.destination_arrays[level - 1][owner][0]] // 2
@@ -815,6 +822,46 @@ class ckks_engine(EvaluatorOps):
         self.backend.cc_mult_evk(plan, ins, row0s, kpack, first_part, row_off, out)
         return self._new(([out[0]], [out[1]]), types.origins["ct"], level=level)
 
+    def _sharded_native(self, level):
+        """This rank's device if the level is limb-sharded over ranks (one process per GPU), this rank holds rows of it and
+        the backend has the native halves of an op (lf_*_pre / lf_ks_plan_fwd / lf_*_post); None otherwise."""
+        if self.comm is None or self.comm.world_size <= 1 or not getattr(self.backend, "native_ops", False):
+            return None
+        if self.ctx.logN < self.backend.fused_ks_min_logN or not hasattr(self.backend, "cc_mult_pre"):
+            return None
+        loc = self._loc(level)
+        return loc[0] if len(loc) == 1 and self.len_devices[level] > 1 else None
+
+    def _sharded_forward(self, plan, d, level, relin):
+        """The digit exchange between the halves of a sharded op: this rank's digits (plan.state) go out as one batch of
+        point-to-point messages while it extends + transforms the digits it owns; the foreign runs follow the single wait."""
+        tabs = self._ks_tables(level)
+        state = self._ws("ks_state", (plan.ell, self.ctx.N), d)          # = plan.state
+        dig, ready = self._exchange_digits({d: state}, level, tabs)[d]
+        for handle, first, count in ready:
+            if handle is not None:
+                handle.wait()
+            self.backend.plan_fwd(plan, dig, first, count, relin)
+
+    def _cc_mult_sharded_native(self, a, b, evk, level, d):
+        """cc_mult + relinearize of a limb-sharded level with the host side of this rank in three native calls + one per run
+        of digits (lf_cc_mult_evk_pre, lf_ks_plan_fwd, lf_cc_mult_evk_post) around the two exchanges."""
+        N = self.ctx.N
+        per_dev, round_at = self._rescale_operands([a, b])               # exchange 1: the dropped limb's rows
+        srcs, r0s = per_dev[d]
+        if not all(t.is_contiguous() for t in srcs + r0s):
+            return None
+        plan, _, first_part, row_off = self._op_plan(level, d)
+        assert plan.round_at == round_at
+        ins, row0s = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in srcs]), (ctypes.c_void_p * 4)(*[t.data_ptr() for t in r0s])
+        from .backend import _ds
+        self.backend.cc_mult_pre(plan, ins, row0s, _ds(srcs[0])[1])
+        self._sharded_forward(plan, d, level, True)                      # exchange 2: the digits
+        kpack = self._key_pack(evk)[self._loc(0, special=True).index(d)]
+        out = torch.empty((2, plan.ell, N), dtype=torch.int64, device=self.ntt.devices[d])
+        self.backend.cc_mult_post(plan, kpack, first_part, row_off, out)
+        return self._new(([out[0]], [out[1]]), types.origins["ct"], level=level)
+
     # =============================================================================================
     # multiplication (eng.py:1072-1151)
     # =============================================================================================
@@ -832,6 +879,11 @@ class ckks_engine(EvaluatorOps):
             d = self._native_level(level)
             if d is not None and self._native_level(a.level) == d:
                 out = self._cc_mult_native(a, b, evk, level, d)
+                if out is not None:
+                    return out
+            d = self._sharded_native(level)
+            if d is not None and getattr(self.backend, "relin_fold", False):
+                out = self._cc_mult_sharded_native(a, b, evk, level, d)
                 if out is not None:
                     return out
         d0, d1, d2 = [], [], []
@@ -1220,6 +1272,17 @@ class ckks_engine(EvaluatorOps):
                 self.backend.switch_key_native(plan, ct.data[0][0], ct.data[1][0], pinv, canonical, kpack, first_part, row_off, out)
                 return data_struct(data=([out[0]], [out[1]]), include_special=False, ntt_state=False,
                                    montgomery_state=ct.montgomery_state, origin=types.origins["ct"], level=level, hash=self.hash)
+            d = self._sharded_native(level)
+            if d is not None and ct.data[0][0].is_contiguous() and ct.data[1][0].is_contiguous():
+                # a limb-sharded level: digits, [exchange], extension + NTT per run, tail — the host side in native calls
+                plan, _, first_part, row_off = self._op_plan(level, d)
+                self.backend.switch_key_pre(plan, ct.data[1][0], pinv, canonical)
+                self._sharded_forward(plan, d, level, False)
+                kpack = self._key_pack(key)[self._loc(0, special=True).index(d)]
+                out = torch.empty((2, plan.ell, self.ctx.N), dtype=torch.int64, device=self.ntt.devices[d])
+                self.backend.switch_key_post(plan, ct.data[0][0], pinv, canonical, kpack, first_part, row_off, out)
+                return data_struct(data=([out[0]], [out[1]]), include_special=False, ntt_state=False,
+                                   montgomery_state=ct.montgomery_state, origin=types.origins["ct"], level=level, hash=self.hash)
             c0, c1 = self.create_switcher(ct.data[1], key, level, addends=(ct.data[0], None), galois=(pinv, canonical))
             return data_struct(data=(c0, c1), include_special=False, ntt_state=False,
                                montgomery_state=ct.montgomery_state, origin=types.origins["ct"], level=level, hash=self.hash)
@@ -1344,8 +1407,17 @@ class ckks_engine(EvaluatorOps):
         (the rotate_single form: canonical words)."""
         d = self._loc(level)[0]
         pinv = pow(exponent, -1, 2 * self.ctx.N)
-        gal = (pinv, self._vec("_2q", d, level, False))
-        out = self._ks_batch([ct.data[1][0] for ct in cts], [(ct.data[0][0], None) for ct in cts], key, level, gal)
+        if self._native_level(level) == d and hasattr(self.backend, "switch_key_batch_native") and \
+                all(ct.data[0][0].is_contiguous() and ct.data[1][0].is_contiguous() for ct in cts):
+            # the whole group as ONE native call (lf_switch_key_batch)
+            plan, _, first_part, row_off = self._op_plan(level, d, len(cts))
+            kpack = self._key_pack(key)[self._loc(0, special=True).index(d)]
+            out = torch.empty((len(cts), 2, plan.ell, self.ctx.N), dtype=torch.int64, device=self.ntt.devices[d])
+            self.backend.switch_key_batch_native(plan, [ct.data[0][0] for ct in cts], [ct.data[1][0] for ct in cts], pinv, True, kpack,
+                                                 first_part, row_off, out)
+        else:
+            gal = (pinv, self._vec("_2q", d, level, False))
+            out = self._ks_batch([ct.data[1][0] for ct in cts], [(ct.data[0][0], None) for ct in cts], key, level, gal)
         return [data_struct(data=([out[b][0]], [out[b][1]]), include_special=False, ntt_state=False,
                             montgomery_state=ct.montgomery_state, origin=types.origins["ct"], level=level, hash=self.hash)
                 for b, ct in enumerate(cts)]
@@ -1431,6 +1503,23 @@ class ckks_engine(EvaluatorOps):
         N, logN = self.ctx.N, self.ctx.logN
         nct = len(pairs)
         rows = self._rows(d, level, False)
+        if self._native_level(level) == d and self._native_level(level - 1) == d and hasattr(self.backend, "cc_mult_evk_batch_native") \
+                and getattr(self.backend, "relin_fold", False) \
+                and all(t.is_contiguous() and t.dtype == torch.int64 for a, b in pairs for ct in (a, b) for t in (ct.data[0][0], ct.data[1][0])):
+            # the whole group as ONE native call (lf_cc_mult_evk_batch)
+            plan, _, first_part, row_off = self._op_plan(level, d, nct)
+            ins, row0s = (ctypes.c_void_p * (4 * nct))(), (ctypes.c_void_p * (4 * nct))()
+            k = 0
+            for a, b in pairs:
+                for ct in (a, b):
+                    for comp in range(2):
+                        ptr = ct.data[comp][0].data_ptr()
+                        row0s[k], ins[k] = ptr, ptr + N * 8      # the dropped limb is the first row; the survivors follow it
+                        k += 1
+            kpack = self._key_pack(evk)[self._loc(0, special=True).index(d)]
+            out = torch.empty((nct, 2, plan.ell, N), dtype=torch.int64, device=self.ntt.devices[d])
+            self.backend.cc_mult_evk_batch_native(plan, ins, row0s, kpack, first_part, row_off, out)
+            return [self._new(([out[t][0]], [out[t][1]]), types.origins["ct"], level=level) for t in range(nct)]
         c = self._consts(d, level, False)
         fold = getattr(self.backend, "relin_fold", False)
         # rescale + forward transform of the operands, two pairs (8 polynomials) per launch
