@@ -335,8 +335,11 @@ __device__ __forceinline__ void ks_ext_cols_body(int b, const i64 *__restrict__ 
     }
 }
 
+#ifndef KS_EXT_COLS_WAVES
+#define KS_EXT_COLS_WAVES 4
+#endif
 template <int K>
-__global__ void __launch_bounds__(NTT_COL_THREADS) ks_ext_cols_mixed(const i64 *__restrict__ state, i64 *__restrict__ tmp,
+__global__ void __launch_bounds__(NTT_COL_THREADS) __attribute__((amdgpu_waves_per_eu(KS_EXT_COLS_WAVES))) ks_ext_cols_mixed(const i64 *__restrict__ state, i64 *__restrict__ tmp,
                                                                      KsGeom kg, ClassLists cl, const i64 *__restrict__ desc,
                                                                      const i64 *__restrict__ E, const double *__restrict__ Ed,
                                                                      const i64 *__restrict__ psi_br,
