@@ -406,7 +406,8 @@ def test_c3_silver_cc_mult_decode_within_2_pow_minus_30_of_the_checker():
 @pytest.mark.parametrize("name", ["silver", "sb45"])
 def test_hip_native_op_entries_equal_the_step_by_step_engine(name):
     """lf_cc_mult_evk / lf_switch_key (one native call per op over an lf_ks_plan) against the same engine with the entries
-    switched off, i.e. the Python orchestration of the individual steps — levels 0, 1 and a deep one, rotate and conjugate."""
+    switched off, i.e. the Python orchestration of the individual steps — levels 0, 1 and a deep one, rotate and conjugate, and
+    the batched entries (lf_switch_key_batch, lf_cc_mult_evk_batch) against the step-by-step groups."""
     from liberate_fhe_amd.fhe import ckks_engine
     from liberate_fhe_amd.fhe.backend import HipBackend
     params = GOLD[name]["params"]
@@ -424,6 +425,10 @@ def test_hip_native_op_entries_equal_the_step_by_step_engine(name):
             prod = eng.cc_mult(a, b, evk)
             res += [digest(prod), digest(eng.rotate_single(a, rotk)), digest(eng.conjugate(a, conjk)),
                     digest(eng.rotate_single(prod, rotk))]
+            # the batched entries (lf_switch_key_batch / lf_cc_mult_evk_batch: groups of 4, 2 and a single one) against the
+            # Python orchestration of the same groups
+            res += [digest(x) for x in eng.rotate_single_batch([a, b, a, a, b, b, a], rotk)]
+            res += [digest(x) for x in eng.cc_mult_batch([(a, b), (b, a), (a, a), (b, b), (a, b), (b, a), (a, a)], evk)]
         outs.append(res)
     assert outs[0] == outs[1]
 
