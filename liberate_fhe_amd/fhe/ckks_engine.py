@@ -1362,31 +1362,32 @@ class ckks_engine(EvaluatorOps):
 
     def _run_groups(self, jobs, dev_id, prepare=None):
         """Run independent group jobs (callables returning lists of data_structs) alternately on two streams of
-        the device: a group's memory-bound phases (the key stream of the inner product) overlap the other group's
+        the device (LF_ENGINE_LANES, Python side only; measured: 2 beats 1 and 3): a group's memory-bound phases (the key stream of the inner product) overlap the other group's
         instruction-bound ones, and launch tails fill.  Each lane has its own workspaces.  Returns the results in
         order; the caller's stream waits for the side lane before returning.
         Lazily built shared state (key pack, per-level tables, fp64 twiddle twins) is produced by launches on the
         stream of whichever call touches it first: `prepare()` builds all of it on the caller's stream BEFORE the
         side lane is forked (idempotent: dictionary hits afterwards), so the side lane never reads it half-built."""
         device = self.ntt.devices[dev_id]
-        if len(jobs) < 2 or not str(device).startswith("cuda") or os.environ.get("LF_ENGINE_LANES", "2") == "1":
+        lanes = max(1, int(os.environ.get("LF_ENGINE_LANES", "2")))
+        if len(jobs) < 2 or not str(device).startswith("cuda") or lanes == 1:
             return [job() for job in jobs]
         main = torch.cuda.current_stream(device)
-        side = self._lane_streams.get(dev_id)
-        if side is None:
-            side = self._lane_streams[dev_id] = torch.cuda.Stream(device=device)
+        sides = self._lane_streams.setdefault(dev_id, [])
+        while len(sides) < lanes - 1:
+            sides.append(torch.cuda.Stream(device=device))
         results = []
-        first = 0
         if prepare is not None:
             prepare()
         fork = torch.cuda.Event()
         fork.record(main)
-        side.wait_event(fork)
+        for side in sides[:lanes - 1]:
+            side.wait_event(fork)
         try:
-            for n, job in enumerate(jobs[first:]):
-                self._lane = n & 1
+            for n, job in enumerate(jobs):
+                self._lane = n % lanes
                 if self._lane:
-                    with torch.cuda.stream(side):
+                    with torch.cuda.stream(sides[self._lane - 1]):
                         res = job()
                     for r in res:
                         for comp in r.data:
@@ -1397,9 +1398,10 @@ class ckks_engine(EvaluatorOps):
                 results.append(res)
         finally:
             self._lane = 0
-        join = torch.cuda.Event()
-        join.record(side)
-        main.wait_event(join)
+        for side in sides[:lanes - 1]:
+            join = torch.cuda.Event()
+            join.record(side)
+            main.wait_event(join)
         return results
 
     def _automorphism_batch(self, cts, exponent, key, level):
