@@ -956,8 +956,9 @@ def main():
             dist.destroy_process_group()
         except Exception:
             pass
-    if spot != "ok":
+    if spot.startswith("MISMATCH"):
         sys.exit(4)      # the headline kernel's words differ from the oracle's on this box: the line says so, the exit code too
+    # (an ERROR of the checker itself — e.g. no C compiler for the oracle on the box — is reported in the line, not as a failure)
 
 
 if __name__ == "__main__":
