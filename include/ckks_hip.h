@@ -34,7 +34,8 @@ extern "C" {
 
 #define LF_ERR_ARG 10001
 
-/* Library probe: returns the ABI version (currently 9; __graft_entry__.build() asserts it). */
+/* Library probe: returns the ABI version (currently LF_ABI_VERSION; __graft_entry__.build() asserts it). */
+#define LF_ABI_VERSION 11
 int lf_abi_version(void);
 
 /* Compile-time capacities of the fused kernels, so that callers can refuse a parameter set BEFORE any launch
@@ -49,7 +50,9 @@ int lf_abi_version(void);
 int lf_limits(int which);
 
 /* Launch-shape thresholds (never results: every setting produces the same words).  Returns the previous value, -1 for an
- * unknown `which`; value < 0 only reads.  Process-wide; set before launching from several threads.
+ * unknown `which`; value < 0 only reads.  PROCESS-WIDE mutable state, read by every entry at launch time on whatever
+ * thread calls it and not synchronised: set it once, before any other thread launches (the engine never touches it; only
+ * the A/B tools under tools/ do).
  *   LF_TUNE_KS_EXT_COLS_MAX   largest logN - 12 (0 .. 4) for which the key switch's extension + leading stages run as the
  *                             column kernel (one register step per column, no LDS); above it the LDS-tiled form.
  *   (knob 0 was the one-launch key-switch transform of round 3: slower at every preset size on MI355X, removed.) */
@@ -369,7 +372,11 @@ int lf_rescale_ntt(const int64_t *const *in, const int64_t *const *row0, int cou
 typedef struct lf_ks_plan {
     int32_t logN, ell, K, nparts;        /* ring degree, ordinary limbs at the op's level, special primes, digits */
     int32_t dig_nparts, device;          /* digits lf_ks_digits builds here (= nparts on one device) */
-    int32_t max_nct, reserved_;          /* ciphertexts per batched call the scratch below is sized for (1, 2 or 4) */
+    int32_t max_nct;                     /* ciphertexts per batched call the scratch below is sized for (1, 2 or 4) */
+    int32_t md_consts;                   /* `count` md_ws was primed for by lf_ks_moddown_consts (the op entries run
+                                            lf_ks_moddown_one only for exactly that many polynomials: 2 x the ciphertexts
+                                            of the call); 0 = never primed: every entry takes lf_ks_moddown_ws, which
+                                            needs no preparation.  A zero-filled struct is therefore always safe. */
     int64_t round_at;                    /* cc_mult: rescale rounding threshold q_l / 2 (lf_rescale) */
     int64_t md_ws_words;
     const int64_t *ql, *qh, *kl, *kh, *_2q, *Rs, *Ninv;      /* device, [rows] */

@@ -81,7 +81,7 @@ _SIGNATURES = {
 
 class KsPlan(ctypes.Structure):
     """lf_ks_plan (include/ckks_hip.h), field for field."""
-    _fields_ = ([(n, ctypes.c_int32) for n in ("logN", "ell", "K", "nparts", "dig_nparts", "device", "max_nct", "reserved_")]
+    _fields_ = ([(n, ctypes.c_int32) for n in ("logN", "ell", "K", "nparts", "dig_nparts", "device", "max_nct", "md_consts")]
                 + [("round_at", _L), ("md_ws_words", _L)]
                 + [(n, _P) for n in ("ql", "qh", "kl", "kh", "_2q", "Rs", "Ninv", "q_host", "psi", "ipsi", "psi_dp", "ipsi_dp",
                                      "dig_desc", "dig_tab", "ext_desc", "E", "Ed", "PiR", "PiP", "own", "rescale_scales", "PR",

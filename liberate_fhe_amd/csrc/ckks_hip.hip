@@ -122,7 +122,7 @@ __global__ void clock_probe_kernel(unsigned long long *out, int samples, unsigne
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-int lf_abi_version(void) { return 10; }
+int lf_abi_version(void) { return LF_ABI_VERSION; }
 
 int lf_clock_probe(uint64_t *out, int samples, uint64_t ticks, int device, void *stream) {
     // (at most 10 s of spinning in all: the wave holds its CU slot for samples x ticks x 10 ns)

@@ -19,6 +19,24 @@ static int plan_ok(const lf_ks_plan *p) {
            p->state && p->ext && p->sum && p->md_ws;
 }
 
+static int batch_ok(const lf_ks_plan *p, int nct) {
+    return plan_ok(p) && (nct == 1 || nct == 2 || nct == 4) && nct <= p->max_nct;
+}
+
+static int moddown_any(const lf_ks_plan *p, const int64_t *const *ss, int64_t *const *outs, const int64_t *const *adds, int count,
+                       int64_t gal_pinv, const int64_t *g2q, void *stream) {
+    const int64_t N = (int64_t)1 << p->logN;
+    // up to two special primes (bronze, silver): the elimination among the special rows is at most one product per
+    // coefficient — done inside the mod-down launch (lf_ks_moddown_one), which only READS the level constants
+    // lf_ks_moddown_consts wrote behind the pivots of `md_consts` polynomials.  A plan whose workspace was never primed
+    // (md_consts = 0) or primed for another count takes the two-launch form, which writes them where its own count puts them.
+    if (p->K <= LF_MODDOWN_ONE_MAX_K && count == p->md_consts)
+        return lf_ks_moddown_one(ss, outs, adds, count, p->ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, gal_pinv, g2q,
+                                 p->ql, p->qh, p->kl, p->kh, p->device, stream);
+    return lf_ks_moddown_ws(ss, outs, adds, count, p->ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, gal_pinv, g2q, p->ql,
+                            p->qh, p->kl, p->kh, p->device, stream);
+}
+
 int lf_cc_mult_evk(const lf_ks_plan *p, const int64_t *const *in, const int64_t *const *row0, const int64_t *ksk,
                    int64_t part_stride, int64_t comp_stride, int64_t row_off, int key_format, int64_t *out0, int64_t *out1,
                    void *stream) {
@@ -43,13 +61,7 @@ int lf_cc_mult_evk(const lf_ks_plan *p, const int64_t *const *in, const int64_t 
         return e;
     const int64_t *ss[2] = {p->sum, p->sum + (int64_t)rows * N};
     int64_t *outs[2] = {out0, out1};
-    // up to two special primes (bronze, silver): the elimination among the special rows is at most one product per
-    // coefficient — done inside the mod-down launch (lf_ks_moddown_one; the plan's workspace holds the constants)
-    if (p->K <= LF_MODDOWN_ONE_MAX_K)
-        return lf_ks_moddown_one(ss, outs, nullptr, 2, ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, 0, nullptr, p->ql,
-                                 p->qh, p->kl, p->kh, dev, stream);
-    return lf_ks_moddown_ws(ss, outs, nullptr, 2, ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, 0, nullptr, p->ql,
-                            p->qh, p->kl, p->kh, dev, stream);
+    return moddown_any(p, ss, outs, nullptr, 2, 0, nullptr, stream);
 }
 
 int lf_switch_key(const lf_ks_plan *p, const int64_t *c0, const int64_t *c1, int64_t gal_pinv, int gal_canonical,
@@ -68,32 +80,12 @@ int lf_switch_key(const lf_ks_plan *p, const int64_t *c0, const int64_t *c1, int
     const int64_t *ss[2] = {p->sum, p->sum + (int64_t)rows * N};
     int64_t *outs[2] = {out0, out1};
     const int64_t *adds[2] = {c0, nullptr};
-    if (p->K <= LF_MODDOWN_ONE_MAX_K)   // see lf_cc_mult_evk
-        return lf_ks_moddown_one(ss, outs, adds, 2, ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, gal_pinv, g2q, p->ql,
-                                 p->qh, p->kl, p->kh, dev, stream);
-    return lf_ks_moddown_ws(ss, outs, adds, 2, ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, gal_pinv, g2q, p->ql,
-                            p->qh, p->kl, p->kh, dev, stream);
+    return moddown_any(p, ss, outs, adds, 2, gal_pinv, g2q, stream);
 }
 
 /* ---- batches under one key: nct = 1, 2 or 4 ciphertexts per launch set (plan->max_nct >= nct; scratch of ciphertext t at
  * t times the single-ciphertext size).  The compositions the engine's Python used to issue step by step (_ks_batch,
  * _cc_mult_group) behind one call each. ---- */
-static int batch_ok(const lf_ks_plan *p, int nct) {
-    return plan_ok(p) && (nct == 1 || nct == 2 || nct == 4) && nct <= p->max_nct;
-}
-
-static int moddown_any(const lf_ks_plan *p, const int64_t *const *ss, int64_t *const *outs, const int64_t *const *adds, int count,
-                       int64_t gal_pinv, const int64_t *g2q, void *stream) {
-    const int64_t N = (int64_t)1 << p->logN;
-    // (the level constants sit behind the pivots of 2 * max_nct polynomials: a smaller group on a bigger plan takes the
-    // two-launch form, which rewrites them where its own count puts them)
-    if (p->K <= LF_MODDOWN_ONE_MAX_K && count == 2 * p->max_nct)
-        return lf_ks_moddown_one(ss, outs, adds, count, p->ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, gal_pinv, g2q,
-                                 p->ql, p->qh, p->kl, p->kh, p->device, stream);
-    return lf_ks_moddown_ws(ss, outs, adds, count, p->ell, p->K, N, p->md_ws, p->md_ws_words, p->PiR, p->PiP, p->Rs, gal_pinv, g2q, p->ql,
-                            p->qh, p->kl, p->kh, p->device, stream);
-}
-
 int lf_switch_key_batch(const lf_ks_plan *p, int nct, const int64_t *const *c0, const int64_t *const *c1, int64_t gal_pinv,
                         int gal_canonical, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
                         int key_format, int64_t *const *out0, int64_t *const *out1, void *stream) {

@@ -319,6 +319,7 @@ class HipBackend:
         if plan.K <= self.moddown_one_max_K:   # the ops then run the one-launch mod-down: its level constants, once
             check(lib.lf_ks_moddown_consts(plan.md_ws, plan.md_ws_words, 2 * plan.max_nct, plan.ell, plan.K, 1 << plan.logN, plan.PiP,
                                            *c.mont(), dev, st), "lf_ks_moddown_consts")
+            plan.md_consts = 2 * plan.max_nct   # the op entries take the one-launch form for exactly this count
         return plan, keep
 
     @staticmethod
