@@ -83,49 +83,80 @@ def event_time_ms(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def cpu_baseline(ctx, rows_idx, batch, budget_s=12.0):
-    """The oracle's NTT on the host cores over the same [batch*30, N] stack (OpenMP over rows)."""
-    from oracle import oracle as orc
-    h = lambda v: np.ascontiguousarray(np.tile(np.asarray([v[i] for i in rows_idx], dtype=np.int64), batch))
-    ql, qh, kl, kh = h(ctx.q_lower_bits), h(ctx.q_higher_bits), h(ctx.k_lower_bits), h(ctx.k_higher_bits)
-    q2, Rs = h(ctx.q_double), h(ctx.R_square)
-    psi = np.ascontiguousarray(np.tile(ctx.psi_br[rows_idx], (batch, 1)))
-    n = len(rows_idx) * batch
-    orc.mont_enter(psi, Rs, n, ql, qh, kl, kh)
-    rng = np.random.default_rng(5)
-    x = rng.integers(0, 1 << 40, size=(n, ctx.N), dtype=np.int64)
-    orc.ntt(x, psi, n, ctx.logN, q2, ql, qh, kl, kh)   # warm (page-in, thread pool)
-    t0, reps = time.time(), 0
-    while True:
-        orc.ntt(x, psi, n, ctx.logN, q2, ql, qh, kl, kh)
-        reps += 1
-        if time.time() - t0 > budget_s or reps >= 50:
-            break
-    dt = (time.time() - t0) / reps
-    threads = min(os.cpu_count() or 1, n)
-    out = {"value": batch / dt, "unit": "poly-NTT(L=30,logN=16)/s", "cores": threads, "kind": "port",
-           "sample": f"{reps} x forward NTT of {batch} polys x {len(rows_idx)} limbs, N=65536, C oracle + OpenMP over limb rows"}
-    # the same kernel on ONE core (BASELINE.md §4): one polynomial's 30 limbs, OpenMP pinned to a single thread
+def physical_cores():
+    """One logical CPU per physical core this process may run on (SMT siblings counted once), in CPU order."""
     try:
-        import ctypes
-        gomp = ctypes.CDLL("libgomp.so.1")
-        before = gomp.omp_get_max_threads()
-        gomp.omp_set_num_threads(1)
-        n1 = len(rows_idx)
-        x1 = np.ascontiguousarray(x[:n1])
-        orc.ntt(x1, psi[:n1], n1, ctx.logN, q2[:n1], ql[:n1], qh[:n1], kl[:n1], kh[:n1])
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return list(range(os.cpu_count() or 1))
+    seen, out = set(), []
+    for c in allowed:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            out.append(c)
+    return out or [0]
+
+
+def cpu_baseline(ctx, rows_idx, batch_cap=64, budget_s=12.0):
+    """The oracle's NTT on the host cores over a [batch*30, N] stack of the same workload.  Threads = min(rows, physical
+    cores), each pinned to its own core (oracle.pin_threads), static schedule, and every row — data and twiddles — first
+    touched by the thread that transforms it (oracle.place_rows), so nothing is read across sockets; the batch is the
+    smallest one <= batch_cap whose rows divide evenly over the threads (else batch_cap), so no thread idles in the last
+    round.  `value` = this threaded leg; `single_thread` = the same kernel on ONE core, the number a GPU/CPU ratio
+    should be read against."""
+    from oracle import oracle as orc
+    L = len(rows_idx)
+    cpus = physical_cores()
+    cores = len(cpus)
+    batch = next((b for b in range(1, batch_cap + 1) if b * L >= cores and (b * L) % cores == 0), batch_cap)
+    n = L * batch
+    threads = min(cores, n)
+    before = orc.omp_threads(threads)
+    affinity = os.sched_getaffinity(0)
+    unpinned = orc.pin_threads(cpus[:threads])
+    try:
+        col = lambda v: np.asarray([v[i] for i in rows_idx], dtype=np.int64)
+        h = lambda v: np.ascontiguousarray(np.tile(col(v), batch))
+        ql, qh, kl, kh = h(ctx.q_lower_bits), h(ctx.q_higher_bits), h(ctx.k_lower_bits), h(ctx.k_higher_bits)
+        q2 = h(ctx.q_double)
+        psi1 = np.ascontiguousarray(ctx.psi_br[rows_idx].copy())
+        orc.mont_enter(psi1, col(ctx.R_square), L, ql[:L], qh[:L], kl[:L], kh[:L])
+        psi = orc.place_rows(psi1, n)                       # row r's twiddles beside row r's thread
+        rng = np.random.default_rng(5)
+        x = orc.place_rows(rng.integers(0, 1 << 40, size=(L, ctx.N), dtype=np.int64), n)
+        orc.ntt(x, psi, n, ctx.logN, q2, ql, qh, kl, kh)   # warm (thread pool)
+        t0, reps = time.time(), 0
+        while True:
+            orc.ntt(x, psi, n, ctx.logN, q2, ql, qh, kl, kh)
+            reps += 1
+            if time.time() - t0 > budget_s or reps >= 200:
+                break
+        dt = (time.time() - t0) / reps
+        out = {"value": batch / dt, "unit": "poly-NTT(L=30,logN=16)/s", "cores": threads, "kind": "port",
+               "sample": f"{reps} x forward NTT of {batch} polys x {L} limbs, N=65536, C oracle, OpenMP static over limb rows, "
+                         f"{threads} threads pinned one per physical core ({cores} available, {unpinned} not pinned), "
+                         "rows and twiddles first-touched by their thread"}
+        # the same kernel on ONE core (BASELINE.md §4): one polynomial's 30 limbs, a single OpenMP thread
+        orc.omp_threads(1)
+        x1 = np.ascontiguousarray(x[:L])
+        orc.ntt(x1, psi[:L], L, ctx.logN, q2[:L], ql[:L], qh[:L], kl[:L], kh[:L])
         t0, reps1 = time.time(), 0
         while True:
-            orc.ntt(x1, psi[:n1], n1, ctx.logN, q2[:n1], ql[:n1], qh[:n1], kl[:n1], kh[:n1])
+            orc.ntt(x1, psi[:L], L, ctx.logN, q2[:L], ql[:L], qh[:L], kl[:L], kh[:L])
             reps1 += 1
             if time.time() - t0 > 4.0 or reps1 >= 20:
                 break
-        gomp.omp_set_num_threads(before)
         out["single_thread"] = {"value": reps1 / (time.time() - t0), "unit": "poly-NTT(L=30,logN=16)/s", "cores": 1,
-                                "sample": f"{reps1} x forward NTT of 1 poly x {n1} limbs, one OpenMP thread"}
-    except Exception as e:   # a baseline, never a reason to lose the line
-        out["single_thread"] = {"error": f"{type(e).__name__}: {e}"[:200]}
-    return out
+                                "sample": f"{reps1} x forward NTT of 1 poly x {L} limbs, one OpenMP thread"}
+        out["threads_speedup_over_one"] = out["value"] / out["single_thread"]["value"]
+        return out
+    finally:
+        orc.omp_threads(before)
+        os.sched_setaffinity(0, affinity)     # thread 0 of the team is this thread: give it its CPUs back
 
 
 def cpu_ntt_baseline_preset(name, budget_s=4.0):
@@ -365,10 +396,9 @@ def cpu_engine_baseline(preset="silver", budget_s=25.0, max_reps=10):
 
 
 def _reduce_device(dev):
-    """Where the tensors of the default group's reductions live: the GPU with RCCL, the host when the group is gloo (the
-    rehearsal, or the fallback after a failed RCCL initialisation)."""
-    import torch.distributed as dist
-    return "cpu" if "gloo" in str(dist.get_backend()) and "nccl" not in str(dist.get_backend()) else dev
+    """Where the tensors of the DEFAULT group's reductions live: the host — the default group is gloo on every run
+    (main(): RCCL is a second group, agreed on collectively)."""
+    return "cpu"
 
 
 def _max_over_ranks(ms, dev):
@@ -388,16 +418,17 @@ def _natural(eng, ct):
     return out
 
 
-def comm_prepare(dev, world, rank, local_rank):
+def comm_prepare(dev, world, rank, local_rank, grp=None):
     """N > 1, BEFORE the watchdog starts: the process group of the limb-sharded legs and one untimed all-pairs exchange on
-    it.  RCCL sets a point-to-point channel up lazily, on a pair's first message; the first key switch of the sharded
+    it (`grp` = the RCCL group main() brought up and the ranks agreed on; None in the rehearsal: a gloo group).  RCCL sets a point-to-point channel up lazily, on a pair's first message; the first key switch of the sharded
     engine addresses all N (N - 1) directed pairs in one group — that set-up belongs here, under the communicator's
     long timeout, not inside the 300 s watchdog of the timed legs.  Returns (group, comm block of the JSON line)."""
     import datetime
     import torch.distributed as dist
     # (its timeout must NOT undercut the watchdog: a communicator that times out first tears the process down before the
     # line is printed)
-    grp = dist.new_group(ranks=list(range(world)), timeout=datetime.timedelta(seconds=900))
+    if grp is None:    # rehearsal: gloo + host staging
+        grp = dist.new_group(ranks=list(range(world)), timeout=datetime.timedelta(seconds=900))
     pr = torch.cuda.get_device_properties(local_rank)
     me = {"rank": rank, "device": dev, "name": pr.name,
           "pci": f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}.0",
@@ -616,31 +647,47 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     nccl_error = None
+    rccl = None          # the RCCL process group (barriers of the timed region, the limb-sharded legs); None: not up
     if world > 1:
         import datetime
         import torch.distributed as dist
+        # The DEFAULT group is gloo on every run: it always comes up (host TCP), carries the host-side reductions (max over
+        # ranks, parity counters) and is what the ranks use to AGREE on whether RCCL is usable — a rank-local try/except
+        # around an RCCL initialisation would leave mixed backends behind a partial failure, and the job would hang.
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
         if rehearse:
-            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
             from tests import gloo_device_p2p      # gloo moves host memory only: device messages are staged (test transport)
             gloo_device_p2p.install()
         else:
             try:
-                dist.init_process_group("nccl", device_id=torch.device(dev), timeout=datetime.timedelta(seconds=900))
+                rccl = dist.new_group(ranks=list(range(world)), backend="nccl", timeout=datetime.timedelta(seconds=180))
+                probe = torch.ones(1, dtype=torch.int64, device=dev)
+                dist.all_reduce(probe, group=rccl)             # first RCCL collective of the process: communicator set-up
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"RCCL all_reduce of ones returned {int(probe.item())}, expected {world}")
             except Exception as e:
-                # RCCL did not come up: the replica headline needs only a barrier and a max over ranks — those run over gloo
-                # on host tensors; the limb-sharded legs (device point-to-point) are skipped and the line says why
-                print(f"[bench] rank {rank}: RCCL initialisation failed ({type(e).__name__}: {e}); falling back to gloo for the "
-                      "barriers, limb-sharded legs skipped", file=sys.stderr, flush=True)
                 nccl_error = f"{type(e).__name__}: {e}"[:300]
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=900))
+                print(f"[bench] rank {rank}: RCCL did not come up ({nccl_error})", file=sys.stderr, flush=True)
+            flag = torch.tensor([0 if nccl_error is None else 1], dtype=torch.int64)
+            dist.all_reduce(flag)                              # gloo: every rank learns the same answer
+            if int(flag.item()):
+                if nccl_error is None:
+                    nccl_error = f"RCCL came up here but failed on {int(flag.item())} of {world} ranks"
+                rccl = None
+
+    def barrier():
+        """Barrier of the timed region: on RCCL (a device-side collective on the compute device) when it is up, and always on
+        the default gloo group."""
+        if world > 1:
+            if rccl is not None:
+                dist.barrier(group=rccl)
+            dist.barrier()
 
     import __graft_entry__ as g
     if rank == 0:
         g.build()
-    if world > 1:
-        dist.barrier()
+    barrier()
 
     from liberate_fhe_amd._native import lib, check
     from liberate_fhe_amd.ntt import twiddles
@@ -672,8 +719,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
@@ -681,8 +727,7 @@ def main():
         step()
     e1.record()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     wall = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1) / args.steps
     if world > 1:
@@ -721,10 +766,15 @@ def main():
     except Exception as e:
         spot = f"ERROR: {type(e).__name__}: {e}"[:300]
     if world > 1:
-        t = torch.tensor([0 if spot == "ok" else 1], dtype=torch.int64, device=_reduce_device(dev))
+        # two counters over the ranks: only a MISMATCH anywhere fails the run; a checker ERROR elsewhere is reported as such
+        t = torch.tensor([1 if spot.startswith("MISMATCH") else 0, 1 if spot.startswith("ERROR") else 0], dtype=torch.int64,
+                         device=_reduce_device(dev))
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        if int(t.item()) and spot == "ok":
-            spot = f"MISMATCH on {int(t.item())} other rank(s)"
+        n_bad, n_err = int(t[0].item()), int(t[1].item())
+        if n_bad and not spot.startswith("MISMATCH"):
+            spot = f"MISMATCH on {n_bad} of {world} ranks (this rank: {spot})"
+        elif n_err and spot == "ok":
+            spot = f"ok on this rank; checker ERROR on {n_err} of {world} ranks (not a mismatch)"
 
     # Roofline of the dominant kernel, ntt_pass16_fwd_seq: the tiled pass (12 of the 16 stages) of all 30 limbs,
     # integer-class blocks first, then the fp64 class.  In the step above it follows the column pass, so it is
@@ -853,7 +903,9 @@ def main():
         "parity_spot_check": spot,
         "config": {"workload": f"gold preset (logN=16), rows {lo}..{total - 1} of the prime chain (25 scale + base + 4 special"
                                f" primes = 30 limbs), {B} polynomials per GPU per step, forward NTT via lf_ntt (C ABI)",
-                   "batch_per_gpu": B, "limbs": L_LIMBS, "logN": LOGN, "parallelism": f"replicas x{world} (independent polynomials)"},
+                   "batch_per_gpu": B, "limbs": L_LIMBS, "logN": LOGN, "parallelism": f"replicas x{world} (independent polynomials)",
+                   # repeated here because drivers keep `config` verbatim: "ok" = the timed kernel's words equal the oracle's
+                   "parity_spot_check": spot},
         # What bounds the dominant kernel is VALU instruction issue, not HBM (the bytes would take half the time): `frac`
         # stays the algorithmic-bytes fraction of the 8 TB/s HBM peak the contract asks for, `issue_frac` is the measured
         # utilisation of the pipe that actually limits it (PMC; null when the counters were not taken on this build)
@@ -910,7 +962,7 @@ def main():
         rates, roof = engine_rates(dev, quick=False)
         extra.update(rates)
         result["roofline_engine_ops"] = roof     # cc_mult_evk / rotate_single: the metric's second half, per preset
-        result["cpu_baseline"] = cpu_baseline(ctx, rows_idx, batch=min(B, 16))   # bounded sample of the same workload
+        result["cpu_baseline"] = cpu_baseline(ctx, rows_idx, batch_cap=min(B, 64))   # bounded sample of the same workload
         for preset, budget, reps in (("silver", 20.0, 10), ("bronze", 6.0, 10), ("gold", 15.0, 3)):
             try:
                 result["cpu_baseline"][f"cc_mult_evk_{preset}"] = cpu_engine_baseline(preset, budget, reps)
@@ -931,10 +983,11 @@ def main():
         done = threading.Event()
         grp = comm_block = None
         if nccl_error is not None:
-            result["comm"] = {"error": "RCCL initialisation failed, barriers over gloo, limb-sharded legs skipped: " + nccl_error}
+            result["comm"] = {"error": "RCCL did not come up on every rank; barriers over gloo, limb-sharded legs skipped: " + nccl_error}
+            result["sharded"] = "skipped: " + nccl_error
         elif not args.no_sharded:
             try:
-                grp, comm_block = comm_prepare(dev, world, rank, local_rank)     # untimed channel set-up, before the watchdog
+                grp, comm_block = comm_prepare(dev, world, rank, local_rank, rccl)     # untimed channel set-up, before the watchdog
                 result["comm"] = comm_block
             except Exception as e:
                 result["comm"] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -948,6 +1001,14 @@ def main():
         threading.Thread(target=watchdog, daemon=True).start()
         multi_gpu_rates(dev, world, rank, extra, sharded=not args.no_sharded and grp is not None, grp=grp, comm_block=comm_block)
         done.set()
+        # one top-level word on the limb-sharded legs (BASELINE configs[3]), so that a green replica line cannot be misread
+        if "sharded" not in result:
+            if args.no_sharded:
+                result["sharded"] = "skipped: --no-sharded"
+            elif "cc_mult_evk_gold_limb_sharded_ops_per_s" in extra:
+                result["sharded"] = "ok: parity-gated against the unsharded engine on every rank, then timed (extra.*limb_sharded*)"
+            else:
+                result["sharded"] = "failed: " + str(extra.get("multi_gpu_limb_sharded_error") or result.get("comm", {}).get("error") or "no rate produced")
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -957,7 +1018,9 @@ def main():
         except Exception:
             pass
     if spot.startswith("MISMATCH"):
-        sys.exit(4)      # the headline kernel's words differ from the oracle's on this box: the line says so, the exit code too
+        sys.exit(4)
+    if world > 1 and nccl_error is not None:
+        sys.exit(6)      # N > 1 without RCCL: the replica headline above is valid, the limb-sharded legs did not run — not a green run      # the headline kernel's words differ from the oracle's on this box: the line says so, the exit code too
     # (an ERROR of the checker itself — e.g. no C compiler for the oracle on the box — is reported in the line, not as a failure)
 
 

@@ -845,12 +845,14 @@ class ckks_engine(EvaluatorOps):
 
     def _cc_mult_sharded_native(self, a, b, evk, level, d):
         """cc_mult + relinearize of a limb-sharded level with the host side of this rank in three native calls + one per run
-        of digits (lf_cc_mult_evk_pre, lf_ks_plan_fwd, lf_cc_mult_evk_post) around the two exchanges."""
+        of digits (lf_cc_mult_evk_pre, lf_ks_plan_fwd, lf_cc_mult_evk_post) around the two exchanges.  Always completes: every
+        rank issues exactly one rescale exchange and one digit exchange per op, whatever the layout of its operands."""
         N = self.ctx.N
         per_dev, round_at = self._rescale_operands([a, b])               # exchange 1: the dropped limb's rows
         srcs, r0s = per_dev[d]
-        if not all(t.is_contiguous() for t in srcs + r0s):
-            return None
+        # never bail out from here: the exchange above has happened on every rank, and contiguity is a per-rank property —
+        # a rank that fell back to the step-by-step path would repeat it while its peers go on to the digit exchange
+        srcs, r0s = [t.contiguous() for t in srcs], [t.contiguous() for t in r0s]
         plan, _, first_part, row_off = self._op_plan(level, d)
         assert plan.round_at == round_at
         ins, row0s = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in srcs]), (ctypes.c_void_p * 4)(*[t.data_ptr() for t in r0s])

@@ -22,7 +22,11 @@
  * (compile with -fwrapv), arithmetic right shift of negative values
  * (gcc/clang behaviour, same as the CUDA device code).
  */
+#define _GNU_SOURCE
+#include <sched.h>
+#include <omp.h>
 #include <stdint.h>
+#include <string.h>
 #include <stddef.h>
 
 #define HALF 31
@@ -272,7 +276,8 @@ void lfo_ntt(int64_t *a, const int64_t *psi_br, int rows, int logN,
              const int64_t *_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh)
 {
     const int64_t N = (int64_t)1 << logN;
-#pragma omp parallel for schedule(dynamic, 1)
+    /* static schedule: row r always runs on the same thread, the one lfo_place_rows let touch its pages first */
+#pragma omp parallel for schedule(static)
     for (int r = 0; r < rows; ++r) {
         int64_t *x = a + (int64_t)r * N;
         const int64_t *w = psi_br + (int64_t)r * N;
@@ -298,7 +303,7 @@ void lfo_intt(int64_t *a, const int64_t *ipsi_br, const int64_t *Ninv, int rows,
               const int64_t *_2q, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh)
 {
     const int64_t N = (int64_t)1 << logN;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(static)
     for (int r = 0; r < rows; ++r) {
         int64_t *x = a + (int64_t)r * N;
         const int64_t *w = ipsi_br + (int64_t)r * N;
@@ -320,6 +325,32 @@ void lfo_intt(int64_t *a, const int64_t *ipsi_br, const int64_t *Ninv, int rows,
         }
         for (int64_t j = 0; j < N; ++j) x[j] = mm(x[j], Ninv[r], ql[r], qh[r], kl[r], kh[r]);
     }
+}
+
+/* Timing aid of bench.py's cpu_baseline (no reference counterpart): OpenMP thread t of the team of `n` pins itself to
+ * logical CPU cpus[t] (one per physical core, chosen by the caller).  Returns the number of threads that could not. */
+int lfo_pin_threads(const int *cpus, int n)
+{
+    int failed = 0;
+#pragma omp parallel num_threads(n) reduction(+ : failed)
+    {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        CPU_SET(cpus[omp_get_thread_num()], &set);
+        if (sched_setaffinity(0, sizeof(set), &set) != 0) failed += 1;
+    }
+    return failed;
+}
+
+/* Timing aid of bench.py's cpu_baseline (no reference counterpart): dst[r] = src[r mod src_rows] for r < rows, copied by
+ * the thread that lfo_ntt / lfo_intt will run row r on (same static schedule), so that on a multi-socket host every
+ * row's pages are first touched — and therefore placed — next to the core that transforms it.  dst must be fresh,
+ * untouched memory (np.empty) for the placement to happen. */
+void lfo_place_rows(int64_t *dst, const int64_t *src, int rows, int src_rows, int64_t N)
+{
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < rows; ++r)
+        memcpy(dst + (int64_t)r * N, src + (int64_t)(r % src_rows) * N, (size_t)N * sizeof(int64_t));
 }
 
 /* Galois automorphism on coefficient rows, following the reference's

@@ -134,5 +134,30 @@ def mont_sub(a, b, c, rows, _2q):
     lib().lfo_mont_sub(_i64(a), _i64(b), _i64(c), int(rows), _N(a), _i64(_2q))
 
 
+def place_rows(src, rows):
+    """[rows, N] copy of src (rows repeat cyclically), every row first touched by the OpenMP thread that ntt / intt run it
+    on (bench.py's cpu_baseline: page placement on a multi-socket host)."""
+    assert src.dtype == np.int64 and src.ndim == 2
+    dst = np.empty((rows, src.shape[1]), dtype=np.int64)
+    lib().lfo_place_rows(_i64(dst), _i64(np.ascontiguousarray(src)), int(rows), int(src.shape[0]), _N(src))
+    return dst
+
+
+def omp_threads(n=None):
+    """Read (n is None) or set the OpenMP thread count of the oracle's parallel loops."""
+    gomp = ctypes.CDLL("libgomp.so.1")
+    before = gomp.omp_get_max_threads()
+    if n is not None:
+        gomp.omp_set_num_threads(int(n))
+    return before
+
+
+def pin_threads(cpus):
+    """Pin OpenMP thread t of a team of len(cpus) to logical CPU cpus[t] (the calling thread is thread 0: restore its
+    affinity afterwards with os.sched_setaffinity).  Returns how many threads could not be pinned."""
+    arr = (ctypes.c_int * len(cpus))(*cpus)
+    return int(lib().lfo_pin_threads(arr, len(cpus)))
+
+
 def galois(a, dst, rows, p):
     lib().lfo_galois(_i64(a), _i64(dst), int(rows), _N(a), ctypes.c_int64(p))
