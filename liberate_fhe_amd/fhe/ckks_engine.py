@@ -1067,7 +1067,9 @@ class ckks_engine(EvaluatorOps):
         groups = tabs["groups"]
         if self.comm is not None and self.comm.world_size > 1:
             me = self.local_ids[0]
-            if not loc:   # no rows at this level: nothing to switch, nothing to send, nothing to receive
+            if not loc:   # no rows at this level: nothing to switch, nothing to send, nothing to receive ..
+                if getattr(self.comm, "whole_group_exchange", False):   # .. unless the exchange is a whole-group collective
+                    self.comm.exchange_rows(None, [(g[0], g[3], g[4]) for g in groups], list(range(n_alive)), width=N).wait()
                 return {}
             buf = self._ws("ks_digits_all", (tabs["total_rows"], N), me)
             for owner, first, count, row0, nrows, src_row in groups:

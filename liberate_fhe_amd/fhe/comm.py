@@ -38,10 +38,33 @@ class _Works:
             w.wait()
 
 
+class _GatherWorks:
+    """Handle of a padded all-gather: the wait orders the stream after the collective, then moves every foreign piece from
+    the gathered slab to its rows of the storage-order buffer (device-to-device copies on the caller's stream)."""
+
+    def __init__(self, work, moves):
+        self.work, self.moves = work, moves
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        for dst, src in self.moves:
+            dst.copy_(src)
+
+
 class DistComm:
-    def __init__(self, group=None, local_device=None):
+    """exchange = "p2p" (default): the key-switch digits travel as one batch of point-to-point messages between the ranks
+    that hold rows; "allgather": as ONE padded all-gather (RCCL: ncclAllGather) over the whole group — the form SURVEY.md
+    §8(e) and BASELINE's north star name.  Same words land in the same rows either way (tests/test_distributed_cpu.py);
+    which one is faster on xGMI is a measurement (`bench.py --gpus N` times both)."""
+
+    def __init__(self, group=None, local_device=None, exchange="p2p"):
         if not dist.is_initialized():
             raise RuntimeError("DistComm needs an initialised torch.distributed process group")
+        if exchange not in ("p2p", "allgather"):
+            raise ValueError("DistComm: exchange must be 'p2p' or 'allgather'")
+        self.exchange = exchange
+        self._slabs = {}
         self.group = group
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
@@ -74,7 +97,64 @@ class DistComm:
     # Device buffers need a backend that moves device memory point to point: RCCL ("nccl").  gloo carries host tensors
     # only — the CPU test-suite runs this very code over it; a GPU rehearsal over gloo installs the host-staging
     # transport of tests/gloo_device_p2p.py underneath dist.batch_isend_irecv (test infrastructure, not a fallback).
-    def exchange_rows(self, buf, pieces, peers):
+    @property
+    def whole_group_exchange(self):
+        """True: exchange_rows is a collective of the WHOLE group — ranks without rows at the level call it too (buf None)."""
+        return self.exchange == "allgather"
+
+    def exchange_rows(self, buf, pieces, peers, width=None):
+        """The digit exchange in this communicator's form (see the class docstring); `width` = words per row, needed
+        by a rank that passes buf = None (whole-group form, no rows at the level)."""
+        if self.exchange == "allgather":
+            return self.exchange_rows_allgather(buf, pieces, peers, width)
+        return self.exchange_rows_p2p(buf, pieces, peers)
+
+    def exchange_rows_allgather(self, buf, pieces, peers, width=None):
+        """The same exchange as ONE all-gather: every rank of the group contributes a slab of `most` rows — the pieces it
+        owns packed one after the other, the rest padding (shards are unequal: gold over 8 GPUs owns 7 / 4 / .. / 4 rows) —
+        and receives everybody's; the wait then copies every foreign piece to its rows of `buf`.  A collective of the whole
+        group: ranks outside `peers` call it with buf = None, contribute padding and drop what they receive.  Costs one
+        packing copy of the own rows, one scatter copy of the foreign ones, and `world x most` rows on the wire per rank
+        against the exact rows of the point-to-point form."""
+        world = self.world_size
+        owned = {}
+        for owner, row0, n in pieces:
+            owned.setdefault(owner, []).append((row0, n))
+        most = max(sum(n for _, n in v) for v in owned.values())
+        if buf is not None:
+            width, dtype, device = buf.shape[1], buf.dtype, buf.device
+        else:
+            if width is None:
+                raise ValueError("exchange_rows_allgather: a rank without rows must pass the row width")
+            dtype, device = torch.int64, torch.device(self.local_device)
+        key = (most, width, dtype, str(device))
+        slab = self._slabs.get(key)
+        if slab is None:
+            if len(self._slabs) > 64:
+                self._slabs.clear()
+            slab = self._slabs[key] = (torch.empty((most, width), dtype=dtype, device=device),
+                                       torch.empty((world, most, width), dtype=dtype, device=device))
+        send, recv = slab
+        moves = []
+        if buf is not None and self.rank in peers:
+            at = 0
+            for row0, n in owned.get(self.rank, []):
+                send[at:at + n].copy_(buf[row0:row0 + n])
+                at += n
+            for owner, ps in owned.items():
+                if owner == self.rank:
+                    continue
+                at = 0
+                for row0, n in ps:
+                    moves.append((buf[row0:row0 + n], recv[owner, at:at + n]))
+                    at += n
+        try:
+            work = dist.all_gather_into_tensor(recv.view(world * most, width), send, group=self.group, async_op=True)
+        except (RuntimeError, NotImplementedError):   # a backend without the flat form: the list form, same bytes
+            work = dist.all_gather([recv[r] for r in range(world)], send, group=self.group, async_op=True)
+        return _GatherWorks(work, moves)
+
+    def exchange_rows_p2p(self, buf, pieces, peers):
         """All-pairs exchange, in place on the contiguous [rows, N] `buf`.  pieces = [(owner, first row, rows), ..]
         (group ranks; every rank passes the same list), peers = the group ranks taking part.  This rank sends the
         pieces it owns to every other peer and receives every other piece from its owner — one batch of asynchronous

@@ -34,7 +34,7 @@ def _ops(eng, synth):
             "cc_mult(prod,prod,evk)": eng.cc_mult(prod, prod, evk)}
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, exchange="p2p"):
     warnings.filterwarnings("ignore")
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -45,7 +45,7 @@ def _worker(rank, world, port, outdir):
     from liberate_fhe_amd.fhe.comm import DistComm
     from liberate_fhe_amd.utils import synth
     from tests.oracle_backend import OracleBackend
-    eng = ckks_engine(devices=["cpu"], backend=OracleBackend(), comm=DistComm(local_device="cpu"), **PARAMS)
+    eng = ckks_engine(devices=["cpu"], backend=OracleBackend(), comm=DistComm(local_device="cpu", exchange=exchange), **PARAMS)
     assert eng.local_ids == [rank]
     for name, ct in _ops(eng, synth).items():
         for comp, shards in enumerate(ct.data):
@@ -56,10 +56,10 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def _run(world):
-    port = 29500 + (os.getpid() % 2000) + world
+def _run(world, exchange="p2p"):
+    port = 29500 + (os.getpid() % 2000) + world + (50 if exchange != "p2p" else 0)
     with tempfile.TemporaryDirectory() as outdir:
-        mp.spawn(_worker, args=(world, port, outdir), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, outdir, exchange), nprocs=world, join=True)
         out = {}
         for f in os.listdir(outdir):
             name, comp, rank, _ = f.rsplit(".", 3)
@@ -75,8 +75,10 @@ def _digest(shards_by_rank):
     return h.hexdigest()
 
 
-def test_two_ranks_reproduce_reference_two_device_digests():
-    got = _run(2)
+@pytest.mark.parametrize("exchange", ["p2p", "allgather"])
+def test_two_ranks_reproduce_reference_two_device_digests(exchange):
+    """Both forms of the digit exchange (point-to-point batch, padded all-gather) against the REFERENCE's digests."""
+    got = _run(2, exchange)
     want = GOLD["small_x2"]["ops"]
     assert set(got) == set(want)
     for name, comps in want.items():
@@ -84,14 +86,15 @@ def test_two_ranks_reproduce_reference_two_device_digests():
             assert _digest(got[name][comp]) == rec["sha256"], (name, comp)
 
 
-def test_three_ranks_equal_single_process_three_devices():
+@pytest.mark.parametrize("exchange", ["p2p", "allgather"])
+def test_three_ranks_equal_single_process_three_devices(exchange):
     warnings.filterwarnings("ignore")
     from liberate_fhe_amd.fhe import ckks_engine
     from liberate_fhe_amd.utils import synth
     from tests.oracle_backend import OracleBackend
     eng = ckks_engine(devices=["cpu"] * 3, backend=OracleBackend(), **PARAMS)
     want = _ops(eng, synth)
-    got = _run(3)
+    got = _run(3, exchange)
     for name, ct in want.items():
         for comp, tensors in enumerate(ct.data):
             h = hashlib.sha256()
@@ -248,7 +251,7 @@ def _chain_ops(eng, synth):
     return out
 
 
-def _chain_worker(rank, world, port, outdir):
+def _chain_worker(rank, world, port, outdir, exchange="p2p"):
     warnings.filterwarnings("ignore")
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
@@ -260,7 +263,7 @@ def _chain_worker(rank, world, port, outdir):
     from liberate_fhe_amd.fhe.comm import DistComm
     from liberate_fhe_amd.utils import synth
     from tests.oracle_backend import OracleBackend
-    eng = ckks_engine(devices=["cpu"], backend=OracleBackend(), comm=DistComm(local_device="cpu"), **GOLD_SHAPE)
+    eng = ckks_engine(devices=["cpu"], backend=OracleBackend(), comm=DistComm(local_device="cpu", exchange=exchange), **GOLD_SHAPE)
     for name, ct in _chain_ops(eng, synth).items():
         for comp, shards in enumerate(ct.data):
             arr = shards[0].numpy() if shards else np.zeros((0, eng.ctx.N), dtype=np.int64)
@@ -269,7 +272,10 @@ def _chain_worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_eight_ranks_gold_chain_shape_through_levels_where_ranks_drop_out():
+@pytest.mark.parametrize("exchange", ["p2p", "allgather"])
+def test_eight_ranks_gold_chain_shape_through_levels_where_ranks_drop_out(exchange):
+    """.. in both forms of the digit exchange: the all-gather is a collective of the whole group, so the ranks that have run
+    out of rows at a level still take part in it (padding in, nothing kept) — word for word the point-to-point results."""
     warnings.filterwarnings("ignore")
     from liberate_fhe_amd.fhe import ckks_engine
     from liberate_fhe_amd.utils import synth
@@ -278,9 +284,9 @@ def test_eight_ranks_gold_chain_shape_through_levels_where_ranks_drop_out():
     assert [len(d) for d in eng.ntt.p.destination_arrays_with_special[0]] == [11, 8, 8, 8, 8, 8, 8, 8]
     assert (eng.len_devices[0], eng.len_devices[10], eng.len_devices[20], eng.len_devices[33]) == (8, 7, 4, 1)
     want = _chain_ops(eng, synth)
-    port = 33500 + (os.getpid() % 2000)
+    port = 33500 + (os.getpid() % 2000) + (50 if exchange != "p2p" else 0)
     with tempfile.TemporaryDirectory() as outdir:
-        mp.spawn(_chain_worker, args=(8, port, outdir), nprocs=8, join=True)
+        mp.spawn(_chain_worker, args=(8, port, outdir, exchange), nprocs=8, join=True)
         for name, ct in want.items():
             for comp, shards in enumerate(ct.data):
                 for rank in range(8):
