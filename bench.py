@@ -294,6 +294,88 @@ def engine_rates(dev, quick):
     return out, roof
 
 
+def ntt_rates_preset(name, dev, batch, iters=20):
+    """BASELINE's metric is quoted at logN 15 AND 16: forward (lf_ntt = ntt_cuda.ntt, exact lazy words) and inverse (lf_intt
+    with tail 2 = ntt_cuda.intt_exit_reduce) transforms of `batch` polynomials x EVERY limb of the preset's chain (special
+    primes included: silver 19, gold 39, platinum 59+) through the C ABI, inputs resident in HBM, each with its roofline
+    block (16 N bytes per limb-NTT).  Outside the headline's timed region; N = 1 only."""
+    from liberate_fhe_amd._native import lib, check
+    from liberate_fhe_amd.fhe import presets
+    from liberate_fhe_amd.fhe.context.ckks_context import ckks_context
+    from liberate_fhe_amd.ntt import ntt_context, twiddles
+    from liberate_fhe_amd.utils import synth
+    params = {k: v for k, v in presets.params[name].items() if k != "devices"}
+    ctx = ckks_context(**params)
+    ntt = ntt_context(ctx, devices=[dev])
+    L, N, logN = len(ctx.q), ctx.N, ctx.logN
+    d = torch.device(dev).index or 0
+    x = torch.empty((batch, L, N), dtype=torch.int64, device=dev)
+    one = torch.from_numpy(synth.uniform_rows(77, list(range(L)), ctx.q, N, lazy=True)).to(dev)
+    x[:] = one
+    psi, ipsi, q2, ql, qh, kl, kh, ninv = (t[0] for t in (ntt.psi, ntt.ipsi, ntt._2q, ntt.ql, ntt.qh, ntt.kl, ntt.kh, ntt.Ninv))
+    st = torch.cuda.current_stream().cuda_stream
+    dp, idp = twiddles.dp_pointer(psi, ql, qh, kl, kh, d, st), twiddles.dp_pointer(ipsi, ql, qh, kl, kh, d, st)
+    q_host = np.array(ctx.q, dtype=np.int64)
+
+    def fwd():
+        check(lib.lf_ntt(x.data_ptr(), batch, L, logN, psi.data_ptr(), dp, q_host.ctypes.data, 0, 0, q2.data_ptr(), ql.data_ptr(),
+                         qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), d, st), "lf_ntt")
+
+    def inv():
+        check(lib.lf_intt(x.data_ptr(), batch, L, logN, ipsi.data_ptr(), idp, q_host.ctypes.data, ninv.data_ptr(), 2, 0, q2.data_ptr(),
+                          ql.data_ptr(), qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), d, st), "lf_intt")
+
+    # round trip first: intt_exit_reduce(ntt(x)) is x's canonical residues (the transforms are exact inverses modulo q)
+    fwd(); inv()
+    torch.cuda.synchronize()
+    qcol = torch.tensor(ctx.q, dtype=torch.int64, device=dev)[:, None]
+    ok = bool(torch.equal(x[0], one % qcol))
+    out = {"limbs": L, "logN": logN, "batch": batch, "round_trip_identity": ok}
+    nbytes = 16 * N * L * batch
+    for key, fn, prep in (("forward", fwd, None), ("inverse_exit_reduce", inv, fwd)):
+        x[:] = one
+        if prep:
+            prep()
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        ms = event_time_ms(fn, iters)
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out[key] = {"poly_ntt_per_s": batch / (ms * 1e-3), "limb_ntt_per_s": batch * L / (ms * 1e-3), "ms_per_step": ms,
+                    "roofline": {"bound": "valu_issue" if logN >= 13 else "latency", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_step": nbytes,
+                                 "note": "whole transform (both launches), 16 N bytes per limb; no PMC table for this shape"}}
+    del x
+    torch.cuda.empty_cache()
+    return out
+
+
+def platinum_rates(dev):
+    """The reference's largest preset (logN 17, 6 special primes; presets/params.py): cc_mult(+relinearize) and rotate_single
+    ops/s.  logN 17 takes the 8-words tiled kernels and the LDS-tiled extension."""
+    from liberate_fhe_amd.fhe import ckks_engine, presets
+    from liberate_fhe_amd.utils import synth
+    eng = ckks_engine(**{**presets.params["platinum"], "devices": [dev]})
+    a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
+    evk = synth.key_switch_key(eng, 5)
+    rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
+    for _ in range(10):
+        eng.cc_mult(a, b, evk)
+        eng.rotate_single(a, rotk)
+    torch.cuda.synchronize()
+    out = {}
+    ms = event_time_ms(lambda: eng.cc_mult(a, b, evk), 20)
+    out["cc_mult_evk_platinum_ops_per_s"] = 1e3 / ms
+    out["roofline_cc_mult"] = op_roofline(eng, "cc_mult", 1e3 / ms, None)
+    ms = event_time_ms(lambda: eng.rotate_single(a, rotk), 20)
+    out["rotate_single_platinum_ops_per_s"] = 1e3 / ms
+    out["roofline_rotate"] = op_roofline(eng, "rotate", 1e3 / ms, None)
+    out["limbs_level0_with_special"] = len(eng.ntt.p.destination_arrays_with_special[0][0])
+    del eng, a, b, evk, rotk
+    torch.cuda.empty_cache()
+    return out
+
+
 def api_endpoints(dev):
     """Wall-clock of the API endpoints the reference's example notebook times (`examples/[Example] CKKS
     engine.ipynb` cells 6-12, silver, unnamed NVIDIA GPU — context, not a target).  Every figure here is SYNCHRONISED
@@ -958,6 +1040,21 @@ def main():
         extra["poly_ntt_per_s_ciphertext_limbs_1_integer_class"] = B / (ct_ms * 1e-3)
         extra["ciphertext_limbs_note"] = (f"rows {lo_ct}..{total - 5}: 29 scale primes + base prime (a level-5 ciphertext, no special primes);"
                                           " reported for the limb-mix sensitivity only, the metric above keeps its 5 integer-class limbs")
+        # the other halves of BASELINE's metric ("NTTs/sec at logN = 15, 16"): every limb of the silver chain at logN 15, the
+        # whole gold chain incl. the inverse chain, and the reference's largest preset — each with its own roofline block
+        x = None      # the headline's stack (3.75 GiB) is not needed any more
+        torch.cuda.empty_cache()
+        ntt_presets = {}
+        for pname, pbatch in (("silver", 256), ("gold", 96), ("platinum", 24)):
+            try:
+                ntt_presets[pname] = ntt_rates_preset(pname, dev, pbatch)
+            except Exception as e:
+                ntt_presets[pname] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        result["ntt_presets"] = ntt_presets
+        try:
+            extra["platinum"] = platinum_rates(dev)
+        except Exception as e:
+            extra["platinum"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         extra["api_endpoints"] = api_endpoints(dev)
         rates, roof = engine_rates(dev, quick=False)
         extra.update(rates)

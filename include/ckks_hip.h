@@ -35,7 +35,7 @@ extern "C" {
 #define LF_ERR_ARG 10001
 
 /* Library probe: returns the ABI version (currently LF_ABI_VERSION; __graft_entry__.build() asserts it). */
-#define LF_ABI_VERSION 11
+#define LF_ABI_VERSION 12
 int lf_abi_version(void);
 
 /* Compile-time capacities of the fused kernels, so that callers can refuse a parameter set BEFORE any launch
@@ -123,6 +123,11 @@ int lf_mont_sub(const int64_t *a, const int64_t *b, int64_t *c, int rows, int64_
  * only, lf_intt (tail >= 2) multiplies fp64-class limbs by N^-1 instead of N^-1 R^-1.  Used by the fused
  * cc_mult, whose tensor product then needs one plain modular product per term (lf_tensor, plain = 1). */
 #define LF_NTT_PLAIN 2
+/* lf_rescale_ntt at two-launch ring degrees (logN 13 .. 16) only: enqueue ONE of its two launches — the column pass, the only
+ * one that reads `in` / `row0` (addresses that change from call to call), or the tiled pass, which touches `x` alone (a
+ * caller may keep it, with the launches behind it, in a HIP graph: lf_cc_mult_evk_pre's `which`).  Not both. */
+#define LF_NTT_ONLY_COLS 4
+#define LF_NTT_ONLY_TILED 8
 
 /* The auxiliary table from the Montgomery-form compact table mont[rows][N]: out[rows][2N] (8-byte words).
  * Primes below 2^41: out[r][j] = (double)reduce_q(redc(mont[r][j])) for j < N; entry 0 of the row (psi^0 = 1, which
@@ -163,6 +168,11 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
 int lf_intt_mul(int64_t *dst, const int64_t *a, int64_t a_stride, const int64_t *b, int64_t b_stride, int batch, int rows, int logN,
                 const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *q_host, const int64_t *Ninv, int tail, int flags,
                 const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+
+/* Not one of the reference's ops: `count` (<= 8) rows of N words, each anywhere in device memory (16-byte aligned; HOST array
+ * of device pointers), into the consecutive rows of dst — one launch.  The engine stages the dropped limb's rows of all
+ * operands of a rescale with it before they fan out to the other ranks (ckks_engine.py:999-1011 stages them through the host). */
+int lf_gather_rows(const int64_t *const *src, int64_t *dst, int count, int64_t N, int device, void *stream);
 
 /* Galois automorphism of coefficient-domain rows (reference: encdec.py:224-270 `rotate`/`conjugate`,
  * done there with torch advanced indexing): dst[i][(p*n mod 2N) mod N] = +/- a[i][n], sign - iff
@@ -426,15 +436,21 @@ int lf_cc_mult_evk_batch(const lf_ks_plan *plan, int nct, const int64_t *const *
  *                                            storage-order buffer `digits` (own digits while the others travel, foreign runs
  *                                            after the wait); relin != 0: inside cc_mult (own-limb pairs skipped);
  *   lf_cc_mult_evk_post / lf_switch_key_post inner product over ALL digits + inverse NTT + mod-down (+ c0(X^p)).
- * pre, fwd over every digit, post == lf_cc_mult_evk / lf_switch_key. */
-int lf_cc_mult_evk_pre(const lf_ks_plan *plan, const int64_t *const *in, const int64_t *const *row0, void *stream);
+ * pre, fwd over every digit, post == lf_cc_mult_evk / lf_switch_key.
+ * `which` (bit mask, 3 = the whole half) separates the launches whose ADDRESSES change from call to call from those that only
+ * touch the plan's scratch, tables and the key — the second kind can be captured once into a HIP graph and replayed (the
+ * engine does: a rank of a sharded gold cc_mult enqueues in ~55 us of host time instead of 140, profiles/r05_host_overhead.txt):
+ *   lf_cc_mult_evk_pre   1 = the launch that reads in / row0 (rescale + column pass), 2 = the rest (tiled pass, x1 * y1,
+ *                        inverse NTT, digits);  lf_switch_key_pre is one launch, it reads c1;
+ *   lf_*_post            1 = inner product + inverse NTT, 2 = the mod-down (reads c0, writes out0 / out1). */
+int lf_cc_mult_evk_pre(const lf_ks_plan *plan, const int64_t *const *in, const int64_t *const *row0, int which, void *stream);
 int lf_switch_key_pre(const lf_ks_plan *plan, const int64_t *c1, int64_t gal_pinv, int gal_canonical, void *stream);
 int lf_ks_plan_fwd(const lf_ks_plan *plan, const int64_t *digits, int first, int count, int relin, void *stream);
 int lf_cc_mult_evk_post(const lf_ks_plan *plan, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
-                        int key_format, int64_t *out0, int64_t *out1, void *stream);
+                        int key_format, int64_t *out0, int64_t *out1, int which, void *stream);
 int lf_switch_key_post(const lf_ks_plan *plan, const int64_t *c0, int64_t gal_pinv, int gal_canonical, const int64_t *ksk,
                        int64_t part_stride, int64_t comp_stride, int64_t row_off, int key_format, int64_t *out0, int64_t *out1,
-                       void *stream);
+                       int which, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Samplers: the reference's csprng extensions, src/liberate/csprng/.

@@ -59,6 +59,7 @@ _SIGNATURES = {
     "lf_ks_digits_batch": [_P, _P, _I, _I, _P, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P],
     "lf_ks_digits_galois": [_P, _P, _I, _P, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P],
     "lf_galois_batch": [_P, _P, _I, _I, _I, _L, _P, _I, _P],
+    "lf_gather_rows": [_P, _P, _I, _L, _I, _P],
     "lf_rescale_ntt": [_P, _P, _I, _P, _I, _I, _P, _L, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P],
     "lf_chacha20": [_P, _P, _L, _U, _I, _P],
     "lf_randint_fast": [_P, _P, _I, _L, _P, _L, _U, _I, _P],
@@ -94,11 +95,11 @@ _SIGNATURES["lf_switch_key"] = [ctypes.POINTER(KsPlan), _P, _P, _L, _I, _P, _L, 
 _PL = ctypes.POINTER(KsPlan)
 _SIGNATURES["lf_switch_key_batch"] = [_PL, _I, _P, _P, _L, _I, _P, _L, _L, _L, _I, _P, _P, _P]
 _SIGNATURES["lf_cc_mult_evk_batch"] = [_PL, _I, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P]
-_SIGNATURES["lf_cc_mult_evk_pre"] = [_PL, _P, _P, _P]
+_SIGNATURES["lf_cc_mult_evk_pre"] = [_PL, _P, _P, _I, _P]
 _SIGNATURES["lf_switch_key_pre"] = [_PL, _P, _L, _I, _P]
 _SIGNATURES["lf_ks_plan_fwd"] = [_PL, _P, _I, _I, _I, _P]
-_SIGNATURES["lf_cc_mult_evk_post"] = [_PL, _P, _L, _L, _L, _I, _P, _P, _P]
-_SIGNATURES["lf_switch_key_post"] = [_PL, _P, _L, _I, _P, _L, _L, _L, _I, _P, _P, _P]
+_SIGNATURES["lf_cc_mult_evk_post"] = [_PL, _P, _L, _L, _L, _I, _P, _P, _I, _P]
+_SIGNATURES["lf_switch_key_post"] = [_PL, _P, _L, _I, _P, _L, _L, _L, _I, _P, _P, _I, _P]
 
 for _name, _args in _SIGNATURES.items():
     _fn = getattr(lib, _name)
@@ -120,3 +121,5 @@ LF_KEY_RAW = 0
 LF_KEY_PLANES = 1
 LF_NTT_RELAXED = 1
 LF_NTT_PLAIN = 2
+LF_NTT_ONLY_COLS = 4
+LF_NTT_ONLY_TILED = 8

@@ -84,6 +84,11 @@ struct GaloisBatch {
     i64 *dst[LF_BATCH_MAX];
 };
 
+__global__ void __launch_bounds__(256) gather_rows_kernel(GaloisBatch gb, i64 N) {
+    const i64 j = ((i64)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (j < N) *reinterpret_cast<longlong2 *>(gb.dst[blockIdx.y] + j) = *reinterpret_cast<const longlong2 *>(gb.a[blockIdx.y] + j);
+}
+
 __global__ void __launch_bounds__(256) galois_kernel(GaloisBatch gb, int logN, i64 p, const i64 *__restrict__ _2q) {
     const i64 *__restrict__ a = gb.a[blockIdx.z];
     i64 *__restrict__ dst = gb.dst[blockIdx.z];
@@ -209,6 +214,21 @@ int lf_galois_batch(const int64_t *const *a, int64_t *const *dst, int count, int
     const i64 N = (i64)1 << logN;
     dim3 grid((unsigned)((N + 255) / 256), (unsigned)rows, (unsigned)count);
     hipLaunchKernelGGL(galois_kernel, grid, dim3(256), 0, (hipStream_t)stream, gb, logN, (i64)p, (const i64 *)_2q);
+    return (int)hipGetLastError();
+}
+
+// count (<= LF_BATCH_MAX) rows of N words from anywhere into consecutive rows of dst: ONE launch where a host loop of copies
+// would be `count` (the owner of a dropped limb stages the rows its peers need: ckks_engine._rescale_operands)
+int lf_gather_rows(const int64_t *const *src, int64_t *dst, int count, int64_t N, int device, void *stream) {
+    if (count < 0 || count > LF_BATCH_MAX || N < 2 || (N & 1) || !src || !dst) return LF_ERR_ARG;
+    for (int i = 0; i < count; ++i)
+        if (!src[i] || ((uintptr_t)src[i] & 15)) return LF_ERR_ARG;
+    if ((uintptr_t)dst & 15) return LF_ERR_ARG;
+    if (count == 0) return 0;
+    if (int e = lf_set_device(device)) return e;
+    GaloisBatch gb;
+    for (int i = 0; i < count; ++i) gb.a[i] = (const i64 *)src[i], gb.dst[i] = (i64 *)dst + (i64)i * N;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((N / 2 + 255) / 256), (unsigned)count), dim3(256), 0, (hipStream_t)stream, gb, (i64)N);
     return (int)hipGetLastError();
 }
 

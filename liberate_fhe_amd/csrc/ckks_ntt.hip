@@ -157,12 +157,16 @@ int lf_rescale_ntt(const int64_t *const *in, const int64_t *const *row0, int cou
     if ((flags & LF_NTT_RELAXED) && (!psi_dp || !q_host)) return LF_ERR_ARG;   // before anything is launched
     if (count == 0 || rows == 0) return 0;
     const int S1 = logN - NTT_TILE_LOG_MAX;
+    if ((flags & (LF_NTT_ONLY_COLS | LF_NTT_ONLY_TILED)) && !(S1 >= 1 && S1 <= 4)) return LF_ERR_ARG;   // two-launch sizes only
     if (S1 >= 1 && S1 <= 4) {
         RescaleSrc rsrc;
         for (int i = 0; i < count; ++i) rsrc.in[i] = (const i64 *)in[i], rsrc.row0[i] = (const i64 *)row0[i];
         rsrc.scales = (const i64 *)scales;
         rsrc.round_at = (i64)round_at;
-        return ntt_forward(x, count, rows, logN, psi_br, psi_dp, q_host, Rs, flags, ql, qh, kl, kh, device, stream, &rsrc);
+        // LF_NTT_ONLY_COLS / LF_NTT_ONLY_TILED: one of the two launches (the first reads `in` / `row0`, the second only `x`)
+        const int only = (flags & LF_NTT_ONLY_COLS) ? 1 : (flags & LF_NTT_ONLY_TILED) ? 2 : 0;
+        if ((flags & LF_NTT_ONLY_COLS) && (flags & LF_NTT_ONLY_TILED)) return LF_ERR_ARG;
+        return ntt_forward(x, count, rows, logN, psi_br, psi_dp, q_host, Rs, flags, ql, qh, kl, kh, device, stream, &rsrc, only);
     }
     // sizes without a column pass: the two steps one after the other
     int64_t *outs[LF_NTT_RS_MAX];

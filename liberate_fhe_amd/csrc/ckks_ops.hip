@@ -156,14 +156,24 @@ int lf_cc_mult_evk_batch(const lf_ks_plan *p, int nct, const int64_t *const *in,
  *   fwd    extension + forward NTT of digits first .. first + count - 1 of the gathered buffer (own digits while the
  *          others travel, the foreign runs after the wait);
  *   post   inner product over all digits + inverse NTT + mod-down. ---- */
-int lf_cc_mult_evk_pre(const lf_ks_plan *p, const int64_t *const *in, const int64_t *const *row0, void *stream) {
-    if (!plan_ok(p) || !p->rescale_scales || !p->x4 || !p->d2 || !in || !row0) return LF_ERR_ARG;
+int lf_cc_mult_evk_pre(const lf_ks_plan *p, const int64_t *const *in, const int64_t *const *row0, int which, void *stream) {
+    if (!plan_ok(p) || !p->rescale_scales || !p->x4 || !p->d2 || !(which & 3) || (which & ~3) || ((which & 1) && (!in || !row0)))
+        return LF_ERR_ARG;
     const int ell = p->ell, logN = p->logN, dev = p->device;
     const int64_t N = (int64_t)1 << logN, poly = (int64_t)ell * N;
     const int relaxed_plain = LF_NTT_RELAXED | LF_NTT_PLAIN;
-    if (int e = lf_rescale_ntt(in, row0, 4, p->x4, ell, logN, p->rescale_scales, p->round_at, p->psi, p->psi_dp, p->q_host, p->Rs,
-                               relaxed_plain, p->_2q, p->ql, p->qh, p->kl, p->kh, dev, stream))
-        return e;
+    // which = 3: everything.  1: only the launch that reads the operands (rescale + column pass) — the one launch of this half
+    // whose addresses change from call to call; 2: the rest (fixed addresses of the plan: a caller may replay it from a graph)
+    const int64_t *const none[8] = {};   // (lf_rescale_ntt takes up to 8 polynomials; unused by the tiled pass)
+    if (which & 1)
+        if (int e = lf_rescale_ntt(in, row0, 4, p->x4, ell, logN, p->rescale_scales, p->round_at, p->psi, p->psi_dp, p->q_host, p->Rs,
+                                   relaxed_plain | (which == 3 ? 0 : LF_NTT_ONLY_COLS), p->_2q, p->ql, p->qh, p->kl, p->kh, dev, stream))
+            return e;
+    if (!(which & 2)) return 0;
+    if (which == 2)
+        if (int e = lf_rescale_ntt(none, none, 4, p->x4, ell, logN, p->rescale_scales, p->round_at, p->psi, p->psi_dp, p->q_host, p->Rs,
+                                   relaxed_plain | LF_NTT_ONLY_TILED, p->_2q, p->ql, p->qh, p->kl, p->kh, dev, stream))
+            return e;
     if (int e = lf_intt_mul(p->d2, p->x4 + poly, poly, p->x4 + 3 * poly, poly, 1, ell, logN, p->ipsi, p->ipsi_dp, p->q_host, p->Ninv, 2,
                             relaxed_plain, p->ql, p->qh, p->kl, p->kh, dev, stream))
         return e;
@@ -188,13 +198,17 @@ int lf_ks_plan_fwd(const lf_ks_plan *p, const int64_t *digits, int first, int co
 }
 
 int lf_cc_mult_evk_post(const lf_ks_plan *p, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
-                        int key_format, int64_t *out0, int64_t *out1, void *stream) {
-    if (!plan_ok(p) || !p->PR || !p->x4 || !ksk || !out0 || !out1) return LF_ERR_ARG;
+                        int key_format, int64_t *out0, int64_t *out1, int which, void *stream) {
+    if (!plan_ok(p) || !p->PR || !p->x4 || !(which & 3) || (which & ~3) || ((which & 1) && !ksk) || ((which & 2) && (!out0 || !out1)))
+        return LF_ERR_ARG;
     const int rows = p->ell + p->K;
     const int64_t N = (int64_t)1 << p->logN;
-    if (int e = lf_relin_tail(p->nparts, rows, p->logN, ksk, part_stride, comp_stride, row_off, key_format, p->ext, p->sum, p->ipsi,
-                              p->ipsi_dp, p->Ninv, p->x4, p->PR, p->ell, p->own, p->q_host, p->ql, p->qh, p->kl, p->kh, p->device, stream))
-        return e;
+    // which: 1 = inner product + inverse NTT (fixed addresses: plan scratch and the key), 2 = the mod-down that writes out0 / out1
+    if (which & 1)
+        if (int e = lf_relin_tail(p->nparts, rows, p->logN, ksk, part_stride, comp_stride, row_off, key_format, p->ext, p->sum, p->ipsi,
+                                  p->ipsi_dp, p->Ninv, p->x4, p->PR, p->ell, p->own, p->q_host, p->ql, p->qh, p->kl, p->kh, p->device, stream))
+            return e;
+    if (!(which & 2)) return 0;
     const int64_t *ss[2] = {p->sum, p->sum + (int64_t)rows * N};
     int64_t *outs[2] = {out0, out1};
     return moddown_any(p, ss, outs, nullptr, 2, 0, nullptr, stream);
@@ -202,14 +216,16 @@ int lf_cc_mult_evk_post(const lf_ks_plan *p, const int64_t *ksk, int64_t part_st
 
 int lf_switch_key_post(const lf_ks_plan *p, const int64_t *c0, int64_t gal_pinv, int gal_canonical, const int64_t *ksk,
                        int64_t part_stride, int64_t comp_stride, int64_t row_off, int key_format, int64_t *out0, int64_t *out1,
-                       void *stream) {
-    if (!plan_ok(p) || !ksk || !out0 || !out1) return LF_ERR_ARG;
+                       int which, void *stream) {
+    if (!plan_ok(p) || !(which & 3) || (which & ~3) || ((which & 1) && !ksk) || ((which & 2) && (!out0 || !out1))) return LF_ERR_ARG;
     const int rows = p->ell + p->K;
     const int64_t N = (int64_t)1 << p->logN;
     const int64_t *g2q = (gal_pinv && gal_canonical) ? p->_2q : nullptr;
-    if (int e = lf_ks_tail(p->nparts, rows, p->logN, ksk, part_stride, comp_stride, row_off, key_format, p->ext, p->sum, p->ipsi, p->ipsi_dp,
-                           p->Ninv, p->q_host, p->ql, p->qh, p->kl, p->kh, p->device, stream))
-        return e;
+    if (which & 1)   // see lf_cc_mult_evk_post
+        if (int e = lf_ks_tail(p->nparts, rows, p->logN, ksk, part_stride, comp_stride, row_off, key_format, p->ext, p->sum, p->ipsi, p->ipsi_dp,
+                               p->Ninv, p->q_host, p->ql, p->qh, p->kl, p->kh, p->device, stream))
+            return e;
+    if (!(which & 2)) return 0;
     const int64_t *ss[2] = {p->sum, p->sum + (int64_t)rows * N};
     int64_t *outs[2] = {out0, out1};
     const int64_t *adds[2] = {c0, nullptr};

@@ -140,6 +140,11 @@ class HipBackend:
         dev, st = _ds(dsts[0])
         check(lib.lf_galois_batch(_parr(srcs), _parr(dsts), len(srcs), rows, logN, p, _p(_2q), dev, st), "lf_galois_batch")
 
+    def gather_rows(self, rows, dst):
+        """len(rows) <= 8 row tensors [N] -> the consecutive rows of dst [len(rows), N]: one launch."""
+        dev, st = _ds(dst)
+        check(lib.lf_gather_rows(_parr(rows), _p(dst), len(rows), dst.size(-1), dev, st), "lf_gather_rows")
+
     # ---- fused engine ops ------------------------------------------------------------------------
     def rescale_batch(self, srcs, row0s, outs, rows, scales, round_at, c: Consts):
         dev, st = _ds(outs[0])
@@ -346,8 +351,9 @@ class HipBackend:
               "lf_cc_mult_evk_batch")
 
     # ---- the halves of an op around the digit exchange (one process per GPU) -----------------------------------------
-    def cc_mult_pre(self, plan, ins, row0s, st):
-        check(lib.lf_cc_mult_evk_pre(ctypes.byref(plan), ins, row0s, st), "lf_cc_mult_evk_pre")
+    def cc_mult_pre(self, plan, ins, row0s, st, which=3):
+        """which: 1 = the launch that reads the operands, 2 = the rest of the half (plan addresses only), 3 = both."""
+        check(lib.lf_cc_mult_evk_pre(ctypes.byref(plan), ins, row0s, which, st), "lf_cc_mult_evk_pre")
 
     def switch_key_pre(self, plan, c1, pinv, canonical):
         dev, st = _ds(c1)
@@ -357,17 +363,22 @@ class HipBackend:
         dev, st = _ds(digits)
         check(lib.lf_ks_plan_fwd(ctypes.byref(plan), _p(digits), first, count, 1 if relin else 0, st), "lf_ks_plan_fwd")
 
-    def cc_mult_post(self, plan, key, first_part, row_off, out):
-        dev, st = _ds(out)
+    def cc_mult_post(self, plan, key, first_part, row_off, out, which=3):
+        """which: 1 = inner product + inverse NTT (plan addresses + the key), 2 = the mod-down into `out`, 3 = both
+        (out may be None with which = 1)."""
+        dev, st = _ds(key)
         base, ps, cs = self._key_args(key, first_part)
-        check(lib.lf_cc_mult_evk_post(ctypes.byref(plan), base, ps, cs, row_off, self._kfmt(key), out.data_ptr(),
-                                      out.data_ptr() + out.stride(0) * 8, st), "lf_cc_mult_evk_post")
+        o0 = out.data_ptr() if out is not None else None
+        o1 = out.data_ptr() + out.stride(0) * 8 if out is not None else None
+        check(lib.lf_cc_mult_evk_post(ctypes.byref(plan), base, ps, cs, row_off, self._kfmt(key), o0, o1, which, st), "lf_cc_mult_evk_post")
 
-    def switch_key_post(self, plan, c0, pinv, canonical, key, first_part, row_off, out):
-        dev, st = _ds(out)
+    def switch_key_post(self, plan, c0, pinv, canonical, key, first_part, row_off, out, which=3):
+        dev, st = _ds(key)
         base, ps, cs = self._key_args(key, first_part)
-        check(lib.lf_switch_key_post(ctypes.byref(plan), _p(c0), pinv, 1 if canonical else 0, base, ps, cs, row_off, self._kfmt(key),
-                                     out.data_ptr(), out.data_ptr() + out.stride(0) * 8, st), "lf_switch_key_post")
+        o0 = out.data_ptr() if out is not None else None
+        o1 = out.data_ptr() + out.stride(0) * 8 if out is not None else None
+        check(lib.lf_switch_key_post(ctypes.byref(plan), _p(c0) if c0 is not None else None, pinv, 1 if canonical else 0, base, ps, cs,
+                                     row_off, self._kfmt(key), o0, o1, which, st), "lf_switch_key_post")
 
     def cc_mult_evk(self, plan, ins, row0s, key, first_part, row_off, out):
         """ins / row0s: ctypes arrays of 4 device pointers; out [2, ell, N]."""

@@ -91,6 +91,9 @@ class ckks_engine(EvaluatorOps):
         self._workspace = {}
         self._md_ready = set()
         self._lane = 0          # pipeline lane whose workspaces / stream the batched ops currently use
+        # a rank of a limb-sharded op replays its fixed-address launches from HIP graphs (see _sharded_segments); LF_ENGINE_GRAPHS=0
+        # keeps every launch eager
+        self.graph_sharded = os.environ.get("LF_ENGINE_GRAPHS", "1") != "0"
         self._lane_streams = {}
         self._check_kernel_limits()
 
@@ -707,9 +710,12 @@ class ckks_engine(EvaluatorOps):
             buf = self._ws("rescale_rows", (2 * len(cts), N), me)
             if owner == me:
                 i = loc_before.index(owner)
-                for k, ct in enumerate(cts):
-                    buf[2 * k].copy_(ct.data[0][i][0])
-                    buf[2 * k + 1].copy_(ct.data[1][i][0])
+                rows = [ct.data[comp][i][0] for ct in cts for comp in range(2)]
+                if hasattr(self.backend, "gather_rows") and len(rows) <= 8 and all(r.is_contiguous() and r.data_ptr() % 16 == 0 for r in rows):
+                    self.backend.gather_rows(rows, buf)      # one launch instead of a copy per row
+                else:
+                    for k, r in enumerate(rows):
+                        buf[k].copy_(r)
             self.comm.fanout_into(buf, owner, targets)   # one message per rank that still holds rows at the next level
             for k in range(len(cts)):
                 rows0.append([{d: buf[2 * k + comp] for d in targets if d in self.local_ids} for comp in range(2)])
@@ -832,6 +838,29 @@ class ckks_engine(EvaluatorOps):
         loc = self._loc(level)
         return loc[0] if len(loc) == 1 and self.len_devices[level] > 1 else None
 
+    def _sharded_schedule(self, level, d):
+        """The digit exchange of this rank at `level` as plain data: (digit buffer in storage order, pieces and peers of
+        comm.exchange_rows, [(buffer row, rows, state row)] of the digits this rank owns, its own runs [(first digit, digits)],
+        the foreign runs)."""
+        key = ("sched", level, d)
+        hit = self._tables.get(key)
+        if hit is None:
+            tabs = self._ks_tables(level)
+            groups, nparts = tabs["groups"], len(tabs["order"])
+            own_rows = [(row0, nrows, src_row) for owner, first, count, row0, nrows, src_row in groups if owner == d]
+            own_runs = [(first, count) for owner, first, count, _, _, _ in groups if owner == d]
+            foreign, run = [], None
+            for owner, first, count, _, _, _ in groups + [(d, nparts, 0, 0, 0, 0)]:
+                if owner == d:
+                    if run is not None:
+                        foreign.append(run)
+                        run = None
+                else:
+                    run = (first, count) if run is None else (run[0], run[1] + count)
+            hit = self._tables[key] = ([(g[0], g[3], g[4]) for g in groups], list(range(self.len_devices[level])), own_rows, own_runs,
+                                       foreign, tabs["total_rows"])
+        return hit
+
     def _sharded_forward(self, plan, d, level, relin):
         """The digit exchange between the halves of a sharded op: this rank's digits (plan.state) go out as one batch of
         point-to-point messages while it extends + transforms the digits it owns; the foreign runs follow the single wait."""
@@ -843,24 +872,134 @@ class ckks_engine(EvaluatorOps):
                 handle.wait()
             self.backend.plan_fwd(plan, dig, first, count, relin)
 
+    @staticmethod
+    def _capture(fn, device):
+        """fn() — launches on torch's current stream, fixed addresses only — as a HIP graph: one warm-up run on a side stream
+        (lazy tables), then the capture.  Returns the graph (replay() enqueues it on the current stream)."""
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        g = torch.cuda.CUDAGraph()
+        # thread_local: calls other threads make meanwhile (a communicator's proxy thread) do not invalidate the capture
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            fn()
+        return g
+
+    def _sharded_segments(self, kind, level, d, plan, kpack, first_part, row_off):
+        """The launches of a rank's half-ops that only touch the plan's scratch, the tables and the key, captured ONCE per
+        (op kind, level, lane, key pack) into three HIP graphs around the digit exchange:
+            a1  cc_mult: the rest of `pre` (tiled pass of the operands, x1 * y1, inverse NTT, digits); both kinds: this rank's
+                digit rows into the storage-order exchange buffer;
+            a2  extension + forward NTT of the digits it owns (runs beside the exchange);
+            c   the same for the foreign runs, then inner product + inverse NTT.
+        What stays eager is what reads or writes caller tensors: the first launch (operands) and the mod-down (result), and
+        the exchange itself.  A replay costs 6-8 us of host time whatever it holds (tools/graph_host_cost.py) against 4.4 us per
+        launch: a rank of a gold cc_mult over 8 GPUs enqueues in ~55 us instead of 140 (profiles/r05_host_overhead.txt).
+        None when the device is not a HIP device (the CPU checker backend)."""
+        dev = self.ntt.devices[d]
+        if not self.graph_sharded or not str(dev).startswith("cuda") or not hasattr(torch.cuda, "CUDAGraph"):
+            return None
+        fmt = getattr(kpack, "lf_key_format", 0)
+        key = ("sgraph", kind, level, d, self._lane, kpack.data_ptr(), tuple(kpack.stride()), fmt, first_part, row_off)
+        hit = self._tables.get(key)
+        if hit is not None:
+            return hit
+        relin = kind == "mult"
+        pieces, peers, own_rows, own_runs, foreign, total_rows = self._sharded_schedule(level, d)
+        N = self.ctx.N
+        state = self._ws("ks_state", (plan.ell, N), d)
+        buf = self._ws("ks_digits_all", (total_rows, N), d)
+        from .backend import _ds
+        be = self.backend
+
+        def a1():
+            if relin:
+                be.cc_mult_pre(plan, None, None, _ds(buf)[1], which=2)
+            for row0, nrows, src_row in own_rows:
+                buf[row0:row0 + nrows].copy_(state[src_row:src_row + nrows])
+
+        def a2():
+            for first, count in own_runs:
+                be.plan_fwd(plan, buf, first, count, relin)
+
+        def c():
+            for first, count in foreign:
+                be.plan_fwd(plan, buf, first, count, relin)
+            if relin:
+                be.cc_mult_post(plan, kpack, first_part, row_off, None, which=1)
+            else:
+                be.switch_key_post(plan, None, 0, False, kpack, first_part, row_off, None, which=1)
+
+        try:
+            hit = {"a1": self._capture(a1, dev) if (relin or own_rows) else None,
+                   "a2": self._capture(a2, dev) if own_runs else None, "c": self._capture(c, dev),
+                   "buf": buf, "pieces": pieces, "peers": peers, "keep": (state, kpack)}
+        except Exception as e:     # a capture that fails costs nothing but the replays: this rank goes on with eager launches
+            import warnings        # (the exchanges it issues are the same either way, so its peers are not affected)
+            warnings.warn(f"HIP-graph capture of the sharded op segments failed ({type(e).__name__}: {e}); eager launches from here on")
+            self.graph_sharded = False
+            torch.cuda.synchronize(dev)
+            return None
+        self._tables[key] = hit
+        return hit
+
+    def _sharded_exchange_replay(self, seg):
+        """a1 -> [exchange, asynchronous] -> a2 beside it -> wait -> c."""
+        if seg["a1"] is not None:
+            seg["a1"].replay()
+        handle = self.comm.exchange_rows(seg["buf"], seg["pieces"], seg["peers"])
+        if seg["a2"] is not None:
+            seg["a2"].replay()
+        handle.wait()
+        seg["c"].replay()
+
     def _cc_mult_sharded_native(self, a, b, evk, level, d):
         """cc_mult + relinearize of a limb-sharded level with the host side of this rank in three native calls + one per run
-        of digits (lf_cc_mult_evk_pre, lf_ks_plan_fwd, lf_cc_mult_evk_post) around the two exchanges.  Always completes: every
+        of digits (lf_cc_mult_evk_pre, lf_ks_plan_fwd, lf_cc_mult_evk_post) around the two exchanges — on a HIP device the
+        fixed-address launches among them replayed from three HIP graphs (_sharded_segments).  Always completes: every
         rank issues exactly one rescale exchange and one digit exchange per op, whatever the layout of its operands."""
         N = self.ctx.N
-        per_dev, round_at = self._rescale_operands([a, b])               # exchange 1: the dropped limb's rows
-        srcs, r0s = per_dev[d]
-        # never bail out from here: the exchange above has happened on every rank, and contiguity is a per-rank property —
-        # a rank that fell back to the step-by-step path would repeat it while its peers go on to the digit exchange
-        srcs, r0s = [t.contiguous() for t in srcs], [t.contiguous() for t in r0s]
+        # exchange 1: the dropped limb's rows of the four polynomials, one message from their owner (the lean form of
+        # _rescale_operands for ONE local device: pointers only, the per-level facts cached)
+        lvl = a.level
+        facts = self._tables.get(("rs_sharded", lvl, d))
+        if facts is None:
+            owner = self.ntt.p.rescaler_loc[lvl]
+            facts = self._tables[("rs_sharded", lvl, d)] = (owner, self._loc(lvl).index(d), list(range(self.len_devices[level])),
+                                                           self.ctx.q[self.ntt.p.destination_arrays[lvl][owner][0]] // 2)
+        owner, i, targets, round_at = facts
+        # never bail out from here: the exchange happens on every rank, and contiguity is a per-rank property — a rank that
+        # fell back to the step-by-step path would repeat it while its peers go on to the digit exchange
+        polys = [t if t.is_contiguous() else t.contiguous() for t in (a.data[0][i], a.data[1][i], b.data[0][i], b.data[1][i])]
+        rbuf = self._ws("rescale_rows", (4, N), d)
+        if owner == d:
+            if all(t.data_ptr() % 16 == 0 for t in polys):
+                self.backend.gather_rows([t[0] for t in polys], rbuf)      # one launch instead of a copy per row
+            else:
+                for k, t in enumerate(polys):
+                    rbuf[k].copy_(t[0])
+        self.comm.fanout_into(rbuf, owner, targets)
         plan, _, first_part, row_off = self._op_plan(level, d)
         assert plan.round_at == round_at
-        ins, row0s = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in srcs]), (ctypes.c_void_p * 4)(*[t.data_ptr() for t in r0s])
+        skip = N * 8 if owner == d else 0                                  # the owner's surviving rows start behind the dropped one
+        ins = (ctypes.c_void_p * 4)(*[t.data_ptr() + skip for t in polys])
+        r0 = rbuf.data_ptr()
+        row0s = (ctypes.c_void_p * 4)(r0, r0 + N * 8, r0 + 2 * N * 8, r0 + 3 * N * 8)
+        srcs = polys
         from .backend import _ds
-        self.backend.cc_mult_pre(plan, ins, row0s, _ds(srcs[0])[1])
-        self._sharded_forward(plan, d, level, True)                      # exchange 2: the digits
         kpack = self._key_pack(evk)[self._loc(0, special=True).index(d)]
         out = torch.empty((2, plan.ell, N), dtype=torch.int64, device=self.ntt.devices[d])
+        seg = self._sharded_segments("mult", level, d, plan, kpack, first_part, row_off)
+        if seg is not None:
+            self.backend.cc_mult_pre(plan, ins, row0s, _ds(srcs[0])[1], which=1)     # eager: reads the operands
+            self._sharded_exchange_replay(seg)                                      # exchange 2: the digits
+            self.backend.cc_mult_post(plan, kpack, first_part, row_off, out, which=2)   # eager: the mod-down writes the result
+            return self._new(([out[0]], [out[1]]), types.origins["ct"], level=level)
+        self.backend.cc_mult_pre(plan, ins, row0s, _ds(srcs[0])[1])
+        self._sharded_forward(plan, d, level, True)                      # exchange 2: the digits
         self.backend.cc_mult_post(plan, kpack, first_part, row_off, out)
         return self._new(([out[0]], [out[1]]), types.origins["ct"], level=level)
 
@@ -1280,11 +1419,16 @@ class ckks_engine(EvaluatorOps):
             if d is not None and ct.data[0][0].is_contiguous() and ct.data[1][0].is_contiguous():
                 # a limb-sharded level: digits, [exchange], extension + NTT per run, tail — the host side in native calls
                 plan, _, first_part, row_off = self._op_plan(level, d)
-                self.backend.switch_key_pre(plan, ct.data[1][0], pinv, canonical)
-                self._sharded_forward(plan, d, level, False)
                 kpack = self._key_pack(key)[self._loc(0, special=True).index(d)]
                 out = torch.empty((2, plan.ell, self.ctx.N), dtype=torch.int64, device=self.ntt.devices[d])
-                self.backend.switch_key_post(plan, ct.data[0][0], pinv, canonical, kpack, first_part, row_off, out)
+                self.backend.switch_key_pre(plan, ct.data[1][0], pinv, canonical)     # one launch, reads c1
+                seg = self._sharded_segments("switch", level, d, plan, kpack, first_part, row_off)
+                if seg is not None:
+                    self._sharded_exchange_replay(seg)
+                    self.backend.switch_key_post(plan, ct.data[0][0], pinv, canonical, kpack, first_part, row_off, out, which=2)
+                else:
+                    self._sharded_forward(plan, d, level, False)
+                    self.backend.switch_key_post(plan, ct.data[0][0], pinv, canonical, kpack, first_part, row_off, out)
                 return data_struct(data=([out[0]], [out[1]]), include_special=False, ntt_state=False,
                                    montgomery_state=ct.montgomery_state, origin=types.origins["ct"], level=level, hash=self.hash)
             c0, c1 = self.create_switcher(ct.data[1], key, level, addends=(ct.data[0], None), galois=(pinv, canonical))

@@ -20,7 +20,7 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(so, n), f"{n} declared in include/ckks_hip.h but not exported"
     assert sorted(_native.EXPORTED) == names, "python binding table out of sync with the header"
-    assert _native.lib.lf_abi_version() == 11     # pure host call, no HIP runtime use
+    assert _native.lib.lf_abi_version() == 12     # pure host call, no HIP runtime use
 
 
 def test_python_binding_passes_as_many_arguments_as_the_header_declares():

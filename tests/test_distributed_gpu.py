@@ -75,9 +75,16 @@ def _gold_worker(rank, world, port, outdir):
     a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
     evk = synth.key_switch_key(eng, 5)
     rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
-    for name, ct in (("cc_mult", eng.cc_mult(a, b, evk)), ("rotate", eng.rotate_single(a, rotk))):
-        for comp, shards in enumerate(ct.data):
-            np.save(os.path.join(outdir, f"{name}.{comp}.{rank}.npy"), shards[0].cpu().numpy())
+    # eager launches, then the same ops with this rank's fixed-address launches replayed from HIP graphs (the default): the
+    # first graphed call captures, the second and third replay
+    for mode, graphs, reps in (("eager", False, 1), ("graph", True, 3)):
+        eng.graph_sharded = graphs
+        for _ in range(reps):
+            res = (("cc_mult", eng.cc_mult(a, b, evk)), ("rotate", eng.rotate_single(a, rotk)))
+        for name, ct in res:
+            for comp, shards in enumerate(ct.data):
+                np.save(os.path.join(outdir, f"{mode}.{name}.{comp}.{rank}.npy"), shards[0].cpu().numpy())
+    assert any(k[0] == "sgraph" for k in eng._tables if isinstance(k, tuple)), "the graphed path was not taken"
     dist.barrier()
     dist.destroy_process_group()
 
@@ -100,7 +107,8 @@ def test_two_ranks_gold_fused_exchange_equals_one_process_two_devices():
     for name, ct in (("cc_mult", eng.cc_mult(a, b, evk)), ("rotate", eng.rotate_single(a, rotk))):
         for comp, shards in enumerate(ct.data):
             for rank, t in enumerate(shards):
-                assert (got[f"{name}.{comp}.{rank}.npy"] == t.cpu().numpy()).all(), (name, comp, rank)
+                for mode in ("eager", "graph"):     # graph = third call: captured segments replayed around the live exchange
+                    assert (got[f"{mode}.{name}.{comp}.{rank}.npy"] == t.cpu().numpy()).all(), (mode, name, comp, rank)
 
 
 # ---- a level where a rank has run out of rows (the alive ranks must not wait for it) -----------------

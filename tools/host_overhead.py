@@ -49,28 +49,7 @@ for preset in ("silver", "gold"):
 # ---- a rank of a limb-sharded op: host time to enqueue it, exchanges stubbed out ------------------------------------
 # (no second GPU here: a stand-in communicator whose exchanges return at once — the words a rank would receive are
 # whatever its buffers hold, so the RESULTS are meaningless; the launches and the Python around them are the real ones)
-class NullComm:
-    def __init__(self, world, rank=0, device="cuda:0"):
-        self.world_size, self.rank, self.local_device, self.group, self.backend_name = world, rank, device, None, "null"
-
-    class _Done:
-        def wait(self):
-            pass
-
-    def broadcast(self, tensor, src, shape, device):
-        return tensor if tensor is not None else torch.zeros(shape, dtype=torch.int64, device=device)
-
-    def exchange_rows(self, buf, pieces, peers):
-        return self._Done()
-
-    def fanout_into(self, buf, src, peers):
-        pass
-
-    def broadcast_int(self, value, src=0):
-        return value
-
-    def barrier(self):
-        pass
+from tools.host_overhead_null import NullComm  # noqa: E402
 
 
 for world in (2, 8):
@@ -79,7 +58,9 @@ for world in (2, 8):
     a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
     evk = synth.key_switch_key(eng, 5)
     rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
-    for name, fn in (("cc_mult", lambda: eng.cc_mult(a, b, evk)), ("rotate", lambda: eng.rotate_single(a, rotk))):
+    for graphs in (False, True):
+      eng.graph_sharded = graphs
+      for name, fn in (("cc_mult", lambda: eng.cc_mult(a, b, evk)), ("rotate", lambda: eng.rotate_single(a, rotk))):
         for _ in range(20):
             fn()
         torch.cuda.synchronize()
@@ -93,6 +74,16 @@ for world in (2, 8):
             torch.cuda.synchronize()
         host.sort()
         rows = len(eng.ntt.p.destination_arrays_with_special[0][0])
-        print(f"gold {name}, rank 0 of {world} (limb-sharded, {rows} of 39 rows, exchanges stubbed): host enqueue {1e6 * host[len(host) // 2]:.1f} us/op")
+        dev_t = []
+        for rep in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            dev_t.append((time.perf_counter() - t0) / n)
+        dev_t.sort()
+        print(f"gold {name}, rank 0 of {world} (limb-sharded, {rows} of 39 rows, exchanges stubbed), fixed-address launches "
+              f"{'replayed from 3 HIP graphs' if graphs else 'eager'}: host enqueue {1e6 * host[len(host) // 2]:.1f} us/op, device-paced {1e6 * dev_t[2]:.1f} us/op")
     del eng
     torch.cuda.empty_cache()
