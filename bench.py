@@ -101,6 +101,22 @@ def physical_cores():
     return out or [0]
 
 
+def cpu_quota_cores():
+    """CPU bandwidth limit of this container in cores (cgroup v2 cpu.max / v1 cfs quota), None when unlimited or unreadable:
+    more runnable threads than this only take turns."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
+
+
 def cpu_baseline(ctx, rows_idx, batch_cap=64, budget_s=12.0):
     """The oracle's NTT on the host cores over a [batch*30, N] stack of the same workload.  Threads = min(rows, physical
     cores), each pinned to its own core (oracle.pin_threads), static schedule, and every row — data and twiddles — first
@@ -111,6 +127,9 @@ def cpu_baseline(ctx, rows_idx, batch_cap=64, budget_s=12.0):
     from oracle import oracle as orc
     L = len(rows_idx)
     cpus = physical_cores()
+    quota = cpu_quota_cores()
+    if quota is not None and quota < len(cpus):     # a container limited to fewer CPU-seconds per second than it can see cores
+        cpus = cpus[:max(1, int(quota))]
     cores = len(cpus)
     batch = next((b for b in range(1, batch_cap + 1) if b * L >= cores and (b * L) % cores == 0), batch_cap)
     n = L * batch
@@ -138,7 +157,8 @@ def cpu_baseline(ctx, rows_idx, batch_cap=64, budget_s=12.0):
         dt = (time.time() - t0) / reps
         out = {"value": batch / dt, "unit": "poly-NTT(L=30,logN=16)/s", "cores": threads, "kind": "port",
                "sample": f"{reps} x forward NTT of {batch} polys x {L} limbs, N=65536, C oracle, OpenMP static over limb rows, "
-                         f"{threads} threads pinned one per physical core ({cores} available, {unpinned} not pinned), "
+                         f"{threads} threads pinned one per physical core ({cores} usable: {len(physical_cores())} visible, "
+                         f"cgroup CPU quota {quota if quota is not None else 'none'}; {unpinned} not pinned), "
                          "rows and twiddles first-touched by their thread"}
         # the same kernel on ONE core: one polynomial's 30 limbs, a single OpenMP thread
         orc.omp_threads(1)
@@ -278,7 +298,7 @@ def engine_rates(dev, quick):
         torch.cuda.synchronize()
         ms = event_time_ms(lambda: eng.cc_mult_batch(pairs, evk), max(2, n // 8))
         out[f"cc_mult_evk_{name}_batch{nb}_ops_per_s"] = nb * 1e3 / ms
-        roof[f"cc_mult_evk_{name}_batch{nb}"] = op_roofline(eng, "cc_mult", nb * 1e3 / ms, None)
+        roof[f"cc_mult_evk_{name}_batch{nb}"] = op_roofline(eng, "cc_mult", nb * 1e3 / ms, None, pmc.get(f"{name}_cc_mult_batch"))
         if name == "gold":
             # BASELINE configs[4] at its stated size: 64 level-0 ciphertexts (seeds 100..163) under one rotation key
             cts64 = cts + [synth.ciphertext(eng, 100 + i, 0) for i in range(nb, 64)]
@@ -286,7 +306,7 @@ def engine_rates(dev, quick):
             torch.cuda.synchronize()
             ms = event_time_ms(lambda: eng.rotate_single_batch(cts64, rotk), 3)
             out["rotate_single_gold_batch64_rotations_per_s"] = 64 * 1e3 / ms
-            roof["rotate_single_gold_batch64"] = op_roofline(eng, "rotate", 64 * 1e3 / ms, None)
+            roof["rotate_single_gold_batch64"] = op_roofline(eng, "rotate", 64 * 1e3 / ms, None, pmc.get("gold_rotate_batch"))
             del cts64
         del cts, pairs
         del eng, a, b, evk, rotk
@@ -325,8 +345,12 @@ def ntt_rates_preset(name, dev, batch, iters=20):
         check(lib.lf_intt(x.data_ptr(), batch, L, logN, ipsi.data_ptr(), idp, q_host.ctypes.data, ninv.data_ptr(), 2, 0, q2.data_ptr(),
                           ql.data_ptr(), qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), d, st), "lf_intt")
 
-    # round trip first: intt_exit_reduce(ntt(x)) is x's canonical residues (the transforms are exact inverses modulo q)
-    fwd(); inv()
+    # round trip first: intt_exit_reduce(enter_ntt(x)) is x's canonical residues (nctx.py:554-579; the plain `ntt` timed below
+    # skips the Montgomery entry, so its inverse chain would return x R^-1)
+    rs = ntt.Rs[0]
+    check(lib.lf_ntt(x.data_ptr(), batch, L, logN, psi.data_ptr(), dp, q_host.ctypes.data, rs.data_ptr(), 0, q2.data_ptr(), ql.data_ptr(),
+                     qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), d, st), "lf_ntt (enter_ntt)")
+    inv()
     torch.cuda.synchronize()
     qcol = torch.tensor(ctx.q, dtype=torch.int64, device=dev)[:, None]
     ok = bool(torch.equal(x[0], one % qcol))
@@ -627,56 +651,66 @@ def multi_gpu_rates(dev, world, rank, out, sharded=True, grp=None, comm_block=No
         out["multi_gpu_replicas_error"] = f"{type(e).__name__}: {e}"[:300]
     if not sharded:
         return
+    from liberate_fhe_amd.fhe.comm import DistComm
     try:
-        from liberate_fhe_amd.fhe.comm import DistComm
         if grp is None:
             grp, comm_block = comm_prepare(dev, world, rank, torch.cuda.current_device())
-        eng = ckks_engine(devices=[dev], comm=DistComm(group=grp, local_device=dev), **params)
-        if comm_block is not None:
-            comm_block["key_switch_batch_level0"] = link_bytes(eng, 0)
-            comm_block["key_switch_batch_level10"] = link_bytes(eng, 10)
-        evk = synth.key_switch_key(eng, 5)
-        rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
-        # parity gate (every rank, every row it holds)
-        bad = 1 if want is None else 0
-        if want is not None:
-            for ref, ct in zip(want, parity_ops(eng, evk, rotk)):
-                for prime, rows in _natural(eng, ct).items():
-                    for comp in range(2):
-                        if not torch.equal(rows[comp], ref[prime][comp]):
-                            bad += 1
-        t = torch.tensor([bad], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=grp)
-        if int(t.item()):
-            out["multi_gpu_limb_sharded_error"] = (f"parity gate: {int(t.item())} row(s) of the limb-sharded results differ from the "
-                                                   "unsharded engine (or no reference was computed); rates withheld")
-            return
-        out["limb_sharded_parity"] = ("bit-exact vs the unsharded engine on every rank: cc_mult 0->1, rotate at 0, cc_mult 9->10, "
-                                      "two rotations at level 10 (at 8 ranks the last one holds no rows there)")
-        a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
-        for _ in range(20):
-            eng.cc_mult(a, b, evk)
-        torch.cuda.synchronize()
-        dist.barrier(group=grp)
-        ms = _max_over_ranks(event_time_ms(lambda: eng.cc_mult(a, b, evk), 40), dev)
-        out["cc_mult_evk_gold_limb_sharded_ops_per_s"] = 1e3 / ms
-        for _ in range(10):
-            eng.rotate_single(a, rotk)
-        torch.cuda.synchronize()
-        dist.barrier(group=grp)
-        ms = _max_over_ranks(event_time_ms(lambda: eng.rotate_single(a, rotk), 40), dev)
-        out["rotate_single_gold_limb_sharded_ops_per_s"] = 1e3 / ms
-        out["limb_sharded_rows_per_rank_level0"] = [len(d) for d in eng.ntt.p.destination_arrays_with_special[0]]
-        # host time this rank spends ENQUEUEING one sharded op (the margin before the host, not the GPU, paces a rank)
-        if comm_block is not None:
-            mine = torch.tensor([host_enqueue_us(lambda: eng.cc_mult(a, b, evk)), host_enqueue_us(lambda: eng.rotate_single(a, rotk))],
-                                dtype=torch.float64, device=dev)
-            every = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(every, mine, group=grp)
-            comm_block["host_enqueue_us_per_sharded_cc_mult_by_rank"] = [round(float(t[0]), 1) for t in every]
-            comm_block["host_enqueue_us_per_sharded_rotate_by_rank"] = [round(float(t[1]), 1) for t in every]
-    except Exception as e:   # the headline line must survive a failure of this leg
+    except Exception as e:
         out["multi_gpu_limb_sharded_error"] = f"{type(e).__name__}: {e}"[:300]
+        return
+    # both forms of the key-switch digit exchange in one run, the parity gate in front of each: one batch of point-to-point
+    # messages between the ranks that hold rows (the default), and ONE padded all-gather over the group
+    for mode, suffix in (("p2p", ""), ("allgather", "_allgather")):
+        try:
+            eng = ckks_engine(devices=[dev], comm=DistComm(group=grp, local_device=dev, exchange=mode), **params)
+            if comm_block is not None and mode == "p2p":
+                comm_block["key_switch_batch_level0"] = link_bytes(eng, 0)
+                comm_block["key_switch_batch_level10"] = link_bytes(eng, 10)
+            evk = synth.key_switch_key(eng, 5)
+            rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
+            # parity gate (every rank, every row it holds)
+            bad = 1 if want is None else 0
+            if want is not None:
+                for ref, ct in zip(want, parity_ops(eng, evk, rotk)):
+                    for prime, rows in _natural(eng, ct).items():
+                        for comp in range(2):
+                            if not torch.equal(rows[comp], ref[prime][comp]):
+                                bad += 1
+            t = torch.tensor([bad], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=grp)
+            if int(t.item()):
+                out[f"multi_gpu_limb_sharded{suffix}_error"] = (f"parity gate: {int(t.item())} row(s) of the limb-sharded results differ from the "
+                                                               "unsharded engine (or no reference was computed); rates withheld")
+                continue
+            out[f"limb_sharded{suffix}_parity"] = ("bit-exact vs the unsharded engine on every rank: cc_mult 0->1, rotate at 0, cc_mult 9->10, "
+                                                  "two rotations at level 10 (at 8 ranks the last one holds no rows there)")
+            a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
+            for _ in range(20):
+                eng.cc_mult(a, b, evk)
+            torch.cuda.synchronize()
+            dist.barrier(group=grp)
+            ms = _max_over_ranks(event_time_ms(lambda: eng.cc_mult(a, b, evk), 40), dev)
+            out[f"cc_mult_evk_gold_limb_sharded{suffix}_ops_per_s"] = 1e3 / ms
+            for _ in range(10):
+                eng.rotate_single(a, rotk)
+            torch.cuda.synchronize()
+            dist.barrier(group=grp)
+            ms = _max_over_ranks(event_time_ms(lambda: eng.rotate_single(a, rotk), 40), dev)
+            out[f"rotate_single_gold_limb_sharded{suffix}_ops_per_s"] = 1e3 / ms
+            out["limb_sharded_rows_per_rank_level0"] = [len(d) for d in eng.ntt.p.destination_arrays_with_special[0]]
+            out[f"limb_sharded{suffix}_hip_graphs"] = bool(eng.graph_sharded)
+            # host time this rank spends ENQUEUEING one sharded op (the margin before the host, not the GPU, paces a rank)
+            if comm_block is not None:
+                mine = torch.tensor([host_enqueue_us(lambda: eng.cc_mult(a, b, evk)), host_enqueue_us(lambda: eng.rotate_single(a, rotk))],
+                                    dtype=torch.float64, device=dev)
+                every = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(every, mine, group=grp)
+                comm_block[f"host_enqueue_us_per_sharded_cc_mult_by_rank{suffix}"] = [round(float(t[0]), 1) for t in every]
+                comm_block[f"host_enqueue_us_per_sharded_rotate_by_rank{suffix}"] = [round(float(t[1]), 1) for t in every]
+            del eng, evk, rotk, a, b
+            torch.cuda.empty_cache()
+        except Exception as e:   # the headline line must survive a failure of this leg
+            out[f"multi_gpu_limb_sharded{suffix}_error"] = f"{type(e).__name__}: {e}"[:300]
 
 
 def spawn_ranks(n):

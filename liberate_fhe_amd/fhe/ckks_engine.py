@@ -166,7 +166,12 @@ class ckks_engine(EvaluatorOps):
         return ws, one
 
     def _ws(self, key, shape, dev_id):
-        """Reusable scratch tensor (never returned to the caller); one set per pipeline lane (see _lanes)."""
+        """Reusable scratch tensor (never returned to the caller); one set per pipeline lane (see _lanes).
+        STREAMS: the scratch belongs to the engine, not to a stream — the reference allocates its intermediates per call, this
+        engine reuses them, ordered only by the stream its ops are enqueued on.  Every op of one engine must therefore be
+        enqueued on ONE torch stream per device (the current stream at the time of the call; the batched methods fork and
+        join their own lanes).  A caller that alternates streams between ops of the same engine has to order them itself
+        (stream.wait_stream) or use one engine per stream; ops of DIFFERENT engines are independent."""
         k = (key, tuple(shape), dev_id, self._lane)
         t = self._workspace.get(k)
         if t is None:
@@ -425,7 +430,8 @@ class ckks_engine(EvaluatorOps):
     # ---- packed-key cache --------------------------------------------------------------------------------------
     # Identity of a key = its first tensor (part 0, component b, first local device): data_structs and lists cannot
     # be weakly referenced, tensors can.  An entry dies with that tensor (weakref.finalize), so a key the caller
-    # drops releases its pack (gold: 429 MB per key) and a recycled id() can never alias a dead entry.
+    # drops releases its pack (gold: 429 MB per key, and as much again for the planes copy of the fused path) and a
+    # recycled id() can never alias a dead entry.
     @staticmethod
     def _key_anchor(ksk):
         return ksk.data[0].data[0][0]
@@ -491,9 +497,21 @@ class ckks_engine(EvaluatorOps):
         return self._remember_pack(ksk, packs, own=False)
 
     def release_key(self, ksk):
-        """Drop the packed copy of a foreign key-switch key now (it is also dropped when the key's tensors die).
-        Keys made by this engine are views of their pack and hold no second copy."""
-        self._key_packs.pop(id(self._key_anchor(ksk)), None)
+        """Drop what the engine holds for a key-switch key beyond the key's own tensors, now: the packed copy of a foreign
+        key; for a key made by this engine — whose tensors are views of its raw pack — the PLANES copy the fused key switch
+        reads (a second tensor of the raw pack's size: gold ~ 430 MB per key, a Galois key set 15 x that).  Either is
+        rebuilt on the key's next use and dropped when the key's tensors die."""
+        hit = self._key_packs.get(id(self._key_anchor(ksk)))
+        if hit is not None and hit.get("own"):
+            hit.pop("planes", None)
+            hit.pop("planes_ver", None)
+        else:
+            self._key_packs.pop(id(self._key_anchor(ksk)), None)
+
+    def invalidate_key(self, ksk):
+        """Tell the engine that a key's words were changed behind torch's back (a write through a raw pointer does not move
+        the version counters the engine watches): its planes copy / packed copy is rebuilt on the next use."""
+        self.release_key(ksk)
 
     def _check_kernel_limits(self):
         """The fused kernels reserve registers for at most lf_limits() digit limbs / special primes / rows; a

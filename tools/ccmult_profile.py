@@ -16,8 +16,13 @@ eng = ckks_engine(**{**presets.params[name], "devices": ["cuda:0"]})
 a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
 evk = synth.key_switch_key(eng, 5)
 rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
-fn = (lambda: eng.cc_mult(a, b, evk)) if op == "cc_mult" else (lambda: eng.rotate_single(a, rotk))
-for _ in range(40): fn()   # steady-state clocks (tools/warm_probe.py)
+if op in ("rotate_batch", "cc_mult_batch"):     # 16 ciphertexts under one key: 4 groups of 4 per key-switch launch set, two lanes
+    cts = [synth.ciphertext(eng, 100 + i, 0) for i in range(16)]
+    pairs = [(cts[i], cts[(i + 1) % 16]) for i in range(16)]
+    fn = (lambda: eng.rotate_single_batch(cts, rotk)) if op == "rotate_batch" else (lambda: eng.cc_mult_batch(pairs, evk))
+else:
+    fn = (lambda: eng.cc_mult(a, b, evk)) if op == "cc_mult" else (lambda: eng.rotate_single(a, rotk))
+for _ in range(5 if op.endswith('_batch') else 40): fn()   # steady-state clocks (tools/warm_probe.py)
 torch.cuda.synchronize()
 
 
@@ -31,10 +36,11 @@ def marker():
 
 
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-n = 10
+n = 3 if op.endswith('_batch') else 10
 if mark: marker()
 e0.record()
 for _ in range(n): fn()
 e1.record(); torch.cuda.synchronize()
 if mark: marker()
-print(f"{name} {op}: {e0.elapsed_time(e1)/n*1e3:.1f} us/op  {n/e0.elapsed_time(e1)*1e3:.1f} ops/s")
+per = 16 if op.endswith("_batch") else 1
+print(f"{name} {op}: {e0.elapsed_time(e1)/n/per*1e3:.1f} us/op  {n*per/e0.elapsed_time(e1)*1e3:.1f} ops/s")

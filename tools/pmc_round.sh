@@ -2,7 +2,7 @@
 # PMC passes (separate runs, as the guide prescribes) over the bench step and over gold / silver cc_mult:
 #   tools/pmc_round.sh <tag>      (on the GPU box; then tools/summarize_round.py <tag> -> profiles/)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out; mkdir -p $OUT; REPO=$PWD
 # build ONCE, unprofiled: a profiled process must never spawn the compiler (the profiler's preload would ride along into hipcc,
@@ -24,6 +24,14 @@ for P in gold silver; do
     run ${T}_write WRITE_SIZE -- $C
     run ${T}_valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY -- $C
   done
+done
+# batched groups under one key (nct = 4 per key-switch launch set), gold: the traffic per ciphertext of BASELINE configs[4]
+for OP in rotate_batch cc_mult_batch; do
+  C="$REPO/tools/ccmult_profile.py gold $OP --mark"
+  T=gold_$OP
+  run ${T}_fetch FETCH_SIZE -- $C
+  run ${T}_write WRITE_SIZE -- $C
+  run ${T}_valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY -- $C
 done
 # kernel stats of the bench command itself (the file the roofline numbers are checked against)
 cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o stats -- python3 $REPO/bench.py --no-extra > $OUT/prof_$TAG.log 2>&1; cd $REPO

@@ -13,7 +13,7 @@ import collections, json, os, sqlite3, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, out = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 sys.path.insert(0, ROOT)
 import __graft_entry__ as _g   # noqa: E402
 DIGEST = _g.library_digest()   # the sources these counters were taken at: bench.py drops the figures when the build differs
@@ -120,6 +120,30 @@ for preset in ("gold", "silver"):
             total_bytes += (rd + wr) * per_op
         eo.append(f"# HBM bytes per op (sum over its launches): {total_bytes / 1e6:.1f} MB")
         eo_json[f"{preset}_{op}"] = {"kernels": kernels, "bytes_per_op": total_bytes}
+# batched groups (gold, 16 ciphertexts under one key = 4 launch sets of nct = 4): bytes per CIPHERTEXT
+for op, tag in (("rotate_batch", "gold_rotate_batch"), ("cc_mult_batch", "gold_cc_mult_batch")):
+    try:
+        f, w, v = counters(f"{tag}_fetch"), counters(f"{tag}_write"), counters(f"{tag}_valu")
+    except Exception as e:
+        eo.append(f"## gold {op}: missing ({e})")
+        continue
+    eo += ["", f"## gold {op}: 16 ciphertexts under one key, groups of 4 per key-switch launch set (launches per GROUP in the last column)"]
+    groups = max((d["n"] for k, d in v.items() if k[0].startswith("ks_inner2_kernel")), default=0)   # one inner product per group
+    kernels, total_bytes = [], 0.0
+    for key in sorted(v, key=lambda k: -v[k]["us"] * v[k]["n"]):
+        if not (key[0].startswith(("ntt_", "ks_", "tensor", "rescale"))) or key not in f or key not in w:
+            continue
+        rd, wr, us = 2 * f[key]["FETCH_SIZE"] * 1024, w[key]["WRITE_SIZE"] * 1024, v[key]["us"]
+        busy = v[key]["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (v[key]["SQ_BUSY_CU_CYCLES"] / 256)
+        per_grp = v[key]["n"] / groups if groups else 1
+        if per_grp < 0.5:
+            continue
+        eo.append(f"{key[0]}/g{key[1]} | {us:7.1f} | {rd / 1e6:7.1f} | {wr / 1e6:7.1f} | {(rd + wr) / us / 1e6:5.2f} | {v[key]['SQ_INSTS_VALU']:.4g} | {busy:5.3f} | {per_grp:.2f}")
+        kernels.append({"kernel": key[0], "grid": key[1], "us": us, "per_op": per_grp / 4, "read_MB": rd / 1e6, "write_MB": wr / 1e6,
+                        "moved_TBps": (rd + wr) / us / 1e6, "valu_busy": busy, "valu_wave_instr": v[key]["SQ_INSTS_VALU"]})
+        total_bytes += (rd + wr) * per_grp / 4
+    eo.append(f"# HBM bytes per ciphertext (sum over a group's launches / 4): {total_bytes / 1e6:.1f} MB")
+    eo_json[f"gold_{op}"] = {"kernels": kernels, "bytes_per_op": total_bytes}
 open(os.path.join(out, f"{TAG}_engine_ops_pmc.txt"), "w").write("\n".join(eo) + "\n")
 json.dump(eo_json, open(os.path.join(out, f"{TAG}_engine_ops_pmc.json"), "w"), indent=1)
 print("\n".join(eo))
