@@ -35,7 +35,7 @@ extern "C" {
 #define LF_ERR_ARG 10001
 
 /* Library probe: returns the ABI version (currently LF_ABI_VERSION; __graft_entry__.build() asserts it). */
-#define LF_ABI_VERSION 12
+#define LF_ABI_VERSION 13
 int lf_abi_version(void);
 
 /* Compile-time capacities of the fused kernels, so that callers can refuse a parameter set BEFORE any launch
@@ -488,6 +488,34 @@ int lf_discrete_gaussian(int64_t *rand_bytes, int64_t n, const uint64_t *btree_h
 /* randround_cuda.randround (randround_cuda_kernel.cu:8-56): rand_bytes[i] = sign(c) * (floor|c| +
  * [rand_bytes[i] < rn(frac|c| * 2^32)]), c = coef[i]; rand_bytes holds 32-bit random words. */
 int lf_randround(const double *coef, int64_t *rand_bytes, int64_t n, int device, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The reference's 30-bit / int32 word mode of the same 15 functions (ckks_context.py:213-216 buffer_bit_length = 30:
+ * R = 2^30, 15-bit halves ql / qh / kl / kh, 28-bit message primes; K.cu:141, 223, 339 dispatch the kernel templates for
+ * int32 as well).  No preset, test or example of the reference selects it; it is served for the completeness of the
+ * boundary (csrc/ckks_w30.hip: one plain launch per step of the reference's own chain, its exact lazy words), the fused
+ * engine entries above are 62-bit only.  Arguments as their lf_* counterparts, words and per-row vectors int32;
+ * psi_br / ipsi_br = the compact [rows][N] tables in Montgomery form (R = 2^30).
+ *   mont_mult, mont_enter, mont_redc (ntt.cpp:120-163, 248-263); reduce_2q, make_signed, make_unsigned, tile_unsigned,
+ *   mont_add, mont_sub (347-419); lf30_ntt: Rs = NULL ntt, Rs != NULL enter_ntt (166-216); lf30_intt: tail 0 intt, 1 intt_exit,
+ *   2 intt_exit_reduce, 3 intt_exit_reduce_signed (219-345).
+ * ---------------------------------------------------------------------------------------------- */
+int lf30_mont_mult(const int32_t *a, const int32_t *b, int32_t *c, int rows, int64_t N, const int32_t *ql, const int32_t *qh,
+                   const int32_t *kl, const int32_t *kh, int device, void *stream);
+int lf30_mont_enter(int32_t *a, const int32_t *Rs, int rows, int64_t N, const int32_t *ql, const int32_t *qh, const int32_t *kl,
+                    const int32_t *kh, int device, void *stream);
+int lf30_mont_redc(int32_t *a, int rows, int64_t N, const int32_t *ql, const int32_t *qh, const int32_t *kl, const int32_t *kh,
+                   int device, void *stream);
+int lf30_reduce_2q(int32_t *a, int rows, int64_t N, const int32_t *_2q, int device, void *stream);
+int lf30_make_signed(int32_t *a, int rows, int64_t N, const int32_t *_2q, int device, void *stream);
+int lf30_make_unsigned(int32_t *a, int rows, int64_t N, const int32_t *_2q, int device, void *stream);
+int lf30_tile_unsigned(const int32_t *a, int32_t *dst, int rows, int64_t N, const int32_t *_2q, int device, void *stream);
+int lf30_mont_add(const int32_t *a, const int32_t *b, int32_t *c, int rows, int64_t N, const int32_t *_2q, int device, void *stream);
+int lf30_mont_sub(const int32_t *a, const int32_t *b, int32_t *c, int rows, int64_t N, const int32_t *_2q, int device, void *stream);
+int lf30_ntt(int32_t *a, int batch, int rows, int logN, const int32_t *psi_br, const int32_t *Rs, const int32_t *_2q,
+             const int32_t *ql, const int32_t *qh, const int32_t *kl, const int32_t *kh, int device, void *stream);
+int lf30_intt(int32_t *a, int batch, int rows, int logN, const int32_t *ipsi_br, const int32_t *Ninv, int tail, const int32_t *_2q,
+              const int32_t *ql, const int32_t *qh, const int32_t *kl, const int32_t *kh, int device, void *stream);
 
 #ifdef __cplusplus
 }

@@ -101,6 +101,21 @@ _SIGNATURES["lf_ks_plan_fwd"] = [_PL, _P, _I, _I, _I, _P]
 _SIGNATURES["lf_cc_mult_evk_post"] = [_PL, _P, _L, _L, _L, _I, _P, _P, _I, _P]
 _SIGNATURES["lf_switch_key_post"] = [_PL, _P, _L, _I, _P, _L, _L, _L, _I, _P, _P, _I, _P]
 
+# the 30-bit / int32 word mode of the ntt_cuda surface (csrc/ckks_w30.hip)
+_SIGNATURES.update({
+    "lf30_mont_mult": [_P, _P, _P, _I, _L, _P, _P, _P, _P, _I, _P],
+    "lf30_mont_enter": [_P, _P, _I, _L, _P, _P, _P, _P, _I, _P],
+    "lf30_mont_redc": [_P, _I, _L, _P, _P, _P, _P, _I, _P],
+    "lf30_reduce_2q": [_P, _I, _L, _P, _I, _P],
+    "lf30_make_signed": [_P, _I, _L, _P, _I, _P],
+    "lf30_make_unsigned": [_P, _I, _L, _P, _I, _P],
+    "lf30_tile_unsigned": [_P, _P, _I, _L, _P, _I, _P],
+    "lf30_mont_add": [_P, _P, _P, _I, _L, _P, _I, _P],
+    "lf30_mont_sub": [_P, _P, _P, _I, _L, _P, _I, _P],
+    "lf30_ntt": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P],
+    "lf30_intt": [_P, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P],
+})
+
 for _name, _args in _SIGNATURES.items():
     _fn = getattr(lib, _name)
     _fn.argtypes = _args

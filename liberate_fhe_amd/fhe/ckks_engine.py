@@ -53,6 +53,13 @@ class ckks_engine(EvaluatorOps):
         self.norm = norm
         self.version = VERSION
         self.ctx = ckks_context(**ctx_params)
+        if self.ctx.buffer_bit_length != 62:
+            # the 30-bit word mode is served below the engine: ckks_context, ntt_context and the 15 ntt_cuda functions
+            # (csrc/ckks_w30.hip).  The reference's own engine constructs in that mode but cannot generate a key in it — its
+            # samplers hand int64 words to kernels dispatched on int32 constants (ckks_engine.py:355) — so there is no
+            # reference behaviour to reproduce above the boundary.
+            raise ValueError("ckks_engine: the engine's ops exist for buffer_bit_length = 62; the 30-bit word mode is served by "
+                             "ckks_context / ntt_context / ntt_cuda only (as far as the reference itself works in it)")
 
         if comm is not None and comm.world_size > 1:
             local = devices[0] if devices else comm.local_device

@@ -92,10 +92,10 @@ class ckks_context:
     ):
         # cache_folder / read_cache / save_cache are accepted for call compatibility; every table
         # here is regenerated in about a second, so nothing is written to disk.
-        if buffer_bit_length != 62:
-            # The reference also has a 30-bit/int32 word mode that no preset uses; the HIP
-            # kernels are 62-bit/int64 only.
+        if buffer_bit_length not in (30, 62):
             raise errors.NotFindBufferBitLength(buffer_bit_length)
+        # 30: the reference's int32 word mode (ckks_context.py:213-216; R = 2^30, 28-bit message primes).  The contexts and
+        # the 15 ntt_cuda functions serve it (csrc/ckks_w30.hip); the engine's fused ops are 62-bit only.
 
         self.generation_string = (
             f"{buffer_bit_length}_{scale_bits}_{logN}_{num_scales}_"
@@ -113,8 +113,8 @@ class ckks_context:
         self.sigma = sigma
         self.uniform_ternary_secret = uniform_ternary_secret
         self.secret_key_sampling_method = "uniform ternary" if uniform_ternary_secret else "sparse ternary"
-        self.torch_dtype = torch.int64
-        self.numpy_dtype = np.int64
+        self.torch_dtype = {30: torch.int32, 62: torch.int64}[buffer_bit_length]
+        self.numpy_dtype = {30: np.int32, 62: np.int64}[buffer_bit_length]
         self.N = 1 << logN
         self.message_bits = buffer_bit_length - 2
 

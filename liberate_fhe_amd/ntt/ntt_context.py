@@ -79,7 +79,7 @@ class ntt_context:
     # ---------------------------------------------------------------------------------------------
     def partition_variable(self, variable):
         """Rows of `variable` (one per prime) gathered per GPU in that GPU's level-0 row order."""
-        v = np.asarray(variable, dtype=np.int64)
+        v = np.asarray(variable, dtype=getattr(self.ctx, "numpy_dtype", np.int64))   # int32 in the reference's 30-bit word mode
         out = []
         for dev_id, (rows, dev) in enumerate(zip(self.p.d_special, self.devices)):
             rows = rows if dev_id in self.local_ids else []

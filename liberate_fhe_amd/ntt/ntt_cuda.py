@@ -39,11 +39,23 @@ def _dev_stream(t: torch.Tensor):
 
 
 def _ptr(t: torch.Tensor):
-    if t.dtype != torch.int64:
-        raise TypeError(f"ntt_cuda: int64 tensors only (62-bit word mode), got {t.dtype}")
+    if t.dtype not in (torch.int64, torch.int32):
+        raise TypeError(f"ntt_cuda: int64 tensors (62-bit word mode) or int32 tensors (30-bit word mode), got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError("ntt_cuda: tensor must be contiguous")
     return t.data_ptr()
+
+
+def _w30(t: torch.Tensor) -> bool:
+    """The reference dispatches its kernel templates on the tensor's dtype (K.cu:141 AT_DISPATCH_INTEGRAL_TYPES): int32 =
+    the 30-bit word mode (lf30_* entries), int64 = the 62-bit mode."""
+    return t.dtype == torch.int32
+
+
+def _same_words(what, a, *others):
+    for o in others:
+        if o is not None and o.dtype != a.dtype:
+            raise TypeError(f"ntt_cuda.{what}: mixed word modes ({a.dtype} data with {o.dtype} constants)")
 
 
 def _inplace(t: torch.Tensor):
@@ -82,8 +94,10 @@ def mont_mult(a, b, ql, qh, kl, kh):
         ai_c = ai.contiguous()
         bi_c = bi.contiguous()
         c = torch.empty_like(ai_c)
-        check(lib.lf_mont_mult(_ptr(ai_c), _ptr(bi_c), _ptr(c), ai_c.size(0), ai_c.size(-1),
-                               _ptr(l), _ptr(h), _ptr(kl_), _ptr(kh_), dev, st), "mont_mult")
+        _same_words("mont_mult", ai_c, bi_c, l, h, kl_, kh_)
+        fn = lib.lf30_mont_mult if _w30(ai_c) else lib.lf_mont_mult
+        check(fn(_ptr(ai_c), _ptr(bi_c), _ptr(c), ai_c.size(0), ai_c.size(-1),
+                 _ptr(l), _ptr(h), _ptr(kl_), _ptr(kh_), dev, st), "mont_mult")
         out.append(c)
     return out
 
@@ -92,8 +106,10 @@ def mont_enter(a, Rs, ql, qh, kl, kh):
     for ai, r, l, h, kl_, kh_ in zip(a, Rs, ql, qh, kl, kh):
         dev, st = _dev_stream(ai)
         w, back = _inplace(ai)
-        check(lib.lf_mont_enter(_ptr(w), _ptr(r.contiguous()), w.size(0), w.size(-1),
-                                _ptr(l), _ptr(h), _ptr(kl_), _ptr(kh_), dev, st), "mont_enter")
+        _same_words("mont_enter", w, r, l, h, kl_, kh_)
+        fn = lib.lf30_mont_enter if _w30(w) else lib.lf_mont_enter
+        check(fn(_ptr(w), _ptr(r.contiguous()), w.size(0), w.size(-1),
+                 _ptr(l), _ptr(h), _ptr(kl_), _ptr(kh_), dev, st), "mont_enter")
         if back is not None:
             back.copy_(w)
 
@@ -102,7 +118,9 @@ def mont_redc(a, ql, qh, kl, kh):
     for ai, l, h, kl_, kh_ in zip(a, ql, qh, kl, kh):
         dev, st = _dev_stream(ai)
         w, back = _inplace(ai)
-        check(lib.lf_mont_redc(_ptr(w), w.size(0), w.size(-1), _ptr(l), _ptr(h), _ptr(kl_), _ptr(kh_), dev, st),
+        _same_words("mont_redc", w, l, h, kl_, kh_)
+        fn = lib.lf30_mont_redc if _w30(w) else lib.lf_mont_redc
+        check(fn(_ptr(w), w.size(0), w.size(-1), _ptr(l), _ptr(h), _ptr(kl_), _ptr(kh_), dev, st),
               "mont_redc")
         if back is not None:
             back.copy_(w)
@@ -121,6 +139,13 @@ def _forward(a, Rs, psi, _2q, ql, qh, kl, kh, what):
         w, back = _inplace(ai)
         table = _compact(psi[i], inverse=False)
         rs = 0 if Rs is None else _ptr(Rs[i].contiguous())
+        if _w30(w):   # 30-bit word mode: the plain per-stage transform (no fp64 class, no auxiliary table)
+            _same_words(what, w, table, _2q[i], ql[i], qh[i], kl[i], kh[i])
+            check(lib.lf30_ntt(_ptr(w), 1, ql[i].size(0), _logN(w), _ptr(table), rs, _ptr(_2q[i]), _ptr(ql[i]), _ptr(qh[i]),
+                               _ptr(kl[i]), _ptr(kh[i]), dev, st), what)
+            if back is not None:
+                back.copy_(w)
+            continue
         dp = twiddles.dp_pointer(table, ql[i], qh[i], kl[i], kh[i], dev, st)
         _, qhost = twiddles.host_primes(ql[i], qh[i])
         # extent = ql.size(0) rows (K.cu:298, 371)
@@ -143,6 +168,13 @@ def _inverse(a, psi, Ninv, _2q, ql, qh, kl, kh, tail, what):
         dev, st = _dev_stream(ai)
         w, back = _inplace(ai)
         table = _compact(psi[i], inverse=True)
+        if _w30(w):
+            _same_words(what, w, table, Ninv[i], _2q[i], ql[i], qh[i], kl[i], kh[i])
+            check(lib.lf30_intt(_ptr(w), 1, ql[i].size(0), _logN(w), _ptr(table), _ptr(Ninv[i].contiguous()), tail, _ptr(_2q[i]),
+                                _ptr(ql[i]), _ptr(qh[i]), _ptr(kl[i]), _ptr(kh[i]), dev, st), what)
+            if back is not None:
+                back.copy_(w)
+            continue
         dp = twiddles.dp_pointer(table, ql[i], qh[i], kl[i], kh[i], dev, st)
         _, qhost = twiddles.host_primes(ql[i], qh[i])
         check(lib.lf_intt(_ptr(w), 1, ql[i].size(0), _logN(w), _ptr(table), dp, qhost, _ptr(Ninv[i].contiguous()), tail, 0,
@@ -167,39 +199,41 @@ def intt_exit_reduce_signed(a, even, odd, psi, Ninv, _2q, ql, qh, kl, kh):
     _inverse(a, psi, Ninv, _2q, ql, qh, kl, kh, 3, "intt_exit_reduce_signed")
 
 
-def _fixup(fn, what):
+def _fixup(fn, fn30, what):
     def op(a, _2q):
         for ai, q2 in zip(a, _2q):
             dev, st = _dev_stream(ai)
             w, back = _inplace(ai)
-            check(fn(_ptr(w), w.size(0), w.size(-1), _ptr(q2.contiguous()), dev, st), what)
+            _same_words(what, w, q2)
+            check((fn30 if _w30(w) else fn)(_ptr(w), w.size(0), w.size(-1), _ptr(q2.contiguous()), dev, st), what)
             if back is not None:
                 back.copy_(w)
     op.__name__ = what
     return op
 
 
-reduce_2q = _fixup(lib.lf_reduce_2q, "reduce_2q")
-make_signed = _fixup(lib.lf_make_signed, "make_signed")
-make_unsigned = _fixup(lib.lf_make_unsigned, "make_unsigned")
+reduce_2q = _fixup(lib.lf_reduce_2q, lib.lf30_reduce_2q, "reduce_2q")
+make_signed = _fixup(lib.lf_make_signed, lib.lf30_make_signed, "make_signed")
+make_unsigned = _fixup(lib.lf_make_unsigned, lib.lf30_make_unsigned, "make_unsigned")
 
 
-def _binary(fn, what):
+def _binary(fn, fn30, what):
     def op(a, b, _2q):
         out = []
         for ai, bi, q2 in zip(a, b, _2q):
             dev, st = _dev_stream(ai)
             ai_c, bi_c = ai.contiguous(), bi.contiguous()
             c = torch.empty_like(ai_c)
-            check(fn(_ptr(ai_c), _ptr(bi_c), _ptr(c), ai_c.size(0), ai_c.size(-1), _ptr(q2.contiguous()), dev, st), what)
+            _same_words(what, ai_c, bi_c, q2)
+            check((fn30 if _w30(ai_c) else fn)(_ptr(ai_c), _ptr(bi_c), _ptr(c), ai_c.size(0), ai_c.size(-1), _ptr(q2.contiguous()), dev, st), what)
             out.append(c)
         return out
     op.__name__ = what
     return op
 
 
-mont_add = _binary(lib.lf_mont_add, "mont_add")
-mont_sub = _binary(lib.lf_mont_sub, "mont_sub")
+mont_add = _binary(lib.lf_mont_add, lib.lf30_mont_add, "mont_add")
+mont_sub = _binary(lib.lf_mont_sub, lib.lf30_mont_sub, "mont_sub")
 
 
 def tile_unsigned(a, _2q):
@@ -209,7 +243,8 @@ def tile_unsigned(a, _2q):
         ai.squeeze_()  # K.cu:1206
         src = ai.contiguous()
         c = src.new_empty((q2.size(0), src.size(0)))
-        check(lib.lf_tile_unsigned(_ptr(src), _ptr(c), q2.size(0), src.size(0), _ptr(q2.contiguous()), dev, st),
-              "tile_unsigned")
+        _same_words("tile_unsigned", src, q2)
+        fn = lib.lf30_tile_unsigned if _w30(src) else lib.lf_tile_unsigned
+        check(fn(_ptr(src), _ptr(c), q2.size(0), src.size(0), _ptr(q2.contiguous()), dev, st), "tile_unsigned")
         out.append(c)
     return out

@@ -20,7 +20,8 @@ _LIB = os.path.join(_HERE, "_build", "libckks_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
+    newest = max(os.path.getmtime(_SRC), os.path.getmtime(os.path.join(_HERE, "ckks_oracle_impl.h")))
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < newest:
         os.makedirs(os.path.dirname(_LIB), exist_ok=True)
         subprocess.check_call(
             ["gcc", "-O2", "-fwrapv", "-fopenmp", "-shared", "-fPIC", "-o", _LIB, _SRC])
@@ -39,6 +40,11 @@ def lib():
         _lib.lfo_mm_scalar.argtypes = [i64] * 6
         _lib.lfo_redc_scalar.restype = i64
         _lib.lfo_redc_scalar.argtypes = [i64] * 5
+        i32 = ctypes.c_int32
+        _lib.lfo30_mm_scalar.restype = i32
+        _lib.lfo30_mm_scalar.argtypes = [i32] * 6
+        _lib.lfo30_redc_scalar.restype = i32
+        _lib.lfo30_redc_scalar.argtypes = [i32] * 5
     return _lib
 
 
@@ -57,81 +63,103 @@ def _i32(x):
     return _p(x)
 
 
+def _mode(a):
+    """(symbol prefix, word dtype, C type of N) of the word mode an array belongs to: int64 = the reference's 62-bit mode
+    (lfo_*), int32 = its 30-bit mode (lfo30_*: the same C text compiled over int32 words, ckks_oracle_impl.h)."""
+    if a.dtype == np.int64:
+        return "lfo_", np.int64, ctypes.c_int64
+    if a.dtype == np.int32:
+        return "lfo30_", np.int32, ctypes.c_int32
+    raise TypeError(f"oracle arrays are int64 (62-bit mode) or int32 (30-bit mode), not {a.dtype}")
+
+
+def _call(name, a, *args):
+    """lfo_<name> / lfo30_<name> by the dtype of `a`; numpy arrays among args must have the same word dtype (int32 index
+    tables are passed through _i32 by the caller), the token "N" stands for the row length of `a` in the mode's C type."""
+    pre, W, NT = _mode(a)
+    conv = []
+    for x in (a,) + args:
+        if isinstance(x, np.ndarray):
+            assert x.dtype == W, (name, x.dtype, W)
+            conv.append(_p(x))
+        else:
+            conv.append(x)
+    return getattr(lib(), pre + name)(*conv)
+
+
 def _N(a):
-    return ctypes.c_int64(a.shape[-1])
+    return _mode(a)[2](a.shape[-1])
 
 
-def mm_scalar(a, b, ql, qh, kl, kh) -> int:
-    return int(lib().lfo_mm_scalar(a, b, ql, qh, kl, kh))
+def mm_scalar(a, b, ql, qh, kl, kh, bits=62) -> int:
+    f = lib().lfo_mm_scalar if bits == 62 else lib().lfo30_mm_scalar
+    return int(f(a, b, ql, qh, kl, kh))
 
 
-def redc_scalar(x, ql, qh, kl, kh) -> int:
-    return int(lib().lfo_redc_scalar(x, ql, qh, kl, kh))
+def redc_scalar(x, ql, qh, kl, kh, bits=62) -> int:
+    f = lib().lfo_redc_scalar if bits == 62 else lib().lfo30_redc_scalar
+    return int(f(x, ql, qh, kl, kh))
 
 
 def mont_mult(a, b, c, rows, ql, qh, kl, kh):
-    lib().lfo_mont_mult(_i64(a), _i64(b), _i64(c), int(rows), _N(a), _i64(ql), _i64(qh), _i64(kl), _i64(kh))
+    _call("mont_mult", a, b, c, int(rows), _N(a), ql, qh, kl, kh)
 
 
 def mont_enter(a, Rs, rows, ql, qh, kl, kh):
-    lib().lfo_mont_enter(_i64(a), _i64(Rs), int(rows), _N(a), _i64(ql), _i64(qh), _i64(kl), _i64(kh))
+    _call("mont_enter", a, Rs, int(rows), _N(a), ql, qh, kl, kh)
 
 
 def mont_redc(a, rows, ql, qh, kl, kh):
-    lib().lfo_mont_redc(_i64(a), int(rows), _N(a), _i64(ql), _i64(qh), _i64(kl), _i64(kh))
+    _call("mont_redc", a, int(rows), _N(a), ql, qh, kl, kh)
 
 
 def ntt_tab(a, even, odd, psi, rows, _2q, ql, qh, kl, kh):
     logN = even.shape[0]
-    lib().lfo_ntt_tab(_i64(a), _i32(even), _i32(odd), _i64(psi), int(rows), int(logN), _N(a),
-                      _i64(_2q), _i64(ql), _i64(qh), _i64(kl), _i64(kh))
+    _call("ntt_tab", a, _i32(even), _i32(odd), psi, int(rows), int(logN), _N(a), _2q, ql, qh, kl, kh)
 
 
 def enter_ntt_tab(a, Rs, even, odd, psi, rows, _2q, ql, qh, kl, kh):
     logN = even.shape[0]
-    lib().lfo_enter_ntt_tab(_i64(a), _i64(Rs), _i32(even), _i32(odd), _i64(psi), int(rows), int(logN), _N(a),
-                            _i64(_2q), _i64(ql), _i64(qh), _i64(kl), _i64(kh))
+    _call("enter_ntt_tab", a, Rs, _i32(even), _i32(odd), psi, int(rows), int(logN), _N(a), _2q, ql, qh, kl, kh)
 
 
 def intt_tab(a, even, odd, psi, Ninv, rows, _2q, ql, qh, kl, kh):
     logN = even.shape[0]
-    lib().lfo_intt_tab(_i64(a), _i32(even), _i32(odd), _i64(psi), _i64(Ninv), int(rows), int(logN), _N(a),
-                       _i64(_2q), _i64(ql), _i64(qh), _i64(kl), _i64(kh))
+    _call("intt_tab", a, _i32(even), _i32(odd), psi, Ninv, int(rows), int(logN), _N(a), _2q, ql, qh, kl, kh)
 
 
 def ntt(a, psi_br, rows, logN, _2q, ql, qh, kl, kh):
     assert a.shape[-1] == (1 << logN) and psi_br.shape[-1] == (1 << logN)
-    lib().lfo_ntt(_i64(a), _i64(psi_br), int(rows), int(logN), _i64(_2q), _i64(ql), _i64(qh), _i64(kl), _i64(kh))
+    _call("ntt", a, psi_br, int(rows), int(logN), _2q, ql, qh, kl, kh)
 
 
 def intt(a, ipsi_br, Ninv, rows, logN, _2q, ql, qh, kl, kh):
     assert a.shape[-1] == (1 << logN) and ipsi_br.shape[-1] == (1 << logN)
-    lib().lfo_intt(_i64(a), _i64(ipsi_br), _i64(Ninv), int(rows), int(logN),
-                   _i64(_2q), _i64(ql), _i64(qh), _i64(kl), _i64(kh))
+    _call("intt", a, ipsi_br, Ninv, int(rows), int(logN), _2q, ql, qh, kl, kh)
 
 
 def reduce_2q(a, rows, _2q):
-    lib().lfo_reduce_2q(_i64(a), int(rows), _N(a), _i64(_2q))
+    _call("reduce_2q", a, int(rows), _N(a), _2q)
 
 
 def make_signed(a, rows, _2q):
-    lib().lfo_make_signed(_i64(a), int(rows), _N(a), _i64(_2q))
+    _call("make_signed", a, int(rows), _N(a), _2q)
 
 
 def make_unsigned(a, rows, _2q):
-    lib().lfo_make_unsigned(_i64(a), int(rows), _N(a), _i64(_2q))
+    _call("make_unsigned", a, int(rows), _N(a), _2q)
 
 
 def tile_unsigned(a, dst, rows, _2q):
-    lib().lfo_tile_unsigned(_i64(a), _i64(dst), int(rows), _N(dst), _i64(_2q))
+    _call("tile_unsigned", a, dst, int(rows), _N(dst), _2q)
 
 
 def mont_add(a, b, c, rows, _2q):
-    lib().lfo_mont_add(_i64(a), _i64(b), _i64(c), int(rows), _N(a), _i64(_2q))
+    _call("mont_add", a, b, c, int(rows), _N(a), _2q)
 
 
 def mont_sub(a, b, c, rows, _2q):
-    lib().lfo_mont_sub(_i64(a), _i64(b), _i64(c), int(rows), _N(a), _i64(_2q))
+    _call("mont_sub", a, b, c, int(rows), _N(a), _2q)
 
 
 def place_rows(src, rows):
@@ -160,4 +188,4 @@ def pin_threads(cpus):
 
 
 def galois(a, dst, rows, p):
-    lib().lfo_galois(_i64(a), _i64(dst), int(rows), _N(a), ctypes.c_int64(p))
+    _call("galois", a, dst, int(rows), _N(a), _mode(a)[2](p))

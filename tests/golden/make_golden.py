@@ -249,6 +249,40 @@ def run_bronze_ntt():
     return rec
 
 
+W30_PARAMS = dict(buffer_bit_length=30, scale_bits=24, logN=12, num_scales=4, num_special_primes=2, is_secured=False)
+
+
+def run_w30():
+    """The reference's 30-bit / int32 word mode: its ckks_context + ntt_context (constructed through its engine class, the
+    only part of the engine that works in this mode) with the C oracle's int32 instantiation as `ntt_cuda`.  Every one of
+    the 15 functions once, through the reference's own ntt_context methods, on seeded int32 words: one digest each."""
+    eng = rd.reference_engine(1, **W30_PARAMS)
+    ctx, ntt = eng.ctx, eng.ntt
+    assert ctx.torch_dtype == torch.int32
+    N = ctx.N
+    rows = list(ntt.p.d_special[0])
+    q = [int(ctx.q[i]) for i in rows]
+    rng = np.random.default_rng(3030)
+    lazy = np.stack([rng.integers(0, 2 * qi, size=N) for qi in q]).astype(np.int32)
+    other = np.stack([rng.integers(0, 2 * qi, size=N) for qi in q]).astype(np.int32)
+    rec = {"params": W30_PARAMS, "seed": 3030, "q": q, "rows": [int(i) for i in rows], "ops": {}}
+    sha = lambda t: hashlib.sha256(np.ascontiguousarray(t.numpy()).tobytes()).hexdigest()
+    fresh = lambda: torch.from_numpy(lazy.copy())
+    for name in ("ntt", "enter_ntt", "intt", "intt_exit", "intt_exit_reduce", "intt_exit_reduce_signed", "mont_redc", "reduce_2q",
+                 "make_signed", "make_unsigned", "mont_enter"):
+        t = fresh()
+        getattr(ntt, name)([t], 0, -2)
+        rec["ops"][name] = sha(t)
+    a, b = fresh(), torch.from_numpy(other.copy())
+    rec["ops"]["mont_mult"] = sha(ntt.mont_mult([a], [b], 0, -2)[0])
+    rec["ops"]["mont_add"] = sha(ntt.mont_add([a], [b], 0, -2)[0])
+    rec["ops"]["mont_sub"] = sha(ntt.mont_sub([a], [b], 0, -2)[0])
+    one = torch.from_numpy(rng.integers(-1, 2, size=N).astype(np.int32))
+    rec["ops"]["tile_unsigned"] = sha(ntt.tile_unsigned([one], 0, -2)[0])
+    rec["tile_input_sha256"] = hashlib.sha256(np.ascontiguousarray(one.numpy()).tobytes()).hexdigest()
+    return rec
+
+
 def write_pickle_fixture(params):
     """A ciphertext file written by the REFERENCE's save() (host form, eng.py:2001-2015): data, not code."""
     import pickle
@@ -293,6 +327,9 @@ if __name__ == "__main__":
              "keygen_bronze": run_keygen(CONFIGS["bronze"], 1),
              "encdec_small": run_encdec(CONFIGS["small"], 1024), "encdec_silver": run_encdec(CONFIGS["silver"], 128)}
         json.dump(k, open(kpath, "w"), indent=1)
+    if "w30" in which:          # the 30-bit / int32 word mode of the ntt_cuda surface
+        which.remove("w30")
+        json.dump(run_w30(), open(os.path.join(HERE, "w30_ntt.json"), "w"), indent=1)
     if "bronze_ntt" in which:   # BASELINE configs[0]
         which.remove("bronze_ntt")
         json.dump(run_bronze_ntt(), open(os.path.join(HERE, "bronze_ntt.json"), "w"), indent=1)

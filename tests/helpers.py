@@ -27,22 +27,26 @@ def i64(v):
 
 
 class Limbs:
-    """Montgomery / NTT constants of a list of primes for ring degree 2^logN, as host int64 arrays."""
+    """Montgomery / NTT constants of a list of primes for ring degree 2^logN, as host arrays of the word mode:
+    bits = 62 (int64 words, R = 2^62, 31-bit halves) or 30 (the reference's int32 mode: R = 2^30, 15-bit halves)."""
 
-    def __init__(self, logN, q):
+    def __init__(self, logN, q, bits=62):
         self.logN, self.N, self.q = logN, 1 << logN, [int(x) for x in q]
-        N = self.N
+        self.bits, self.R, self.half = bits, 1 << bits, bits // 2
+        self.dtype = np.int64 if bits == 62 else np.int32
+        N, Rr, lb, h = self.N, self.R, (1 << (bits // 2)) - 1, bits // 2
+        arr = lambda v: np.ascontiguousarray(np.asarray(v, dtype=self.dtype))
         self.rows = len(self.q)
-        self.k = [(R * pow(R, -1, qi) - 1) // qi for qi in self.q]
-        self.ql, self.qh = i64([x & LB for x in self.q]), i64([x >> 31 for x in self.q])
-        self.kl, self.kh = i64([x & LB for x in self.k]), i64([x >> 31 for x in self.k])
-        self._2q = i64([2 * x for x in self.q])
-        self.Rs = i64([R * R % x for x in self.q])
-        self.Ninv = i64([pow(N, -1, x) * R % x for x in self.q])
+        self.k = [(Rr * pow(Rr, -1, qi) - 1) // qi for qi in self.q]
+        self.ql, self.qh = arr([x & lb for x in self.q]), arr([x >> h for x in self.q])
+        self.kl, self.kh = arr([x & lb for x in self.k]), arr([x >> h for x in self.k])
+        self._2q = arr([2 * x for x in self.q])
+        self.Rs = arr([Rr * Rr % x for x in self.q])
+        self.Ninv = arr([pow(N, -1, x) * Rr % x for x in self.q])
         brev = bit_reverse_indices(logN)
         self.root = [primitive_root_2N(x, N) for x in self.q]
-        self.psi_plain = np.stack([_power_table(g, N, x)[brev] for g, x in zip(self.root, self.q)])
-        self.ipsi_plain = np.stack([_power_table(pow(g, -1, x), N, x)[brev] for g, x in zip(self.root, self.q)])
+        self.psi_plain = np.stack([_power_table(g, N, x)[brev] for g, x in zip(self.root, self.q)]).astype(self.dtype)
+        self.ipsi_plain = np.stack([_power_table(pow(g, -1, x), N, x)[brev] for g, x in zip(self.root, self.q)]).astype(self.dtype)
         self._mont = None
 
     def mont_tables(self):
@@ -60,7 +64,24 @@ class Limbs:
 
     def uniform(self, seed, lazy=False):
         rng = np.random.default_rng(seed)
-        return np.stack([rng.integers(0, (2 if lazy else 1) * x, size=self.N, dtype=np.int64) for x in self.q])
+        return np.stack([rng.integers(0, (2 if lazy else 1) * x, size=self.N, dtype=np.int64) for x in self.q]).astype(self.dtype)
+
+
+def pick_primes30(logN, n_scale=2, n_message=1, scale_bits=24):
+    """NTT-friendly primes of the 30-bit word mode: `n_scale` near 2^scale_bits, `n_message` just below 2^28
+    (the reference's message_bits = buffer_bit_length - 2, ckks_context.py:222)."""
+    M = 2 << logN
+    out, q = [], (1 << scale_bits) + 1
+    for _ in range(n_scale):
+        q = P.next_ntt_prime(q, M, up=True)
+        out.append(q)
+        q += 2
+    q = (1 << 28) - 1
+    for _ in range(n_message):
+        q = P.next_ntt_prime(q, M, up=False)
+        out.append(q)
+        q -= 2
+    return out
 
 
 def pick_primes(logN, n40=2, n60=1):

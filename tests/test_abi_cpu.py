@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared():
     text = open(os.path.join(ROOT, "include", "ckks_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\bint(?:64_t)?\s+(lf_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\bint(?:64_t)?\s+(lf(?:30)?_\w+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported():
@@ -20,7 +20,7 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(so, n), f"{n} declared in include/ckks_hip.h but not exported"
     assert sorted(_native.EXPORTED) == names, "python binding table out of sync with the header"
-    assert _native.lib.lf_abi_version() == 12     # pure host call, no HIP runtime use
+    assert _native.lib.lf_abi_version() == 13     # pure host call, no HIP runtime use
 
 
 def test_python_binding_passes_as_many_arguments_as_the_header_declares():
@@ -29,7 +29,7 @@ def test_python_binding_passes_as_many_arguments_as_the_header_declares():
     from liberate_fhe_amd import _native
     text = open(os.path.join(ROOT, "include", "ckks_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    for name, params in re.findall(r"\bint(?:64_t)?\s+(lf_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+    for name, params in re.findall(r"\bint(?:64_t)?\s+(lf(?:30)?_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
         params = [p.strip() for p in params.split(",")] if params.strip() not in ("", "void") else []
         sig = _native._SIGNATURES[name]
         assert len(sig) == len(params), f"{name}: header has {len(params)} parameters, binding {len(sig)}"
