@@ -127,6 +127,7 @@ def cpu_baseline(ctx, rows_idx, batch_cap=64, budget_s=12.0):
     from oracle import oracle as orc
     L = len(rows_idx)
     cpus = physical_cores()
+    visible = len(cpus)
     quota = cpu_quota_cores()
     if quota is not None and quota < len(cpus):     # a container limited to fewer CPU-seconds per second than it can see cores
         cpus = cpus[:max(1, int(quota))]
@@ -157,7 +158,7 @@ def cpu_baseline(ctx, rows_idx, batch_cap=64, budget_s=12.0):
         dt = (time.time() - t0) / reps
         out = {"value": batch / dt, "unit": "poly-NTT(L=30,logN=16)/s", "cores": threads, "kind": "port",
                "sample": f"{reps} x forward NTT of {batch} polys x {L} limbs, N=65536, C oracle, OpenMP static over limb rows, "
-                         f"{threads} threads pinned one per physical core ({cores} usable: {len(physical_cores())} visible, "
+                         f"{threads} threads pinned one per physical core ({cores} usable: {visible} visible, "
                          f"cgroup CPU quota {quota if quota is not None else 'none'}; {unpinned} not pinned), "
                          "rows and twiddles first-touched by their thread"}
         # the same kernel on ONE core: one polynomial's 30 limbs, a single OpenMP thread
