@@ -55,8 +55,11 @@ int lf_limits(int which);
  * the A/B tools under tools/ do).
  *   LF_TUNE_KS_EXT_COLS_MAX   largest logN - 12 (0 .. 4) for which the key switch's extension + leading stages run as the
  *                             column kernel (one register step per column, no LDS); above it the LDS-tiled form.
+ *   LF_TUNE_INTT_DIGITS       1 (default): lf_cc_mult_evk(_batch / _pre) form the digits of x1 * y1 inside the last inverse pass
+ *                             where a digit's limbs fit a column thread (lf_intt_mul_digits); 0: always the two launches.
  *   (knob 0 was the one-launch key-switch transform of round 3: slower at every preset size on MI355X, removed.) */
 #define LF_TUNE_KS_EXT_COLS_MAX 1
+#define LF_TUNE_INTT_DIGITS 2
 int lf_tune(int which, int value);
 
 /* Measurement entry (not one of the reference's ops; the engine never calls it): ONE wave, launched on `stream`, takes
@@ -360,6 +363,17 @@ int lf_ks_digits_galois(const int64_t *a, int64_t *state, int nparts, const int6
                         const int64_t *kh, int device, void *stream);
 int lf_galois_batch(const int64_t *const *a, int64_t *const *dst, int count, int rows, int logN, int64_t p,
                     const int64_t *_2q, int device, void *stream);
+
+/* lf_intt_mul (relaxed, tail 2) followed by lf_ks_digits of its result in ONE launch behind the tiled pass: the column thread of
+ * the last inverse pass takes the columns of all `alpha` limbs of its digit, runs the Garner step on the canonical words it holds
+ * and stores the digit state — the coefficient-domain product is never written (cc_mult: ckks_engine.py:1099-1101, 1129, 654-705).
+ * `scratch` [batch][rows][N] receives the tiled pass's output; `state` [batch][rows][N]; desc / tab = lf_ks_digits' tables for
+ * `nparts` digits of at most `max_alpha` limbs.  Applies to two-pass ring degrees with max_alpha * 2^(logN - 12) <= 32 (silver,
+ * bronze); otherwise returns LF_ERR_ARG with nothing launched and the caller takes the two calls.  Same words in `state`. */
+int lf_intt_mul_digits(int64_t *scratch, const int64_t *a, int64_t a_stride, const int64_t *b, int64_t b_stride, int batch, int rows,
+                       int logN, int64_t *state, int nparts, int max_alpha, const int64_t *desc, const int64_t *tab,
+                       const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *q_host, const int64_t *Ninv, int flags,
+                       const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 
 /* cc_mult's opening (ckks_engine.py:1085-1093): rescale `count` (<= 8) polynomials and transform them, i.e.
  * lf_rescale_batch(in, row0, {x + i*rows*N}, ...) followed by lf_ntt(x, count, ...) with the same constants.

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "lf_ks_fwd": [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_ks_tail": [_I, _I, _I, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_intt_mul": [_P, _P, _L, _P, _L, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
+    "lf_intt_mul_digits": [_P, _P, _L, _P, _L, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
     "lf_relin_core_batch": [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_relin_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "lf_relin_tail": [_I, _I, _I, _P, _L, _L, _L, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P],

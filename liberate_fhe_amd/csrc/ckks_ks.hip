@@ -729,13 +729,19 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
 
 }  // namespace
 
+// cc_mult's product -> digits in one launch behind the tiled pass where it qualifies (ckks_ops.hip: product_digits): 0 = never
+int lf_g_intt_digits = 1;
+
 extern "C" {
 
 int lf_tune(int which, int value) {
-    int *knob = which == LF_TUNE_KS_EXT_COLS_MAX ? &g_ks_ext_cols_max : nullptr;
+    int *knob = which == LF_TUNE_KS_EXT_COLS_MAX ? &g_ks_ext_cols_max : which == LF_TUNE_INTT_DIGITS ? &lf_g_intt_digits : nullptr;
     if (!knob) return -1;
     const int old = *knob;
-    if (value >= 0 && !(which == LF_TUNE_KS_EXT_COLS_MAX && value > 4)) *knob = value;
+    if (value < 0) return old;
+    if (which == LF_TUNE_KS_EXT_COLS_MAX && value > 4) return old;
+    if (which == LF_TUNE_INTT_DIGITS && value > 1) return old;
+    *knob = value;
     return old;
 }
 

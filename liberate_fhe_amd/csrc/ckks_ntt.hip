@@ -109,6 +109,69 @@ void launch_cols_mixed_rs(int K, unsigned per_limb, hipStream_t st, i64 *base, c
     }
 }
 
+// ---- last inverse pass + chain tail + key-switch digits in ONE launch (lf_intt_mul_digits) --------------------------------------
+// cc_mult's x1 * y1 leaves its inverse transform only to be cut into mixed-radix digits (ks_digits_kernel: a Garner step per
+// coefficient over the alpha limbs of a digit).  Where a digit's limbs fit a thread — alpha * 2^K words, K = logN - 12 trailing
+// stages: silver 2 x 8, bronze 1 x 4 — the column thread of the inverse pass takes the columns of ALL limbs of its digit, runs
+// the Garner step on the canonical words it holds and stores the digit state directly: the coefficient-domain product is never
+// written, one launch (of silver's eleven) and its dependency gap disappear.  desc / tab = lf_ks_digits' tables.
+template <int K, int AMAX>
+__global__ void __launch_bounds__(NTT_COL_THREADS) ntt_inv_cols_digits(const i64 *__restrict__ src, i64 *__restrict__ state, PassGeom g,
+                                                                      const i64 *__restrict__ desc, const i64 *__restrict__ tab,
+                                                                      const i64 *__restrict__ ipsi_br,
+                                                                      const double *__restrict__ ipsi_dp,
+                                                                      const i64 *__restrict__ Ninv, const i64 *__restrict__ ql,
+                                                                      const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                                                      const i64 *__restrict__ kh) {
+    constexpr int R = 1 << K;
+    const int logC = g.logN - K;
+    const int chunks = (1 << logC) / NTT_COL_THREADS;
+    const int chunk = (int)blockIdx.x % chunks, p = (int)blockIdx.x / chunks, poly = (int)blockIdx.y;
+    const int row_start = __builtin_amdgcn_readfirstlane((int)desc[p * 4 + 0]);
+    const int alpha = __builtin_amdgcn_readfirstlane((int)desc[p * 4 + 1]);
+    const i64 *Y = tab + desc[p * 4 + 2];
+    const i64 *Ls = tab + desc[p * 4 + 3];
+    i64 x[AMAX][R];
+#pragma unroll
+    for (int i = 0; i < AMAX; ++i) {
+        if (i < alpha) {
+            const int crow = row_start + i;
+            const u64 q = ((u64)qh[crow] << 31) | (u64)ql[crow];
+            // tail 2 (intt_exit_reduce): canonical coefficients, what ks_digits_kernel reads
+            if (q < SMALL_PRIME_LIMIT) inv_cols_compute<true, K>(poly, crow, chunk, src, g, ipsi_br, ipsi_dp, Ninv, 2, ql, qh, kl, kh, x[i]);
+            else inv_cols_compute<false, K>(poly, crow, chunk, src, g, ipsi_br, ipsi_dp, Ninv, 2, ql, qh, kl, kh, x[i]);
+        }
+    }
+    // the Garner step of ks_digits_kernel (ckks_fused.hip; pre_extend, ckks_engine.py:654-705), per held coefficient
+    i64 *out = state + ((i64)poly * g.rows << g.logN) + chunk * NTT_COL_THREADS + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        i64 st[AMAX];
+#pragma unroll
+        for (int i = 0; i < AMAX; ++i) st[i] = x[0][k];
+        int lc = 0;
+#pragma unroll
+        for (int i = 0; i < AMAX - 1; ++i) {
+            if (i + 1 < alpha) {
+                const RowMod m = load_mod(ql, qh, kl, kh, row_start + i + 1);
+                const i64 y = mm62s(x[i + 1][k] - st[i + 1], Y[i], m.q, m.k);
+                st[i + 1] = y;
+#pragma unroll
+                for (int jj = i + 2; jj < AMAX; ++jj) {
+                    if (jj < alpha) {
+                        const RowMod mj = load_mod(ql, qh, kl, kh, row_start + jj);
+                        st[jj] += mm62s(y, Ls[lc], mj.q, mj.k);
+                        ++lc;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < AMAX; ++i)
+            if (i < alpha) out[((i64)(row_start + i) << g.logN) + ((i64)k << logC)] = st[i];
+    }
+}
+
 // forward transform of a stack; `rsrc` (optional): the column pass takes its input from a rescale on the fly
 int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
                 const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *ql, const int64_t *qh,
@@ -321,6 +384,44 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
             const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
     (void)_2q;
     return intt_impl(a, nullptr, nullptr, batch, rows, logN, ipsi_br, ipsi_dp, q_host, Ninv, tail, flags, ql, qh, kl, kh, device, stream);
+}
+
+/* lf_intt_mul followed by lf_ks_digits of its result, the coefficient-domain product never written: the first inverse pass forms
+ * a * b into `scratch` ([batch][rows][N], the tiled pass's output), the column pass of every digit's limbs ends in the Garner
+ * step and stores the digit states ([batch][rows][N], state_stride words apart).  Returns LF_ERR_ARG — nothing launched — when
+ * the shape does not qualify (two-pass degrees with max_alpha * 2^(logN - 12) <= 32 words per thread only): the caller then
+ * takes lf_intt_mul + lf_ks_digits.  Same words in `state` either way. */
+int lf_intt_mul_digits(int64_t *scratch, const int64_t *a, int64_t a_stride, const int64_t *b, int64_t b_stride, int batch, int rows,
+                       int logN, int64_t *state, int nparts, int max_alpha, const int64_t *desc, const int64_t *tab,
+                       const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *q_host, const int64_t *Ninv, int flags,
+                       const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    const int S1 = logN - NTT_TILE_LOG_MAX;
+    if (!scratch || !a || !b || !state || !desc || !tab || !ipsi_dp || !q_host || batch < 1 || batch > LF_BATCH_MAX || rows < 1 ||
+        rows > MAX_LIST_ROWS || nparts < 1 || max_alpha < 1 || S1 < 1 || S1 > 4 || (max_alpha << S1) > 32 || !(flags & LF_NTT_RELAXED))
+        return LF_ERR_ARG;
+    if (int e = lf_set_device(device)) return e;
+    const int tl = NTT_TILE_LOG_MAX;
+    const int plain = (flags & LF_NTT_PLAIN) ? 1 : 0;
+    RowList dp, in;
+    classify(rows, q_host, ipsi_dp, dp, in);
+    hipStream_t st = (hipStream_t)stream;
+    const MulSrc ms{(const i64 *)b, (i64)a_stride, (i64)b_stride};
+    const PassGeom g0{logN, tl, 0, tl, 0, 0, rows, batch, 1, 0, plain};
+    launch_pass16(true, 1, batch, st, (const i64 *)a, (i64 *)scratch, g0, in, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)ql,
+                  (const i64 *)qh, (const i64 *)kl, (const i64 *)kh, &ms);
+    const PassGeom g1{logN, tl, 1, S1, tl, tl - S1, rows, batch, 1, 1, plain};
+    const dim3 grid((unsigned)nparts * ((1u << (logN - S1)) / NTT_COL_THREADS), (unsigned)batch), block(NTT_COL_THREADS);
+    const int amax = max_alpha <= 1 ? 1 : max_alpha <= 2 ? 2 : max_alpha <= 4 ? 4 : 8;
+#define LF_ICD(KK, AA)                                                                                                       \
+    hipLaunchKernelGGL((ntt_inv_cols_digits<KK, AA>), grid, block, 0, st, (const i64 *)scratch, (i64 *)state, g1, (const i64 *)desc, \
+                       (const i64 *)tab, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, (const i64 *)ql, (const i64 *)qh,     \
+                       (const i64 *)kl, (const i64 *)kh)
+    if (S1 == 1) { if (amax == 1) LF_ICD(1, 1); else if (amax == 2) LF_ICD(1, 2); else if (amax == 4) LF_ICD(1, 4); else LF_ICD(1, 8); }
+    else if (S1 == 2) { if (amax == 1) LF_ICD(2, 1); else if (amax == 2) LF_ICD(2, 2); else if (amax == 4) LF_ICD(2, 4); else LF_ICD(2, 8); }
+    else if (S1 == 3) { if (amax == 1) LF_ICD(3, 1); else if (amax == 2) LF_ICD(3, 2); else LF_ICD(3, 4); }
+    else { if (amax == 1) LF_ICD(4, 1); else LF_ICD(4, 2); }
+#undef LF_ICD
+    return (int)hipGetLastError();
 }
 
 int lf_intt_mul(int64_t *dst, const int64_t *a, int64_t a_stride, const int64_t *b, int64_t b_stride, int batch, int rows, int logN,

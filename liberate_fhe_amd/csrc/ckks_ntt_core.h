@@ -1446,18 +1446,16 @@ __device__ __forceinline__ void cols_inv_stages(typename A::T (&x)[1 << K], cons
     }
 }
 
+// the column of lane `lane` of chunk `chunk` of limb (poly, crow): its 2^K words through the trailing stages and the chain
+// tail, returned in out[] (word k belongs at coefficient (k << logC) + chunk * NTT_COL_THREADS + lane)
 template <bool DP, int K>
-__device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const PassGeom &g, const RowList &rl,
-                                              const i64 *__restrict__ ipsi_br, const double *__restrict__ ipsi_dp,
-                                              const i64 *__restrict__ Ninv, int tail, const i64 *__restrict__ ql,
-                                              const i64 *__restrict__ qh, const i64 *__restrict__ kl,
-                                              const i64 *__restrict__ kh) {
+__device__ __forceinline__ void inv_cols_compute(int poly, int crow, int chunk, const i64 *__restrict__ a, const PassGeom &g,
+                                                 const i64 *__restrict__ ipsi_br, const double *__restrict__ ipsi_dp,
+                                                 const i64 *__restrict__ Ninv, int tail, const i64 *__restrict__ ql,
+                                                 const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                                 const i64 *__restrict__ kh, i64 (&out)[1 << K]) {
     constexpr int R = 1 << K;
     const int logC = g.logN - K;
-    const int chunks = (1 << logC) / NTT_COL_THREADS;
-    const int chunk = b % chunks, r = b / chunks;
-    // (the integer divisions run on the VALU: pin their wave-uniform results back into SGPRs)
-    const int poly = __builtin_amdgcn_readfirstlane(r % g.batch), crow = __builtin_amdgcn_readfirstlane((int)rl.id[r / g.batch]);
     Ctx c;
     c.m = load_mod(ql, qh, kl, kh, crow);
     c.tw_mont = ipsi_br + ((i64)crow << g.logN);
@@ -1468,7 +1466,7 @@ __device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const 
     const i64 ninv_mont = (tail != TAIL_NONE) ? Ninv[crow] : 0;
     // wave-uniform base + lane index: the 2^K row addresses stay in SGPRs (a per-lane pointer would pin 2^K 64-bit
     // addresses in VGPRs from the loads to the stores)
-    i64 *colu = a + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS;
+    i64 *colu = const_cast<i64 *>(a) + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS;
     const unsigned lane = threadIdx.x;
 
     i64 w[R];
@@ -1505,21 +1503,41 @@ __device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const 
                 if (dp_below_fix_limit(z)) z = dp_lazy_fix(z, (u64)tr, (u64)ninv_mont, c.d.q);
                 if (tail == 1) z = (z == c.d.q) ? c.d.q : dp_mulmod(z, rinv, c.d);   // redc(q) = q (K.cu:587-606)
             }
-            INV_ST(uniform_row(colu, (i64)k << logC) + lane, (tail >= 3) ? (i64)z : dp_to_word(z));
+            out[k] = (tail >= 3) ? (i64)z : dp_to_word(z);
         }
     } else {
         if (!DP && g.relaxed) {   // residues only (the words are canonical: this library's relaxed tiled pass wrote them)
             cols_inv_stages<ArithShoup, K>(w, c);
 #pragma unroll
             for (int k = 0; k < R; ++k)
-                INV_ST(uniform_row(colu, (i64)k << logC) + lane, inv_tail_int(ArithShoup::canon(c, w[k]), tail, ninv_mont, c));
+                out[k] = inv_tail_int(ArithShoup::canon(c, w[k]), tail, ninv_mont, c);
             return;
         }
         if (odd || DP) cols_inv_stages<ArithInt<true>, K>(w, c);
         else cols_inv_stages<ArithInt<false>, K>(w, c);
 #pragma unroll
-        for (int k = 0; k < R; ++k) INV_ST(uniform_row(colu, (i64)k << logC) + lane, inv_tail_int(w[k], tail, ninv_mont, c));
+        for (int k = 0; k < R; ++k) out[k] = inv_tail_int(w[k], tail, ninv_mont, c);
     }
+}
+
+template <bool DP, int K>
+__device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const PassGeom &g, const RowList &rl,
+                                              const i64 *__restrict__ ipsi_br, const double *__restrict__ ipsi_dp,
+                                              const i64 *__restrict__ Ninv, int tail, const i64 *__restrict__ ql,
+                                              const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                              const i64 *__restrict__ kh) {
+    constexpr int R = 1 << K;
+    const int logC = g.logN - K;
+    const int chunks = (1 << logC) / NTT_COL_THREADS;
+    const int chunk = b % chunks, r = b / chunks;
+    // (the integer divisions run on the VALU: pin their wave-uniform results back into SGPRs)
+    const int poly = __builtin_amdgcn_readfirstlane(r % g.batch), crow = __builtin_amdgcn_readfirstlane((int)rl.id[r / g.batch]);
+    i64 out[R];
+    inv_cols_compute<DP, K>(poly, crow, chunk, a, g, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh, out);
+    i64 *colu = a + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS;
+    const unsigned lane = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < R; ++k) INV_ST(uniform_row(colu, (i64)k << logC) + lane, out[k]);
 }
 
 template <bool DP, int K>

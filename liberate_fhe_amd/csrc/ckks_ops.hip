@@ -10,6 +10,8 @@
 #include "../../include/ckks_hip.h"
 #include "ckks_common.h"
 
+extern int lf_g_intt_digits;   // ckks_ks.hip (lf_tune)
+
 extern "C" {
 
 static int plan_ok(const lf_ks_plan *p) {
@@ -37,6 +39,27 @@ static int moddown_any(const lf_ks_plan *p, const int64_t *const *ss, int64_t *c
                             p->qh, p->kl, p->kh, p->device, stream);
 }
 
+// d2 = x1 * y1 -> inverse transform -> digits of the plan's `nct` operand stacks: in ONE launch behind the tiled pass where a
+// digit's limbs fit a column thread (lf_intt_mul_digits: silver, bronze), else the inverse transform and lf_ks_digits(_batch)
+static int product_digits(const lf_ks_plan *p, int nct, void *stream) {
+    const int ell = p->ell, logN = p->logN, dev = p->device;
+    const int64_t N = (int64_t)1 << logN, poly = (int64_t)ell * N;
+    const int relaxed_plain = LF_NTT_RELAXED | LF_NTT_PLAIN;
+    const int64_t xs = nct > 1 ? 4 * poly : poly;   // stride between the operand stacks of a batch
+    const int e = !lf_g_intt_digits ? LF_ERR_ARG : lf_intt_mul_digits(p->d2, p->x4 + poly, xs, p->x4 + 3 * poly, xs, nct, ell, logN, p->state, p->dig_nparts, p->K, p->dig_desc,
+                                     p->dig_tab, p->ipsi, p->ipsi_dp, p->q_host, p->Ninv, relaxed_plain, p->ql, p->qh, p->kl, p->kh, dev, stream);
+    if (e != LF_ERR_ARG) return e;   // launched (0) or a runtime error; LF_ERR_ARG: the shape does not qualify, nothing was launched
+    if (int e2 = lf_intt_mul(p->d2, p->x4 + poly, xs, p->x4 + 3 * poly, xs, nct, ell, logN, p->ipsi, p->ipsi_dp, p->q_host, p->Ninv, 2,
+                             relaxed_plain, p->ql, p->qh, p->kl, p->kh, dev, stream))
+        return e2;
+    if (nct == 1)
+        return lf_ks_digits(p->d2, p->state, p->dig_nparts, p->dig_desc, p->dig_tab, N, p->ql, p->qh, p->kl, p->kh, dev, stream);
+    const int64_t *srcs[4];
+    int64_t *states[4];
+    for (int t = 0; t < nct; ++t) srcs[t] = p->d2 + t * poly, states[t] = p->state + t * poly;
+    return lf_ks_digits_batch(srcs, states, nct, p->dig_nparts, p->dig_desc, p->dig_tab, N, 0, nullptr, p->ql, p->qh, p->kl, p->kh, dev, stream);
+}
+
 int lf_cc_mult_evk(const lf_ks_plan *p, const int64_t *const *in, const int64_t *const *row0, const int64_t *ksk,
                    int64_t part_stride, int64_t comp_stride, int64_t row_off, int key_format, int64_t *out0, int64_t *out1,
                    void *stream) {
@@ -48,13 +71,9 @@ int lf_cc_mult_evk(const lf_ks_plan *p, const int64_t *const *in, const int64_t 
     if (int e = lf_rescale_ntt(in, row0, 4, p->x4, ell, logN, p->rescale_scales, p->round_at, p->psi, p->psi_dp, p->q_host, p->Rs,
                                relaxed_plain, p->_2q, p->ql, p->qh, p->kl, p->kh, dev, stream))
         return e;
-    // d2 = x1 * y1 straight into its inverse transform (1099-1101, 1129)
-    if (int e = lf_intt_mul(p->d2, p->x4 + poly, poly, p->x4 + 3 * poly, poly, 1, ell, logN, p->ipsi, p->ipsi_dp, p->q_host, p->Ninv, 2,
-                            relaxed_plain, p->ql, p->qh, p->kl, p->kh, dev, stream))
-        return e;
+    // d2 = x1 * y1 straight into its inverse transform (1099-1101, 1129), its digits (654-705)
+    if (int e = product_digits(p, 1, stream)) return e;
     // key switch of d2 with d0, d1 folded into its sums (654-961, 1117-1151)
-    if (int e = lf_ks_digits(p->d2, p->state, p->dig_nparts, p->dig_desc, p->dig_tab, N, p->ql, p->qh, p->kl, p->kh, dev, stream))
-        return e;
     if (int e = lf_relin_core_batch(p->state, 0, 1, p->nparts, rows, logN, p->ext_desc, p->E, p->Ed, ksk, part_stride, comp_stride,
                                     row_off, key_format, p->ext, p->sum, p->psi, p->psi_dp, p->ipsi, p->ipsi_dp, p->Ninv, p->x4, 0, p->PR, ell,
                                     p->own, p->q_host, p->ql, p->qh, p->kl, p->kh, dev, stream))
@@ -126,16 +145,8 @@ int lf_cc_mult_evk_batch(const lf_ks_plan *p, int nct, const int64_t *const *in,
                                    stream))
             return e;
     }
-    // the nct products x1 * y1 through one inverse transform (product on load)
-    if (int e = lf_intt_mul(p->d2, p->x4 + poly, 4 * poly, p->x4 + 3 * poly, 4 * poly, nct, ell, logN, p->ipsi, p->ipsi_dp, p->q_host,
-                            p->Ninv, 2, relaxed_plain, p->ql, p->qh, p->kl, p->kh, dev, stream))
-        return e;
-    const int64_t *srcs[4];
-    int64_t *states[4];
-    for (int t = 0; t < nct; ++t) srcs[t] = p->d2 + t * poly, states[t] = p->state + t * poly;
-    if (int e = lf_ks_digits_batch(srcs, states, nct, p->dig_nparts, p->dig_desc, p->dig_tab, N, 0, nullptr, p->ql, p->qh, p->kl, p->kh, dev,
-                                   stream))
-        return e;
+    // the nct products x1 * y1 through one inverse transform (product on load), their digits
+    if (int e = product_digits(p, nct, stream)) return e;
     if (int e = lf_relin_core_batch(p->state, poly, nct, p->nparts, rows, logN, p->ext_desc, p->E, p->Ed, ksk, part_stride, comp_stride,
                                     row_off, key_format, p->ext, p->sum, p->psi, p->psi_dp, p->ipsi, p->ipsi_dp, p->Ninv, p->x4, 4 * poly,
                                     p->PR, ell, p->own, p->q_host, p->ql, p->qh, p->kl, p->kh, dev, stream))
@@ -174,10 +185,7 @@ int lf_cc_mult_evk_pre(const lf_ks_plan *p, const int64_t *const *in, const int6
         if (int e = lf_rescale_ntt(none, none, 4, p->x4, ell, logN, p->rescale_scales, p->round_at, p->psi, p->psi_dp, p->q_host, p->Rs,
                                    relaxed_plain | LF_NTT_ONLY_TILED, p->_2q, p->ql, p->qh, p->kl, p->kh, dev, stream))
             return e;
-    if (int e = lf_intt_mul(p->d2, p->x4 + poly, poly, p->x4 + 3 * poly, poly, 1, ell, logN, p->ipsi, p->ipsi_dp, p->q_host, p->Ninv, 2,
-                            relaxed_plain, p->ql, p->qh, p->kl, p->kh, dev, stream))
-        return e;
-    return lf_ks_digits(p->d2, p->state, p->dig_nparts, p->dig_desc, p->dig_tab, N, p->ql, p->qh, p->kl, p->kh, dev, stream);
+    return product_digits(p, 1, stream);
 }
 
 int lf_switch_key_pre(const lf_ks_plan *p, const int64_t *c1, int64_t gal_pinv, int gal_canonical, void *stream) {

@@ -518,6 +518,31 @@ def test_one_launch_moddown_equals_the_two_launch_form(params):
     assert outs[0] == outs[1] == outs[2]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("params", [dict(logN=13, num_scales=9, num_special_primes=2, is_secured=False), dict(logN=14, num_special_primes=1),
+                                    dict(logN=15, num_special_primes=2), dict(logN=13, scale_bits=45, num_scales=6, num_special_primes=4, is_secured=False)])
+def test_product_digits_inside_the_last_inverse_pass_equal_the_two_launches(params):
+    """cc_mult's x1 * y1: the column thread of the last inverse pass holds the limbs of a digit and runs the Garner step itself
+    (lf_intt_mul_digits, where alpha * 2^(logN - 12) <= 32) against inverse transform + ks_digits as two launches
+    (lf_tune LF_TUNE_INTT_DIGITS = 0): same words from cc_mult and cc_mult_batch at two levels, digits of 1, 2 and 4 limbs."""
+    from liberate_fhe_amd._native import lib
+    from liberate_fhe_amd.fhe import ckks_engine
+    eng = ckks_engine(devices=["cuda:0"], **params)
+    evk = synth.key_switch_key(eng, 5)
+    outs = []
+    try:
+        for fused in (1, 0, 1):
+            assert lib.lf_tune(2, fused) in (0, 1)
+            res = []
+            for level in (0, 2):
+                a, b = synth.ciphertext(eng, 50 + level, level), synth.ciphertext(eng, 60 + level, level)
+                res += [eng.cc_mult(a, b, evk)] + eng.cc_mult_batch([(a, b), (b, a), (a, a), (b, b), (a, b)], evk)
+            outs.append([digest(x) for x in res])
+    finally:
+        lib.lf_tune(2, 1)
+    assert outs[0] == outs[1] == outs[2]
+
+
 def _reference_shaped_switcher(eng, a, ksk, level):
     """create_switcher as the reference composes it from its step methods (eng.py:746-904) on ONE device: digits per part,
     extension + NTT + key products per part, sums, inverse transform, division by P through the checker's chain."""
