@@ -11,6 +11,6 @@ if [ "$REV" != "-" ]; then
   git -C $ROOT archive $REV liberate_fhe_amd/csrc include | tar -x -C $SRC
 fi
 C=$SRC/liberate_fhe_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC "$@" -o $OUT/lib_$NAME.so $C/ckks_hip.hip $C/ckks_ntt.hip $C/ckks_fused.hip $C/ckks_ks.hip $C/ckks_csprng.hip $C/ckks_ops.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC "$@" -o $OUT/lib_$NAME.so $C/ckks_hip.hip $C/ckks_ntt.hip $C/ckks_fused.hip $C/ckks_ks.hip $C/ckks_csprng.hip $C/ckks_ops.hip $C/ckks_w30.hip
 [ "$REV" != "-" ] && rm -rf $SRC
 echo built $OUT/lib_$NAME.so
