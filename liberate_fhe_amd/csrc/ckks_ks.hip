@@ -274,6 +274,28 @@ __device__ __forceinline__ void ks_ext_cols_body(int b, const i64 *__restrict__ 
         // the digit loop is a RUNTIME loop with wave-uniform constants (scalar loads): at most R loads in flight beside the
         // R accumulated words — the unrolled form kept 8 x R loads alive (90 VGPRs at R = 16, measured slower at logN 16)
         double x[R];
+        // Horner form (desc[p][1] >> 16 = offset of the table of the digit's OWN primes m_i mod q_r behind the L table, 0: none):
+        //     y_0 + L_0 y_1 + L_1 y_2 + ..  =  y_0 + m_0 (y_1 + m_1 (y_2 + ..)),   L_i = m_0 .. m_i
+        // alpha - 1 modular products per word instead of alpha (the first constant of the sum form is 1: a wasted product)
+        const int hoff = __builtin_amdgcn_readfirstlane((int)(desc[p * 3 + 1] >> 16));
+        if (!wide && hoff != 0) {
+            {
+                const i64 *rowl = src + ((i64)(alpha - 1) << kg.logN);
+#pragma unroll
+                for (int k = 0; k < R; ++k) x[k] = dp_from_signed(rowl[((i64)k << logC) + lane]);
+            }
+            for (int i = alpha - 2; i >= 0; --i) {
+                const double mi = Ed[hoff + e_off + (i64)i * kg.rows];
+                const i64 *rowi = src + ((i64)i << kg.logN);   // wave-uniform (scalar base + lane offset in the loads below)
+#pragma unroll
+                for (int k = 0; k < R; ++k)   // |x| < 2^44 throughout: balanced product (< q / 2) + a signed digit word (< 2^43)
+                    x[k] = dp_from_signed(rowi[((i64)k << logC) + lane]) + dp_mulmod_bal(x[k], mi, c.d);
+            }
+            cols_fwd_stages<ArithDpR, K>(x, c);
+#pragma unroll
+            for (int k = 0; k < R; ++k) KS_ST(uniform_row(dst, (i64)k << logC) + lane, dp_to_word(dp_reduce(x[k], c.d.q, c.d.qinv)));
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < R; ++k) x[k] = 0.0;
         for (int i = 0; i < alpha; ++i) {

@@ -101,6 +101,9 @@ class ckks_engine(EvaluatorOps):
         # a rank of a limb-sharded op replays its fixed-address launches from HIP graphs (see _sharded_segments); LF_ENGINE_GRAPHS=0
         # keeps every launch eager
         self.graph_sharded = os.environ.get("LF_ENGINE_GRAPHS", "1") != "0"
+        # the column-form extension of the key switch in Horner form (one product per word fewer; _ks_tables); False keeps the
+        # sum over L_{i-1} y_i — same residues either way (tools/ab_engines.py times one against the other)
+        self.ks_horner = True
         self._lane_streams = {}
         self._check_kernel_limits()
 
@@ -1181,8 +1184,18 @@ class ckks_engine(EvaluatorOps):
                 for i in range(len(primes)):
                     plain += [float(L % ctx.q[r]) for r in dest]
                     L *= ctx.q[primes[i]]
+            # behind them, at the same offsets, the digit's own primes m_i mod q_r: the column-form extension evaluates
+            # y_0 + m_0 (y_1 + m_1 (..)) — one product per word fewer than the sum over L_{i-1} y_i (ckks_ks.hip); the offset
+            # of this second table travels in the descriptor (bits 16.. of the alpha word; 0 = no such table)
+            horner = []
+            for s_, (_, rows, primes) in enumerate(order):
+                for i in range(len(primes)):
+                    horner += [float(ctx.q[primes[i]] % ctx.q[r]) for r in dest]
+            if self.ks_horner:
+                for row in desc:
+                    row[1] |= len(plain) << 16
             tabs[("extend", d)] = (self._t64(desc, d), self._t64(flat, d),
-                                   torch.tensor(plain, dtype=torch.float64, device=self.ntt.devices[d]))
+                                   torch.tensor(plain + horner, dtype=torch.float64, device=self.ntt.devices[d]))
             # (3) P_j^-1 R table, [K][rows]
             K, nrows = self.ntt.num_special_primes, len(dest)
             pir = torch.zeros((K, nrows), dtype=torch.int64, device=self.ntt.devices[d])

@@ -543,6 +543,30 @@ def test_product_digits_inside_the_last_inverse_pass_equal_the_two_launches(para
     assert outs[0] == outs[1] == outs[2]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("params", [dict(logN=13, num_scales=9, num_special_primes=2, is_secured=False), dict(logN=15, num_special_primes=2),
+                                    dict(logN=16, num_special_primes=4), dict(logN=13, scale_bits=45, num_scales=6, num_special_primes=4, is_secured=False)])
+def test_key_switch_extension_in_horner_form_equals_the_sum_form(params):
+    """The column-form extension evaluates y_0 + m_0 (y_1 + m_1 (..)) over the digit's own primes (engine.ks_horner, the
+    default: one modular product per word fewer) or the sum over L_{i-1} y_i: same words from cc_mult, rotate and the batches."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    outs = []
+    for horner in (True, False):
+        eng = ckks_engine(devices=["cuda:0"], **params)
+        eng.ks_horner = horner
+        evk, rotk = synth.key_switch_key(eng, 5), synth.key_switch_key(eng, 6, origin="rotation key:3")
+        res = []
+        for level in (0, 2):
+            a, b = synth.ciphertext(eng, 50 + level, level), synth.ciphertext(eng, 60 + level, level)
+            res += [eng.cc_mult(a, b, evk), eng.rotate_single(a, rotk)]
+            res += eng.rotate_single_batch([a, b, a, b, a], rotk) + eng.cc_mult_batch([(a, b), (b, a), (a, a)], evk)
+        outs.append([digest(x) for x in res])
+        tabs = eng._ks_tables(0)
+        assert bool(int(tabs[("extend", 0)][0][0, 1]) >> 16) == horner      # the descriptor carries the second table's offset
+        del eng
+    assert outs[0] == outs[1]
+
+
 def _reference_shaped_switcher(eng, a, ksk, level):
     """create_switcher as the reference composes it from its step methods (eng.py:746-904) on ONE device: digits per part,
     extension + NTT + key products per part, sums, inverse transform, division by P through the checker's chain."""
