@@ -512,11 +512,17 @@ class ckks_engine(EvaluatorOps):
         reads (a second tensor of the raw pack's size: gold ~ 430 MB per key, a Galois key set 15 x that).  Either is
         rebuilt on the key's next use and dropped when the key's tensors die."""
         hit = self._key_packs.get(id(self._key_anchor(ksk)))
+        dropped = []
         if hit is not None and hit.get("own"):
-            hit.pop("planes", None)
+            dropped = hit.pop("planes", None) or []
             hit.pop("planes_ver", None)
         else:
-            self._key_packs.pop(id(self._key_anchor(ksk)), None)
+            gone = self._key_packs.pop(id(self._key_anchor(ksk)), None)
+            dropped = (gone or {}).get("packs", [])
+        # captured segments of a sharded rank hold the pack they were captured on (its address is baked into the graphs)
+        ptrs = {t.data_ptr() for t in dropped}
+        for k in [k for k in self._tables if isinstance(k, tuple) and k and k[0] == "sgraph" and k[5] in ptrs]:
+            del self._tables[k]
 
     def invalidate_key(self, ksk):
         """Tell the engine that a key's words were changed behind torch's back (a write through a raw pointer does not move

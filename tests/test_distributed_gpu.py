@@ -58,7 +58,7 @@ def test_two_ranks_on_one_gpu_reproduce_reference_digests():
             assert _digest(got[name][comp]) == rec["sha256"], (name, comp)
 
 
-def _gold_worker(rank, world, port, outdir):
+def _gold_worker(rank, world, port, outdir, exchange="p2p"):
     warnings.filterwarnings("ignore")
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -71,7 +71,7 @@ def _gold_worker(rank, world, port, outdir):
     from liberate_fhe_amd.fhe.comm import DistComm
     from liberate_fhe_amd.utils import synth
     params = {k: v for k, v in presets.params["gold"].items() if k != "devices"}
-    eng = ckks_engine(devices=["cuda:0"], comm=DistComm(local_device="cuda:0"), **params)
+    eng = ckks_engine(devices=["cuda:0"], comm=DistComm(local_device="cuda:0", exchange=exchange), **params)
     a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
     evk = synth.key_switch_key(eng, 5)
     rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
@@ -89,15 +89,17 @@ def _gold_worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_gold_fused_exchange_equals_one_process_two_devices():
+@pytest.mark.parametrize("exchange", ["p2p", "allgather"])
+def test_two_ranks_gold_fused_exchange_equals_one_process_two_devices(exchange):
     """BASELINE configs[3] in miniature: gold limb-sharded over 2 ranks.  The digits travel group by group and
     each group is extended + transformed as it lands (lf_ks_fwd), the tail (lf_ks_tail) runs once — against one
-    process driving two logical devices, which runs the undivided lf_ks_core on the same shards."""
+    process driving two logical devices, which runs the undivided lf_ks_core on the same shards.  Both forms of the digit
+    exchange (point-to-point batch; one padded all-gather on device buffers), eager launches and graph replay."""
     from liberate_fhe_amd.fhe import ckks_engine, presets
     from liberate_fhe_amd.utils import synth
-    port = 30700 + (os.getpid() % 1000)
+    port = 30700 + (os.getpid() % 1000) + (40 if exchange != "p2p" else 0)
     with tempfile.TemporaryDirectory() as outdir:
-        mp.spawn(_gold_worker, args=(2, port, outdir), nprocs=2, join=True)
+        mp.spawn(_gold_worker, args=(2, port, outdir, exchange), nprocs=2, join=True)
         got = {f: np.load(os.path.join(outdir, f)) for f in os.listdir(outdir)}
     params = {k: v for k, v in presets.params["gold"].items() if k != "devices"}
     eng = ckks_engine(devices=["cuda:0", "cuda:0"], **params)
