@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(NTT_COL_THREADS) ntt_inv_cols_digits(const i64
     const int alpha = __builtin_amdgcn_readfirstlane((int)desc[p * 4 + 1]);
     const i64 *Y = tab + desc[p * 4 + 2];
     const i64 *Ls = tab + desc[p * 4 + 3];
+    if (alpha > AMAX) __builtin_trap();   // a digit wider than the caller's max_alpha: a broken table must not pass for a result
     i64 x[AMAX][R];
 #pragma unroll
     for (int i = 0; i < AMAX; ++i) {
