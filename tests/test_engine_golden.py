@@ -492,6 +492,40 @@ def test_key_planes_format_words_and_results():
 
 
 @pytest.mark.gpu
+def test_release_and_invalidate_key_after_a_write_behind_torchs_back():
+    """A write into a key through a raw pointer (a native kernel on data_ptr) moves no torch version counter: the engine's
+    packed / planes copy of the key is stale until invalidate_key(); release_key drops the copy (rebuilt on the next use) —
+    for a foreign key and for a key the engine made."""
+    from liberate_fhe_amd._native import lib, check
+    from liberate_fhe_amd.fhe import ckks_engine
+    params = dict(logN=13, num_scales=9, num_special_primes=2, is_secured=False)
+    eng = ckks_engine(devices=["cuda:0"], **params)
+    a = synth.ciphertext(eng, 50, 0)
+    rows, N = eng.ntt.stops[0][0], eng.ctx.N
+    q2 = eng.ntt._2q[0]
+    st = torch.cuda.current_stream().cuda_stream
+    for make in (lambda: synth.key_switch_key(eng, 6, origin="rotation key:3"),
+                 lambda: eng.create_rotation_key(eng.create_secret_key(), 3)):
+        key = make()
+        before = digest(eng.rotate_single(a, key))
+        t = key.data[0].data[0][0]                       # part 0, component b, device 0: [rows, N] lazy words
+        ver = t._version
+        c = eng._consts(0, 0, True)
+        Rs = eng._vec("Rs", 0, 0, True)
+        check(lib.lf_mont_enter(t.data_ptr(), Rs.data_ptr(), t.size(0), N, *c.mont(), 0, st), "lf_mont_enter")   # every word x R: other residues
+        assert t._version == ver                         # .. and torch saw nothing
+        stale = digest(eng.rotate_single(a, key))
+        assert stale == before                           # the engine still reads its packed / planes copy: it cannot know
+        eng.invalidate_key(key)
+        fresh = digest(eng.rotate_single(a, key))
+        assert fresh != before                           # rebuilt from the key's tensors as they are now
+        eng.release_key(key)
+        assert digest(eng.rotate_single(a, key)) == fresh    # dropped and rebuilt once more: same words
+        key.data[0].data[1][0][0, 0:8] += 1              # a counted edit: this one the engine sees by itself
+        assert digest(eng.rotate_single(a, key)) != fresh
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("params", [dict(logN=13, num_scales=9, num_special_primes=2, is_secured=False),
                                     dict(logN=14, num_special_primes=1), dict(logN=13, scale_bits=45, num_scales=6, num_special_primes=2, is_secured=False)])
 def test_one_launch_moddown_equals_the_two_launch_form(params):
