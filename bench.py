@@ -558,7 +558,70 @@ def comm_prepare(dev, world, rank, local_rank, grp=None):
              "p2p_warmup_s": time.perf_counter() - t0, "p2p_warmup_all_pairs_ok": ok,
              "transport": "RCCL point-to-point batches (ncclGroup of send / recv) over xGMI" if "nccl" in str(dist.get_backend(grp))
                           else "gloo + host staging (REHEARSAL transport, tests/gloo_device_p2p.py)"}
+    block["selftest"] = comm_selftest(grp, dev, world, rank)
     return grp, block
+
+
+def comm_selftest(grp, dev, world, rank):
+    """The communication PATTERNS of the limb-sharded engine once each on small device buffers, with checked contents, before
+    any engine runs — so that a first contact with RCCL that goes wrong is attributed to a pattern, not to "cc_mult hung":
+      fanout      one owner sends one buffer to every other rank in ONE batch (the rescale row, comm.fanout_into);
+      unequal     an all-pairs batch whose messages differ in size per owner (runs of digits: 7 rows from rank 0, 4 from the rest);
+      subset      the same among the first world - 1 ranks only, the last rank sitting it out (levels where a rank has no rows);
+      allgather   one padded all-gather into a flat tensor (DistComm(exchange="allgather")).
+    Every rank learns every verdict (a MIN over ranks on the default group)."""
+    import torch.distributed as dist
+    from liberate_fhe_amd.fhe.comm import DistComm
+    out = {}
+    comm = DistComm(group=grp, local_device=dev)
+    W = 256
+
+    def verdict(name, fn):
+        t0 = time.perf_counter()
+        try:
+            ok = bool(fn())
+            err = None
+        except Exception as e:
+            ok, err = False, f"{type(e).__name__}: {e}"[:200]
+        torch.cuda.synchronize()
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        out[name] = {"ok_on_every_rank": bool(int(flag.item())), "ms": round(1e3 * (time.perf_counter() - t0), 2)}
+        if err:
+            out[name]["error_on_this_rank"] = err
+
+    def fanout():
+        buf = torch.full((4, W), 7 if rank == 0 else -1, dtype=torch.int64, device=dev)
+        comm.fanout_into(buf, 0, list(range(world)))
+        torch.cuda.synchronize()
+        return (buf == 7).all().item()
+
+    def exchange(peers, form):
+        rows = [7 if r == 0 else 4 for r in range(len(peers))]
+        starts = [sum(rows[:i]) for i in range(len(peers))]
+        buf = torch.full((sum(rows), W), -1, dtype=torch.int64, device=dev)
+        pieces = [(r, starts[i], rows[i]) for i, r in enumerate(peers)]
+        if rank in peers:
+            i = peers.index(rank)
+            buf[starts[i]:starts[i] + rows[i]] = 100 + rank
+        c = comm if form == "p2p" else DistComm(group=grp, local_device=dev, exchange="allgather")
+        if rank not in peers and form == "p2p":
+            return True                                    # takes no part in the point-to-point form
+        c.exchange_rows(buf if rank in peers else None, pieces, peers, width=W).wait()
+        torch.cuda.synchronize()
+        if rank not in peers:
+            return True
+        want = torch.cat([torch.full((rows[i], W), 100 + r, dtype=torch.int64, device=dev) for i, r in enumerate(peers)])
+        return torch.equal(buf, want)
+
+    verdict("fanout", fanout)
+    verdict("unequal_all_pairs", lambda: exchange(list(range(world)), "p2p"))
+    if world > 2:
+        verdict("subset_without_last_rank", lambda: exchange(list(range(world - 1)), "p2p"))
+    verdict("allgather_padded", lambda: exchange(list(range(world)), "allgather"))
+    if world > 2:
+        verdict("allgather_with_idle_rank", lambda: exchange(list(range(world - 1)), "allgather"))
+    return out
 
 
 def link_bytes(eng, level):
