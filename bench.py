@@ -316,7 +316,7 @@ def engine_rates(dev, quick):
 
 
 def ntt_rates_preset(name, dev, batch, iters=20):
-    """BASELINE's metric is quoted at logN 15 AND 16: forward (lf_ntt = ntt_cuda.ntt, exact lazy words) and inverse (lf_intt
+    """BASELINE's metric is quoted at logN 15 AND 16: forward (lf_ntt_ws = ntt_cuda.ntt, exact lazy words; logN 17: lf_ntt) and inverse (lf_intt
     with tail 2 = ntt_cuda.intt_exit_reduce) transforms of `batch` polynomials x EVERY limb of the preset's chain (special
     primes included: silver 19, gold 39, platinum 59+) through the C ABI, inputs resident in HBM, each with its roofline
     block (16 N bytes per limb-NTT).  Outside the headline's timed region; N = 1 only."""
@@ -338,9 +338,11 @@ def ntt_rates_preset(name, dev, batch, iters=20):
     dp, idp = twiddles.dp_pointer(psi, ql, qh, kl, kh, d, st), twiddles.dp_pointer(ipsi, ql, qh, kl, kh, d, st)
     q_host = np.array(ctx.q, dtype=np.int64)
 
+    ws = torch.empty((int(lib.lf_ntt_ws_words(batch, L, logN)),), dtype=torch.int64, device=dev)   # as ntt_cuda.ntt keeps one
+
     def fwd():
-        check(lib.lf_ntt(x.data_ptr(), batch, L, logN, psi.data_ptr(), dp, q_host.ctypes.data, 0, 0, q2.data_ptr(), ql.data_ptr(),
-                         qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), d, st), "lf_ntt")
+        check(lib.lf_ntt_ws(x.data_ptr(), ws.data_ptr(), batch, L, logN, psi.data_ptr(), dp, q_host.ctypes.data, 0, 0, ql.data_ptr(),
+                            qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), d, st), "lf_ntt_ws")
 
     def inv():
         check(lib.lf_intt(x.data_ptr(), batch, L, logN, ipsi.data_ptr(), idp, q_host.ctypes.data, ninv.data_ptr(), 2, 0, q2.data_ptr(),
@@ -892,9 +894,21 @@ def main():
 
     ntt_flags = int(os.environ.get("LF_BENCH_NTT_FLAGS", "0"))   # experiments only: 1 = relaxed transform (not the metric)
 
-    def step():
+    # The transform goes through a workspace (lf_ntt_ws, include/ckks_hip.h: the two passes exchange the fp64-class limbs as
+    # 6-byte planes instead of 8-byte words; same result words on any input) — what ntt_cuda.ntt does for a caller; the
+    # workspace is resident like the operands.  LF_BENCH_NTT_INPLACE=1: the strictly in-place lf_ntt instead (experiments).
+    in_place = os.environ.get("LF_BENCH_NTT_INPLACE", "0") == "1" or ntt_flags != 0
+    ws = None if in_place else torch.empty((int(lib.lf_ntt_ws_words(B, L_LIMBS, LOGN)),), dtype=torch.int64, device=dev)
+
+    def step_in_place():
         check(lib.lf_ntt(x.data_ptr(), B, L_LIMBS, LOGN, psi.data_ptr(), psi_dp, q_host.ctypes.data, 0, ntt_flags, q2.data_ptr(), ql.data_ptr(),
                          qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), local_rank, stream), "lf_ntt")
+
+    def step_ws():
+        check(lib.lf_ntt_ws(x.data_ptr(), ws.data_ptr(), B, L_LIMBS, LOGN, psi.data_ptr(), psi_dp, q_host.ctypes.data, 0, 0, ql.data_ptr(),
+                            qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), local_rank, stream), "lf_ntt_ws")
+
+    step = step_in_place if in_place else step_ws
 
     for _ in range(args.warmup):
         step()
@@ -963,9 +977,14 @@ def main():
     n_roof = max(100, 2 * args.steps)      # >= 100 timed launches of the dominant kernel
 
     def one_pass(which):
+        if ws is not None:
+            check(lib.lf_ntt_pass_ws(x.data_ptr(), ws.data_ptr(), B, L_LIMBS, LOGN, psi.data_ptr(), psi_dp, q_host.ctypes.data, 0, 0, which,
+                                     ql.data_ptr(), qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), local_rank, stream), "lf_ntt_pass_ws")
+            return
         check(lib.lf_ntt_pass(x.data_ptr(), B, L_LIMBS, LOGN, psi.data_ptr(), psi_dp, q_host.ctypes.data, 0, ntt_flags, which,
                               ql.data_ptr(), qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), local_rank, stream), "lf_ntt_pass")
 
+    one_pass(1)                            # (through a workspace the tiled pass reads what a column pass left there)
     for _ in range(3):
         one_pass(2)
     torch.cuda.synchronize()
@@ -1082,7 +1101,9 @@ def main():
         # one polynomial of one more (untimed) step, an integer-class and an fp64-class limb, word for word vs the C oracle
         "parity_spot_check": spot,
         "config": {"workload": f"gold preset (logN=16), rows {lo}..{total - 1} of the prime chain (25 scale + base + 4 special"
-                               f" primes = 30 limbs), {B} polynomials per GPU per step, forward NTT via lf_ntt (C ABI)",
+                               f" primes = 30 limbs), {B} polynomials per GPU per step, forward NTT via "
+                               + ("lf_ntt (C ABI, strictly in place)" if in_place else "lf_ntt_ws (C ABI: lf_ntt through a resident workspace of the operands' size)"),
+                   "workspace_bytes": None if ws is None else int(ws.numel()) * 8,
                    "batch_per_gpu": B, "limbs": L_LIMBS, "logN": LOGN, "parallelism": f"replicas x{world} (independent polynomials)",
                    # repeated here because drivers keep `config` verbatim: "ok" = the timed kernel's words equal the oracle's
                    "parity_spot_check": spot},
@@ -1093,7 +1114,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "issue_frac": valu_busy, "traffic": traffic,
                      "issue_ceiling_frac": None if issue_ceiling is None else issue_ceiling["kernel_frac"],
                      "issue_ceiling": issue_ceiling,
-                     "kernel": "ntt_pass16_fwd_seq<false> (tiled pass = 12 of 16 stages, 16 words per thread, 8 tiles per block, all 30 limbs: 5 integer-class + 25 fp64-class)",
+                     "kernel": ("ntt_pass16_fwd_seq<false>" if in_place else "ntt_pass16_fwd_seq_ws") + " (tiled pass = 12 of 16 stages, 16 words per thread, 8 tiles per block, all 30 limbs: 5 integer-class + 25 fp64-class)",
                      "launches_per_transform": 2, "avg_launch_ms": k_ms, "launches_timed": n_roof,
                      "column_pass_launch_ms": cols_ms,
                      "column_pass_algorithmic_GBps": alg_bytes_per_launch / (cols_ms * 1e-3) / 1e9,
@@ -1117,6 +1138,11 @@ def main():
     if rehearse:
         extra["REHEARSAL"] = "all ranks on cuda:0 over gloo: not a measurement"
     if rank == 0 and world == 1 and not args.no_extra:
+        if ws is not None:      # the same step strictly in place (lf_ntt), for the record of what the workspace buys
+            for _ in range(3):
+                step_in_place()
+            torch.cuda.synchronize()
+            extra["poly_ntt_per_s_in_place_lf_ntt"] = B / (event_time_ms(step_in_place, max(10, args.steps // 2)) * 1e-3)
         # Sensitivity of the headline to the limb mix (NOT the metric): the same step on the 30 limbs of a level-5
         # ciphertext — 29 scale primes + the base prime, no special primes, i.e. 1 integer-class limb instead of 5.
         lo_ct = total - 4 - L_LIMBS
@@ -1129,6 +1155,10 @@ def main():
             x[b] = torch.from_numpy(synth.uniform_rows(5000 + b, rows_ct, ctx.q, N, lazy=True)).to(dev)
 
         def step_ct():
+            if ws is not None:
+                check(lib.lf_ntt_ws(x.data_ptr(), ws.data_ptr(), B, L_LIMBS, LOGN, psi_c.data_ptr(), dp_c, qh_ct.ctypes.data, 0, 0,
+                                    ql_c.data_ptr(), qh_c.data_ptr(), kl_c.data_ptr(), kh_c.data_ptr(), local_rank, stream), "lf_ntt_ws")
+                return
             check(lib.lf_ntt(x.data_ptr(), B, L_LIMBS, LOGN, psi_c.data_ptr(), dp_c, qh_ct.ctypes.data, 0, 0, q2_c.data_ptr(),
                              ql_c.data_ptr(), qh_c.data_ptr(), kl_c.data_ptr(), kh_c.data_ptr(), local_rank, stream), "lf_ntt")
         for _ in range(5):
@@ -1140,7 +1170,7 @@ def main():
                                           " reported for the limb-mix sensitivity only, the metric above keeps its 5 integer-class limbs")
         # the other halves of BASELINE's metric ("NTTs/sec at logN = 15, 16"): every limb of the silver chain at logN 15, the
         # whole gold chain incl. the inverse chain, and the reference's largest preset — each with its own roofline block
-        x = None      # the headline's stack (3.75 GiB) is not needed any more
+        x = ws = None      # the headline's stack and workspace are not needed any more
         torch.cuda.empty_cache()
         ntt_presets = {}
         for pname, pbatch in (("silver", 256), ("gold", 96), ("platinum", 24)):

@@ -35,7 +35,7 @@ extern "C" {
 #define LF_ERR_ARG 10001
 
 /* Library probe: returns the ABI version (currently LF_ABI_VERSION; __graft_entry__.build() asserts it). */
-#define LF_ABI_VERSION 13
+#define LF_ABI_VERSION 14
 int lf_abi_version(void);
 
 /* Compile-time capacities of the fused kernels, so that callers can refuse a parameter set BEFORE any launch
@@ -57,9 +57,15 @@ int lf_limits(int which);
  *                             column kernel (one register step per column, no LDS); above it the LDS-tiled form.
  *   LF_TUNE_INTT_DIGITS       1 (default): lf_cc_mult_evk(_batch / _pre) form the digits of x1 * y1 inside the last inverse pass
  *                             where a digit's limbs fit a column thread (lf_intt_mul_digits); 0: always the two launches.
+ *   LF_TUNE_DIGIT_PLANES      1 (default): between the halves of a key switch (lf_ks_fwd -> lf_ks_tail and every entry built on
+ *                             them) the fp64-class rows of the scratch `tmp` hold their words as two planes, 6 bytes per word
+ *                             (u32 low[N], u16 high[N] behind them) instead of 8, wherever the column kernel extends and the
+ *                             limbs are of both classes; 0: raw words.  `tmp` is scratch either way; the knob must not change
+ *                             between an lf_ks_fwd and its lf_ks_tail.
  *   (knob 0 was the one-launch key-switch transform of round 3: slower at every preset size on MI355X, removed.) */
 #define LF_TUNE_KS_EXT_COLS_MAX 1
 #define LF_TUNE_INTT_DIGITS 2
+#define LF_TUNE_DIGIT_PLANES 3
 int lf_tune(int which, int value);
 
 /* Measurement entry (not one of the reference's ops; the engine never calls it): ONE wave, launched on `stream`, takes
@@ -145,6 +151,24 @@ int lf_twiddle_dp(const int64_t *mont, double *out, int rows, int64_t N, const i
 int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
            const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *_2q, const int64_t *ql,
            const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
+
+/* lf_ntt through a caller-provided WORKSPACE (exact transforms; same result words as lf_ntt, `a` in place).  The two passes
+ * of a logN >= 13 transform hand every word over through HBM; with a workspace the column pass leaves the words of the
+ * fp64-class limbs (primes below 2^41: lazy words below 2^42) there as 6-byte planes instead of 8-byte words and the tiled
+ * pass reads those — 12.5 % fewer bytes per pass; operands outside [0, 2q), whose words can be anything, travel with a third
+ * plane and a flag per column wave, so the reference's result on ANY int64 input is reproduced as by lf_ntt.
+ * ws: lf_ntt_ws_words(batch, rows, logN) words of device memory, 16-byte aligned, contents irrelevant before and scratch
+ * after; it must not be used by another stream while the call runs.  ws = NULL, logN <= 12 or > 16: lf_ntt.  The reference's
+ * ntt (ntt.cpp:421-437) allocates nothing because it makes logN passes in place; the workspace is this design's price for
+ * making two.  LF_NTT_RELAXED: LF_ERR_ARG. */
+int64_t lf_ntt_ws_words(int batch, int rows, int logN);
+int lf_ntt_ws(int64_t *a, int64_t *ws, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
+              const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+              const int64_t *kh, int device, void *stream);
+/* (measurement, as lf_ntt_pass: one of the two launches of lf_ntt_ws; which = 1 reads `a` and writes `ws`, 2 the reverse) */
+int lf_ntt_pass_ws(int64_t *a, int64_t *ws, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
+                   const int64_t *q_host, const int64_t *Rs, int flags, int which, const int64_t *ql, const int64_t *qh,
+                   const int64_t *kl, const int64_t *kh, int device, void *stream);
 
 /* Measurement entry (not one of the reference's ops; the engine never calls it): launch exactly ONE of the two
  * pass kernels of a two-pass forward transform (logN >= 13) with the grid it has inside lf_ntt —

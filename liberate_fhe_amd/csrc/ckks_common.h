@@ -140,6 +140,15 @@ static __device__ __forceinline__ i64 dp_to_word(double d) {
     return __double_as_longlong(d + DP_MAGIC) & 0x000FFFFFFFFFFFFFll;
 }
 
+// a word below 2^48 kept as two PLANES (low 32 bits | high 16 bits: 6 bytes instead of 8, lf_key_planes and the extended
+// digits of a key switch): the double is assembled in registers — exponent | high half in the upper dword, the low word
+// below, minus 2^52 — for the price of the raw word's conversion
+static __device__ __forceinline__ double dp_from_planes(unsigned lo, unsigned hi16) {
+    return __longlong_as_double((i64)(((u64)(0x43300000u | hi16) << 32) | (u64)lo)) - DP_MAGIC;
+}
+typedef unsigned lf_u4_t __attribute__((ext_vector_type(4)));
+typedef unsigned lf_u2_t __attribute__((ext_vector_type(2)));
+
 // exact signed int -> double for |x| < 2^51: one 64-bit integer add and one fp64 add (the generic signed 64-bit
 // conversion costs ~9 instructions)
 static __device__ __forceinline__ double dp_from_signed(i64 x) {

@@ -39,6 +39,21 @@
         else *(p) = (v);                                             \
     } while (0)
 
+// the same word into a row in planes format (u32 low[N] at byte 0, u16 high[N] at byte 4 N); rowb = the row's first word
+#define KS_ST_PL(rowb, N, idx, v)                                                                          \
+    do {                                                                                                   \
+        const i64 v_ = (i64)(v);                                                                           \
+        unsigned *lo_ = uniform_ptr(reinterpret_cast<unsigned *>(rowb) + (idx));                           \
+        unsigned short *hi_ = uniform_ptr(reinterpret_cast<unsigned short *>((rowb) + ((N) >> 1)) + (idx)); \
+        if (NT_KS_EXT) {                                                                                   \
+            __builtin_nontemporal_store((unsigned)v_, lo_ + lane);                                         \
+            __builtin_nontemporal_store((unsigned short)(v_ >> 32), hi_ + lane);                           \
+        } else {                                                                                           \
+            lo_[lane] = (unsigned)v_;                                                                      \
+            hi_[lane] = (unsigned short)(v_ >> 32);                                                        \
+        }                                                                                                  \
+    } while (0)
+
 namespace {
 
 struct KsGeom {
@@ -53,6 +68,7 @@ struct KsGeom {
     // starting at p0) that limb r belongs to, 255 for the special limbs; nullptr: every (digit, limb) pair is extended
     const unsigned char *own;
     int p0;
+    int planes;      // fp64-class rows of tmp in planes format (digit_planes(), ckks_ntt_tile16.h fwd_tile16<.., PLN>)
 };
 
 // ---- K2: extend + strided NTT pass -----------------------------------------------------------------
@@ -268,7 +284,9 @@ __device__ __forceinline__ void ks_ext_cols_body(int b, const i64 *__restrict__ 
     const i64 e_off = desc[p * 3 + 2] + crow;
     const unsigned lane = threadIdx.x;
     const i64 *src = state + (i64)ctu * kg.state_stride + (i64)row_start * kg.N + chunk * NTT_COL_THREADS;
-    i64 *dst = tmp + ((((i64)ctu * kg.nparts + p) * kg.rows + crow) << kg.logN) + chunk * NTT_COL_THREADS;
+    i64 *rowb = tmp + ((((i64)ctu * kg.nparts + p) * kg.rows + crow) << kg.logN);
+    const i64 col0 = (i64)chunk * NTT_COL_THREADS;
+    i64 *dst = rowb + col0;
 
     if (DP) {
         // the digit loop is a RUNTIME loop with wave-uniform constants (scalar loads): at most R loads in flight beside the
@@ -292,6 +310,11 @@ __device__ __forceinline__ void ks_ext_cols_body(int b, const i64 *__restrict__ 
                     x[k] = dp_from_signed(rowi[((i64)k << logC) + lane]) + dp_mulmod_bal(x[k], mi, c.d);
             }
             cols_fwd_stages<ArithDpR, K>(x, c);
+            if (kg.planes) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) KS_ST_PL(rowb, kg.N, col0 + ((i64)k << logC), dp_to_word(dp_reduce(x[k], c.d.q, c.d.qinv)));
+                return;
+            }
 #pragma unroll
             for (int k = 0; k < R; ++k) KS_ST(uniform_row(dst, (i64)k << logC) + lane, dp_to_word(dp_reduce(x[k], c.d.q, c.d.qinv)));
             return;
@@ -315,6 +338,11 @@ __device__ __forceinline__ void ks_ext_cols_body(int b, const i64 *__restrict__ 
             }
         }
         cols_fwd_stages<ArithDpR, K>(x, c);          // |x| < alpha * q on the way in (balanced terms)
+        if (kg.planes) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) KS_ST_PL(rowb, kg.N, col0 + ((i64)k << logC), dp_to_word(dp_reduce(x[k], c.d.q, c.d.qinv)));
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < R; ++k) KS_ST(uniform_row(dst, (i64)k << logC) + lane, dp_to_word(dp_reduce(x[k], c.d.q, c.d.qinv)));
     } else {
@@ -388,12 +416,6 @@ __global__ void __launch_bounds__(NTT_COL_THREADS) __attribute__((amdgpu_waves_p
 // count of the raw kernel (a first version with four coefficients per thread and per-component planes read 25 % fewer key
 // bytes at 96 .. 256 VGPRs and was no faster).  The double is assembled in registers — exponent | high word in the upper
 // dword, the low word below, minus 2^52 — for the price of the raw word's conversion.  Same sums modulo q: same outputs.
-__device__ __forceinline__ double dp_from_planes(unsigned lo, unsigned hi16) {
-    return __longlong_as_double((i64)(((u64)(0x43300000u | hi16) << 32) | (u64)lo)) - DP_MAGIC;
-}
-typedef unsigned lf_u4_t __attribute__((ext_vector_type(4)));
-typedef unsigned lf_u2_t __attribute__((ext_vector_type(2)));
-
 // lf_key_planes: one row pair per blockIdx.y, two coefficients per thread
 __global__ void __launch_bounds__(256) key_planes_kernel(const i64 *__restrict__ src_b, const i64 *__restrict__ src_a,
                                                          i64 *__restrict__ dst_b, i64 *__restrict__ dst_a, i64 N,
@@ -461,12 +483,12 @@ struct RelinFold {
     const unsigned char *own;
 };
 
-template <int NCT, bool FOLD, bool PLANES>
-__global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ ext, const i64 *__restrict__ ksk,
+template <int NCT, bool FOLD, bool PLANES, bool DPL>   // DPL: fp64-class rows of `ext` in planes format (digit_planes())
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCT == 4 ? 5 : 1))) ks_inner2_kernel(const i64 *__restrict__ ext, const i64 *__restrict__ ksk,
                                                         i64 part_stride, i64 comp_stride, i64 row_off, i64 *__restrict__ s,
-                                                        int nparts, int rows, i64 N, RelinFold fold, const i64 *__restrict__ ql,
-                                                        const i64 *__restrict__ qh, const i64 *__restrict__ kl,
-                                                        const i64 *__restrict__ kh) {
+                                                        int nparts, int rows, i64 N, RelinFold fold,
+                                                        const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                        const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
     // each thread owns KI_V 16-byte column pairs 4 KiB apart: every block streams KI_V x 4 KiB contiguous runs
     // from 3 x nparts arrays, enough bytes in flight to keep HBM busy
     constexpr int KI_V = KI_COLS;
@@ -484,6 +506,7 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
 #pragma unroll
         for (int t = 0; t < NCT; ++t) acc[t][0][0] = acc[t][0][1] = acc[t][1][0] = acc[t][1][1] = 0.0;
         const int p_own = (FOLD && fold.own != nullptr && r < fold.ell) ? (int)fold.own[r] : -1;
+        const unsigned bo_lo = (unsigned)j0 * 4u, bo_hi = (unsigned)j0 * 2u;   // DPL: byte offsets of the thread's pair in the planes
         longlong2 xo[NCT];   // the own digit's words: x1 * y1, plain canonical
         if (p_own >= 0) {
 #pragma unroll
@@ -492,14 +515,32 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
                 const longlong2 X1 = *reinterpret_cast<const longlong2 *>(xs), Y1 = *reinterpret_cast<const longlong2 *>(xs + 2 * (i64)fold.ell * N);
                 xo[t].x = dp_to_word(dp_mulmod(dp_from_word(X1.x), dp_from_word(Y1.x), d));
                 xo[t].y = dp_to_word(dp_mulmod(dp_from_word(X1.y), dp_from_word(Y1.y), d));
+                if constexpr (DPL) {   // in the register form of a pair read from the planes: one conversion for every digit
+                    const u64 a = (u64)xo[t].x, b = (u64)xo[t].y;
+                    xo[t].x = (i64)((a & 0xffffffffull) | (b << 32));
+                    xo[t].y = (i64)((a >> 32) | ((b >> 32) << 16));
+                }
             }
         }
 #pragma unroll KI_UNROLL
         for (int p = 0; p < nparts; ++p) {
-            longlong2 x[NCT];
+            longlong2 x[NCT];   // DPL: .x = the two low words, low half of .y = the two high halves (8 + 4 bytes, fwd_tile16<.., PLN>)
+            if constexpr (DPL) {   // SGPR row base + one per-thread byte offset per plane
 #pragma unroll
-            for (int t = 0; t < NCT; ++t)
-                x[t] = p == p_own ? xo[t] : *reinterpret_cast<const longlong2 *>(e + t * ct_ext + (i64)p * rows * N);
+                for (int t = 0; t < NCT; ++t) {
+                    const char *er = reinterpret_cast<const char *>(uniform_ptr(ext + (((i64)t * nparts + p) * rows + r) * N));
+                    if (p == p_own) {
+                        x[t] = xo[t];
+                    } else {
+                        x[t].x = *reinterpret_cast<const i64 *>(er + bo_lo);
+                        x[t].y = (i64)*reinterpret_cast<const unsigned *>(er + 4 * N + bo_hi);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NCT; ++t)
+                    x[t] = p == p_own ? xo[t] : *reinterpret_cast<const longlong2 *>(e + t * ct_ext + (i64)p * rows * N);
+            }
             double k0x, k0y, k1x, k1y;
             if (PLANES) {   // 16 + 8 bytes for both components (see lf_key_planes)
                 const i64 *kr = k - j0 + (i64)p * part_stride;
@@ -514,7 +555,14 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
             }
 #pragma unroll
             for (int t = 0; t < NCT; ++t) {
-                const double x0 = dp_from_word(x[t].x), x1 = dp_from_word(x[t].y);
+                double x0, x1;
+                if constexpr (DPL) {
+                    const unsigned h = (unsigned)x[t].y;
+                    x0 = dp_from_planes((unsigned)x[t].x, h & 0xffffu);
+                    x1 = dp_from_planes((unsigned)((u64)x[t].x >> 32), h >> 16);
+                } else {
+                    x0 = dp_from_word(x[t].x), x1 = dp_from_word(x[t].y);
+                }
                 acc[t][0][0] += dp_mulmod_bal(x0, k0x, d);
                 acc[t][0][1] += dp_mulmod_bal(x1, k0y, d);
                 acc[t][1][0] += dp_mulmod_bal(x0, k1x, d);
@@ -613,6 +661,16 @@ __global__ void __launch_bounds__(256) ks_inner2_kernel(const i64 *__restrict__ 
 // 3 110 -> 3 300 /s (tools/eo.py --ext-cols-max 3 | 4, one box); round 2's fully unrolled form had lost there (116 vs 95 us).
 int g_ks_ext_cols_max = 4;
 
+// The extended digits between ks_forward and ks_tail (tmp: scratch of the key switch, opaque to the caller) keep the
+// fp64-class rows in planes format — 6 bytes per word on each of their three trips — wherever the column kernel extends
+// (logN 13 .. 12 + g_ks_ext_cols_max) and both classes are present.  BOTH halves decide with this function: the knobs must
+// not change between an lf_ks_fwd and its lf_ks_tail (lf_tune is a start-up / A-B facility, see the header).
+int g_digit_planes = 1;
+bool digit_planes(int logN, const RowList &dp, const RowList &in) {
+    const int S1 = logN - NTT_TILE_LOG_MAX;
+    return g_digit_planes && S1 >= 1 && S1 <= g_ks_ext_cols_max && dp.n && in.n;
+}
+
 void classify_rows(int rows, const int64_t *q_host, RowList &dp, RowList &in) {
     dp.n = in.n = 0;
     for (int r = 0; r < rows; ++r) {
@@ -628,9 +686,10 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
                hipStream_t st, const unsigned char *own = nullptr, int p0 = 0) {
     if (!psi_dp) return LF_ERR_ARG;   // the relaxed arithmetic of both classes lives in the auxiliary table
     const int tl = NTT_TILE_LOG_MAX, S1 = logN - tl;
-    const KsGeom kg{logN, tl, S1, rows, nparts, (i64)1 << logN, nct, (i64)state_stride, own, p0};
     RowList dp, in;
     classify_rows(rows, q_host, dp, in);
+    const bool dplanes = digit_planes(logN, dp, in);
+    const KsGeom kg{logN, tl, S1, rows, nparts, (i64)1 << logN, nct, (i64)state_stride, own, p0, dplanes ? 1 : 0};
     const unsigned tiles = 1u << (logN - tl);
     const unsigned polys = (unsigned)nparts * (unsigned)nct;   // extended digits of all ciphertexts: one stack
     const bool mixed = dp.n && in.n;   // both arithmetic classes in one launch per step
@@ -665,7 +724,7 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
     {
         const PassGeom g{logN, tl, 0, tl, S1, 0, rows, (int)polys, 1, 1, 0, own, nparts, p0};
         launch_pass16(false, 1, (int)polys, st, (const i64 *)tmp, (i64 *)tmp, g, in, dp, (const i64 *)psi_br, psi_dp,
-                      (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+                      (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh, nullptr, dplanes);
     }
     return (int)hipGetLastError();
 }
@@ -687,22 +746,29 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
         const i64 N = (i64)1 << logN;
         dim3 grid((unsigned)((N + 512 * KI_COLS - 1) / (512 * KI_COLS)), (unsigned)rows);
         const RelinFold nofold{nullptr, 0, nullptr, 0, nullptr};
-#define LF_INNER_LAUNCH(NCT, FOLDB, PL, FOLDV)                                                                         \
-    hipLaunchKernelGGL((ks_inner2_kernel<NCT, FOLDB, PL>), grid, dim3(256), 0, st, (const i64 *)tmp, (const i64 *)ksk,     \
+#define LF_INNER_LAUNCH(NCT, FOLDB, PL, DPLB, FOLDV)                                                                   \
+    hipLaunchKernelGGL((ks_inner2_kernel<NCT, FOLDB, PL, DPLB>), grid, dim3(256), 0, st, (const i64 *)tmp, (const i64 *)ksk, \
                        (i64)part_stride, (i64)comp_stride, (i64)row_off, (i64 *)s, nparts, rows, N, FOLDV, (const i64 *)ql, \
                        (const i64 *)qh, (const i64 *)kl, (const i64 *)kh)
+#define LF_INNER_DPL(NCT, FOLDB, PL, FOLDV)                                                                            \
+    do {                                                                                                               \
+        if (dplanes) LF_INNER_LAUNCH(NCT, FOLDB, PL, true, FOLDV);                                                     \
+        else LF_INNER_LAUNCH(NCT, FOLDB, PL, false, FOLDV);                                                            \
+    } while (0)
 #define LF_INNER_CASE(NCT)                                                                                             \
     case NCT:                                                                                                          \
-        if (fold && planes) LF_INNER_LAUNCH(NCT, true, true, *fold);                                                   \
-        else if (fold) LF_INNER_LAUNCH(NCT, true, false, *fold);                                                       \
-        else if (planes) LF_INNER_LAUNCH(NCT, false, true, nofold);                                                    \
-        else LF_INNER_LAUNCH(NCT, false, false, nofold);                                                               \
+        if (fold && planes) LF_INNER_DPL(NCT, true, true, *fold);                                                      \
+        else if (fold) LF_INNER_DPL(NCT, true, false, *fold);                                                          \
+        else if (planes) LF_INNER_DPL(NCT, false, true, nofold);                                                       \
+        else LF_INNER_DPL(NCT, false, false, nofold);                                                                  \
         break;
         const bool planes = key_format == LF_KEY_PLANES;
+        const bool dplanes = digit_planes(logN, dp, in);
         switch (nct) {
             LF_INNER_CASE(1) LF_INNER_CASE(2) LF_INNER_CASE(4)
         }
 #undef LF_INNER_LAUNCH
+#undef LF_INNER_DPL
 #undef LF_INNER_CASE
     }
     // K4: inverse transform -> canonical coefficients (relaxed, tail 2), in place on s
@@ -757,12 +823,13 @@ int lf_g_intt_digits = 1;
 extern "C" {
 
 int lf_tune(int which, int value) {
-    int *knob = which == LF_TUNE_KS_EXT_COLS_MAX ? &g_ks_ext_cols_max : which == LF_TUNE_INTT_DIGITS ? &lf_g_intt_digits : nullptr;
+    int *knob = which == LF_TUNE_KS_EXT_COLS_MAX ? &g_ks_ext_cols_max : which == LF_TUNE_INTT_DIGITS ? &lf_g_intt_digits
+                : which == LF_TUNE_DIGIT_PLANES ? &g_digit_planes : nullptr;
     if (!knob) return -1;
     const int old = *knob;
     if (value < 0) return old;
     if (which == LF_TUNE_KS_EXT_COLS_MAX && value > 4) return old;
-    if (which == LF_TUNE_INTT_DIGITS && value > 1) return old;
+    if ((which == LF_TUNE_INTT_DIGITS || which == LF_TUNE_DIGIT_PLANES) && value > 1) return old;
     *knob = value;
     return old;
 }

@@ -176,7 +176,16 @@ __global__ void __launch_bounds__(NTT_COL_THREADS) ntt_inv_cols_digits(const i64
 // forward transform of a stack; `rsrc` (optional): the column pass takes its input from a rescale on the fly
 int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
                 const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *ql, const int64_t *qh,
-                const int64_t *kl, const int64_t *kh, int device, void *stream, const RescaleSrc *rsrc, int only_pass = 0);
+                const int64_t *kl, const int64_t *kh, int device, void *stream, const RescaleSrc *rsrc, int only_pass = 0,
+                int64_t *ws = nullptr);
+
+template <int K>
+void launch_cols_ws_k(unsigned blocks, hipStream_t st, const i64 *a, i64 *ws, unsigned char *wflags, const PassGeom &g,
+                      const ClassLists &cl, const int64_t *psi_br, const double *psi_dp, const i64 *rs, const int64_t *ql,
+                      const int64_t *qh, const int64_t *kl, const int64_t *kh) {
+    hipLaunchKernelGGL((ntt_fwd_cols_ws<K>), dim3(blocks), dim3(NTT_COL_THREADS), 0, st, a, ws, wflags, g, cl, (const i64 *)psi_br,
+                       psi_dp, rs, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+}
 
 }  // namespace
 
@@ -198,6 +207,26 @@ int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, con
            const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
     (void)_2q;
     return ntt_forward(a, batch, rows, logN, psi_br, psi_dp, q_host, Rs, flags, ql, qh, kl, kh, device, stream, nullptr);
+}
+
+int64_t lf_ntt_ws_words(int batch, int rows, int logN) {
+    if (batch < 0 || rows < 0 || logN < 1 || logN > 2 * NTT_TILE_LOG_MAX) return -1;
+    return ((int64_t)batch * rows << logN) + (int64_t)batch * rows * 8;   // the stack + 64 flag bytes per (polynomial, limb)
+}
+
+int lf_ntt_ws(int64_t *a, int64_t *ws, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
+              const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *ql, const int64_t *qh, const int64_t *kl,
+              const int64_t *kh, int device, void *stream) {
+    if (flags & LF_NTT_RELAXED) return LF_ERR_ARG;   // exact transforms only (the relaxed ones live inside the fused ops)
+    return ntt_forward(a, batch, rows, logN, psi_br, psi_dp, q_host, Rs, flags, ql, qh, kl, kh, device, stream, nullptr, 0, ws);
+}
+
+int lf_ntt_pass_ws(int64_t *a, int64_t *ws, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
+                   const int64_t *q_host, const int64_t *Rs, int flags, int which, const int64_t *ql, const int64_t *qh,
+                   const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (which != 1 && which != 2) return LF_ERR_ARG;
+    if (logN <= NTT_TILE_LOG_MAX || (flags & LF_NTT_RELAXED) || !ws) return LF_ERR_ARG;
+    return ntt_forward(a, batch, rows, logN, psi_br, psi_dp, q_host, Rs, flags, ql, qh, kl, kh, device, stream, nullptr, which, ws);
 }
 
 /* Measurement entry (NOT one of the reference's ops, not used by the engine): launch exactly ONE of the two pass
@@ -246,7 +275,8 @@ namespace {
 
 int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
                 const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *ql, const int64_t *qh,
-                const int64_t *kl, const int64_t *kh, int device, void *stream, const RescaleSrc *rsrc, int only_pass) {
+                const int64_t *kl, const int64_t *kh, int device, void *stream, const RescaleSrc *rsrc, int only_pass,
+                int64_t *ws) {
     if (batch < 0 || rows < 0 || rows > MAX_LIST_ROWS || logN < 1 || logN > 2 * NTT_TILE_LOG_MAX) return LF_ERR_ARG;
     const int relaxed = flags & LF_NTT_RELAXED;
     // relaxed arithmetic lives in the auxiliary table (fp64 twiddles, Shoup pairs), whose row layout follows the prime:
@@ -265,11 +295,31 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
     i64 *base = (i64 *)a;
     const int nb = batch;
     const unsigned per_row = (unsigned)nb << (logN - tl);
+    // through a workspace (lf_ntt_ws): exact two-launch sizes whose tiled pass is the 4096-word one; anything else ignores `ws`
+    const bool through_ws = ws && !relaxed && !rsrc && S1 >= 1 && S1 <= 4 && tl == NTT_TILE_LOG_MAX;
+    unsigned char *wflags = through_ws ? reinterpret_cast<unsigned char *>(ws + ((i64)nb * rows << logN)) : nullptr;
     for (int pass = (S1 > 0 ? 0 : 1); pass < 2; ++pass) {
         if (only_pass && pass + 1 != only_pass) continue;   // measurement only: time one pass kernel by itself
         const PassGeom g = pass == 0 ? PassGeom{logN, tl, 1, S1, 0, tl - S1, rows, nb, relaxed, 0, plain}
                                      : PassGeom{logN, tl, 0, tl, S1, 0, rows, nb, relaxed, 1, plain};
         const i64 *rs = (pass == 0 || S1 == 0) ? (const i64 *)Rs : nullptr;
+        if (through_ws) {
+            if (pass == 0) {
+                const unsigned per_limb = (unsigned)nb * ((1u << (logN - S1)) / NTT_COL_THREADS);
+                const ClassLists cl = class_lists(in, dp, per_limb * (unsigned)in.n);
+                const unsigned blocks = (unsigned)cl.in_blocks + per_limb * (unsigned)dp.n;
+                switch (S1) {
+                    case 1: launch_cols_ws_k<1>(blocks, st, base, (i64 *)ws, wflags, g, cl, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+                    case 2: launch_cols_ws_k<2>(blocks, st, base, (i64 *)ws, wflags, g, cl, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+                    case 3: launch_cols_ws_k<3>(blocks, st, base, (i64 *)ws, wflags, g, cl, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+                    case 4: launch_cols_ws_k<4>(blocks, st, base, (i64 *)ws, wflags, g, cl, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+                }
+            } else {
+                launch_pass16_ws(nb, st, (const i64 *)ws, wflags, base, g, in, dp, (const i64 *)psi_br, psi_dp, (const i64 *)ql,
+                                 (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+            }
+            continue;
+        }
         if (pass == 0 && S1 <= 4) {   // leading stages: one register step per column
             const unsigned col_blocks = (unsigned)nb * ((1u << (logN - S1)) / NTT_COL_THREADS);
             if (rsrc) {

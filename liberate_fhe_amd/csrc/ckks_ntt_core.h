@@ -1072,6 +1072,12 @@ __device__ __forceinline__ i64 *uniform_row(i64 *base, i64 off) {
     return p;
 }
 
+template <class T>
+__device__ __forceinline__ T *uniform_ptr(T *p) {
+    asm("" : "+s"(p));
+    return p;
+}
+
 // Streaming accesses (the `nt` bit of global loads / stores): words a pass reads once and writes once should not displace
 // the twiddle rows — as many bytes per tile as the data, re-read by every polynomial of the batch — from L1 / L2.
 // In-process A/B on the headline step (tools/ab_inproc.py, a build with the four switches below false beside this one): whole step -2.8 %, tiled pass
@@ -1253,6 +1259,109 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
         if (odd || DP) cols_fwd_stages<ArithInt<true>, K>(w, c);
         else cols_fwd_stages<ArithInt<false>, K>(w, c);
         COLS_ST_ALL(uniform_row(colu, (i64)k << logC) + lane, w[k])
+    }
+}
+
+// The column pass of an EXACT transform through a workspace (lf_ntt_ws; the tiled pass: fwd_tile16_ws, ckks_ntt_tile16.h):
+// reads the tensor, writes the workspace — fp64-class rows as planes (u32 low[N] | u16 mid[N] at byte 4 N | u16 top[N] at
+// byte 6 N, the last only from a wave that met an operand outside [0, 2q): flag byte wflags[row][v][e], set by the wave holding the
+// columns 256 e + 64 v .. + 63), integer-class
+// rows as raw words.  The arithmetic is fwd_cols_body's exact branch, statement by statement.
+template <bool DP, int K>
+__device__ __forceinline__ void fwd_cols_ws_body(int b, const i64 *__restrict__ a, i64 *__restrict__ ws,
+                                                 unsigned char *__restrict__ wflags, const PassGeom &g, const RowList &rl,
+                                                 const i64 *__restrict__ psi_br, const double *__restrict__ psi_dp,
+                                                 const i64 *__restrict__ Rs, const i64 *__restrict__ ql,
+                                                 const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                                 const i64 *__restrict__ kh) {
+    constexpr int R = 1 << K;
+    const int logC = g.logN - K;                                  // 12: the tiled pass behind is the 4096-word one
+    const int chunks = (1 << logC) / NTT_COL_THREADS;
+    const int chunk = b % chunks, r = b / chunks;
+    const int poly = __builtin_amdgcn_readfirstlane(r % g.batch), crow = __builtin_amdgcn_readfirstlane((int)rl.id[r / g.batch]);
+    const bool enter = Rs != nullptr;
+    Ctx c;
+    c.m = load_mod(ql, qh, kl, kh, crow);
+    c.tw_mont = psi_br + ((i64)crow << g.logN);
+    set_aux<DP>(c, psi_dp, crow, g.logN);
+    c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
+    c.relaxed = 0;
+    c.inv_reduce = 0;
+    const i64 rs = enter ? Rs[crow] : 0;
+    const i64 ri = (i64)(poly * g.rows + crow);
+    const i64 col0 = (i64)chunk * NTT_COL_THREADS;
+    const i64 *colu = a + (ri << g.logN) + col0;
+    const unsigned lane = threadIdx.x;
+    i64 w[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) w[k] = __builtin_nontemporal_load(uniform_ptr(colu + ((i64)k << logC)) + lane);
+    int odd = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) odd |= ((u64)w[k] >= (u64)c.m.q2);
+    if (DP && !odd) {
+        double x[R];
+        const double r1 = enter ? (double)((1ull << 62) % c.m.q) : 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            double v = dp_from_word(w[k]);
+            if (enter) {   // Montgomery entry, emulated exactly: REDC62(a * R^2)
+                v = dp_mulmod(v, r1, c.d);
+                if (dp_below_fix_limit(v)) v = dp_lazy_fix(v, (u64)w[k], (u64)rs, c.d.q);
+            }
+            x[k] = v;
+        }
+        cols_fwd_stages<ArithDp, K>(x, c);
+#pragma unroll
+        for (int k = 0; k < R; ++k) w[k] = dp_to_word(dp_reduce(x[k], c.d.q2, c.d.q2inv));
+    } else {
+        if (enter) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                w[k] = mm62s(w[k], rs, c.m.q, c.m.k);
+                odd |= ((u64)w[k] >= (u64)c.m.q2);
+            }
+        }
+        if (odd || DP) cols_fwd_stages<ArithInt<true>, K>(w, c);
+        else cols_fwd_stages<ArithInt<false>, K>(w, c);
+    }
+    i64 *orow = ws + (ri << g.logN);
+    if constexpr (!DP) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) __builtin_nontemporal_store(w[k], uniform_ptr(orow + col0 + ((i64)k << logC)) + lane);
+    } else {
+        const bool wide = __builtin_amdgcn_ballot_w64(odd != 0) != 0;   // (a lane of the fast branch holds words below 2^42)
+        unsigned *lo = reinterpret_cast<unsigned *>(orow) + col0;
+        unsigned short *mid = reinterpret_cast<unsigned short *>(orow + ((i64)1 << (g.logN - 1))) + col0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            __builtin_nontemporal_store((unsigned)w[k], uniform_ptr(lo + ((i64)k << logC)) + lane);
+            __builtin_nontemporal_store((unsigned short)((u64)w[k] >> 32), uniform_ptr(mid + ((i64)k << logC)) + lane);
+        }
+        if (wide) {
+            unsigned short *top = reinterpret_cast<unsigned short *>(orow + 3 * ((i64)1 << (g.logN - 2))) + col0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) top[((i64)k << logC) + lane] = (unsigned short)((u64)w[k] >> 48);
+        }
+        if ((lane & 63u) == 0) {   // this wave's 64 columns c0 .. c0 + 63 are words 256 e + 64 v + (0 .. 63) of every tile: wave v, index e
+            const unsigned c0 = (unsigned)col0 + lane;
+            wflags[(ri << 6) + (((c0 >> 6) & 3u) << 4) + (c0 >> 8)] = wide ? 1 : 0;
+        }
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(NTT_COL_THREADS) ntt_fwd_cols_ws(const i64 *__restrict__ a, i64 *__restrict__ ws,
+                                                                  unsigned char *__restrict__ wflags, PassGeom g, ClassLists cl,
+                                                                  const i64 *__restrict__ psi_br,
+                                                                  const double *__restrict__ psi_dp,
+                                                                  const i64 *__restrict__ Rs, const i64 *__restrict__ ql,
+                                                                  const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                                                  const i64 *__restrict__ kh) {
+    const int b = blockIdx.x;
+    if (b < cl.in_blocks) {
+        if (b < cl.in_real) fwd_cols_ws_body<false, K>(b, a, ws, wflags, g, cl.in, psi_br, psi_dp, Rs, ql, qh, kl, kh);
+    } else {
+        fwd_cols_ws_body<true, K>(b - cl.in_blocks, a, ws, wflags, g, cl.dp, psi_br, psi_dp, Rs, ql, qh, kl, kh);
     }
 }
 

@@ -201,9 +201,8 @@ __device__ __forceinline__ void inv_regs16_exact(double (&x)[16], int il, const 
 }
 
 // ---- odd tiles: the reference's signed arithmetic, stage by stage (rare; any thread count) -------------------------
-__device__ __forceinline__ void tile16_slow(i64 *sm, const i64 *src, i64 *dst, int base, int s0, int logN, bool inverse, const Ctx &c) {
-    for (int L = threadIdx.x; L < 4096; L += NTT16_THREADS) sm[PAD16(L)] = src[L];
-    __syncthreads();
+// (the tile's words are in LDS at PAD16(L), a barrier behind them)
+__device__ __forceinline__ void tile16_slow_lds(i64 *sm, i64 *dst, int base, int s0, int logN, bool inverse, const Ctx &c) {
     for (int j = 0; j < 12; ++j) {
         const int st = s0 + j;
         const int logd = inverse ? j : 11 - j;
@@ -223,6 +222,11 @@ __device__ __forceinline__ void tile16_slow(i64 *sm, const i64 *src, i64 *dst, i
         __syncthreads();
     }
     for (int L = threadIdx.x; L < 4096; L += NTT16_THREADS) dst[L] = sm[PAD16(L)];
+}
+__device__ __forceinline__ void tile16_slow(i64 *sm, const i64 *src, i64 *dst, int base, int s0, int logN, bool inverse, const Ctx &c) {
+    for (int L = threadIdx.x; L < 4096; L += NTT16_THREADS) sm[PAD16(L)] = src[L];
+    __syncthreads();
+    tile16_slow_lds(sm, dst, base, s0, logN, inverse, c);
 }
 
 // wave v owns byte v of the flag word: every wave writes its byte, so the word needs no reset
@@ -294,18 +298,34 @@ template <> struct FwdArith<true, false> { typedef ArithDp type; };
 template <> struct FwdArith<true, true> { typedef ArithDpR type; };
 template <> struct FwdArith<false, true> { typedef ArithShoup type; };
 
-template <bool DP, bool RLX>
+// PLN (fp64 class, relaxed: the extended digits of a key switch between ks_ext_cols, this pass and the inner product): the row
+// holds its canonical words (< 2^41) as two planes — u32 low[N] at byte 0, u16 high[N] at byte 4 N — 6 bytes per word
+// instead of 8 on each of the digits' three trips.  A tile reads and writes the same 16 KiB + 8 KiB: in place as before.
+template <bool DP, bool RLX, bool PLN = false>
 __device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int tile, const PassGeom &g, const Ctx &c,
                                            const Tw16Last<typename FwdArith<DP, RLX>::type> *lastC = nullptr) {
+    static_assert(!PLN || (DP && RLX), "planes: relaxed fp64-class rows only");
     const int w = lf_tid();
     const int base = tile << 12, E = g.logN, s = g.s0;
     constexpr bool CHECK = !RLX;   // relaxed tiles take the canonical words the library's own first pass wrote
     constexpr bool NTL = RLX ? NT_RLOAD : NT_EXACT, NTS = RLX ? NT_RSTORE : NT_EXACT;   // streaming accesses, ckks_ntt_core.h
     i64 raw[16];
+    unsigned plo[PLN ? 16 : 1];
+    unsigned short phi[PLN ? 16 : 1];
+    if constexpr (PLN) {
+        const unsigned *lo = reinterpret_cast<const unsigned *>(row) + base;
+        const unsigned short *hi = reinterpret_cast<const unsigned short *>(row + ((i64)1 << (E - 1))) + base;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {   // SGPR row pointers + lane index
-        if constexpr (NTL) raw[e] = __builtin_nontemporal_load(uniform_row(row + base, e << 8) + (unsigned)w);
-        else raw[e] = uniform_row(row + base, e << 8)[(unsigned)w];
+        for (int e = 0; e < 16; ++e) {
+            plo[e] = __builtin_nontemporal_load(uniform_ptr(lo + (e << 8)) + (unsigned)w);
+            phi[e] = __builtin_nontemporal_load(uniform_ptr(hi + (e << 8)) + (unsigned)w);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {   // SGPR row pointers + lane index
+            if constexpr (NTL) raw[e] = __builtin_nontemporal_load(uniform_row(row + base, e << 8) + (unsigned)w);
+            else raw[e] = uniform_row(row + base, e << 8)[(unsigned)w];
+        }
     }
     if (CHECK) {
         int odd = 0;
@@ -319,7 +339,7 @@ __device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int t
         typedef typename DpArith<RLX>::type AD;
         double x[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) x[e] = RLX ? dp_from_signed(raw[e]) : dp_from_word(raw[e]);
+        for (int e = 0; e < 16; ++e) x[e] = PLN ? dp_from_planes(plo[e], phi[e]) : RLX ? dp_from_signed(raw[e]) : dp_from_word(raw[e]);
         ok = fwd_tile16_steps<AD, true, RLX>(reinterpret_cast<double *>(sm), sm, x, w, base, E, s, c, CHECK, lastC);
         // the pass accumulated without subtractions: back to the lazy word in [0, 2q) (relaxed: canonical residue)
         const double md = RLX ? c.d.q : c.d.q2, mi = RLX ? c.d.qinv : c.d.q2inv;
@@ -339,6 +359,40 @@ __device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int t
         tile16_slow(sm, row + base, row + base, base, s, E, false, c);
         return;
     }
+    if constexpr (PLN) {
+        // the wave's own LDS span (17 * 64 words = 2 176 dwords; its last reads were this wave's own): 16 low dwords per lane
+        // 20 apart, behind them 8 dwords of packed high halves per lane 12 apart (strides that keep the 16-byte accesses of 16
+        // lanes on distinct banks on the way in) -> 16-byte stores, 1 KiB per instruction, on both planes
+        const int lane = w & 63, wave = w >> 6;
+        unsigned *sw = reinterpret_cast<unsigned *>(sm + 17 * 64 * wave);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const lf_u4_t v = {(unsigned)o[4 * k], (unsigned)o[4 * k + 1], (unsigned)o[4 * k + 2], (unsigned)o[4 * k + 3]};
+            *reinterpret_cast<lf_u4_t *>(sw + lane * 20 + 4 * k) = v;
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            lf_u4_t v;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                v[m] = (unsigned)(o[8 * k + 2 * m] >> 32) | ((unsigned)(o[8 * k + 2 * m + 1] >> 32) << 16);
+            *reinterpret_cast<lf_u4_t *>(sw + 1280 + lane * 12 + 4 * k) = v;
+        }
+        wave_lds_sync();
+        unsigned *lo = reinterpret_cast<unsigned *>(row) + base + (wave << 10);
+        unsigned *hi = reinterpret_cast<unsigned *>(row + ((i64)1 << (E - 1))) + ((base + (wave << 10)) >> 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // words 256 i + 4 lane .. + 3 of the span: thread 16 i + lane / 4, its quad lane % 4
+            const lf_u4_t v = *reinterpret_cast<const lf_u4_t *>(sw + (16 * i + (lane >> 2)) * 20 + 4 * (lane & 3));
+            *reinterpret_cast<lf_u4_t *>(lo + (i << 8) + 4 * lane) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {   // words 512 i + 8 lane .. + 7: thread 32 i + lane / 2, its half lane % 2
+            const lf_u4_t v = *reinterpret_cast<const lf_u4_t *>(sw + 1280 + (32 * i + (lane >> 1)) * 12 + 4 * (lane & 1));
+            *reinterpret_cast<lf_u4_t *>(hi + (i << 8) + 4 * lane) = v;
+        }
+        return;
+    }
     // 16 consecutive result words per thread -> the wave's own 1024-word LDS span -> 16-byte stores, 1 KiB per instruction
     {
         i64 *sp = sm + 17 * w;
@@ -354,6 +408,96 @@ __device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int t
         v.x = so[i * 136];
         v.y = so[i * 136 + 1];
         if constexpr (NTS) nt_store2(row + base + L0 + (i << 7), v);
+        else *reinterpret_cast<longlong2 *>(row + base + L0 + (i << 7)) = v;
+    }
+}
+
+// ---- forward tile of an EXACT transform whose column pass wrote a workspace (lf_ntt_ws) -----------------------------------
+// The two passes of a logN >= 13 transform exchange every word through HBM once.  With a workspace the column pass
+// (fwd_cols_ws_body, ckks_ntt_core.h) leaves the fp64-class rows there as PLANES — u32 low[N] at byte 0, u16 mid[N] at byte 4 N:
+// a lazy word is below 2^42 — and this pass reads 6 bytes per word instead of 8; the result goes to the tensor as raw words.
+// Words the reference's arithmetic produces from operands outside [0, 2q) can be anything: a column wave that met such an
+// operand also writes the words' top 16 bits (third plane at byte 6 N) and raises its flag byte wf[v][e] (columns 256 e + 64 v
+// .. + 63); the tile's wave v reads exactly the words of those column waves, e = 0 .. 15, so it tests its own 16 flag bytes
+// (two scalar loads) and fetches the top plane only where one is set.  Integer-class rows are raw words in the workspace.
+template <bool DP>
+__device__ __forceinline__ void ws_load_tile(const i64 *__restrict__ srow, const unsigned char *__restrict__ wf, int base, int E,
+                                             int w, i64 (&raw)[16]) {
+    if constexpr (DP) {
+        const unsigned *lo = reinterpret_cast<const unsigned *>(srow) + base;
+        const unsigned short *mid = reinterpret_cast<const unsigned short *>(srow + ((i64)1 << (E - 1))) + base;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const unsigned l = __builtin_nontemporal_load(uniform_ptr(lo + (e << 8)) + (unsigned)w);
+            const unsigned m = __builtin_nontemporal_load(uniform_ptr(mid + (e << 8)) + (unsigned)w);
+            raw[e] = (i64)(((u64)m << 32) | (u64)l);
+        }
+        const int wave = __builtin_amdgcn_readfirstlane(w >> 6);
+        const u64 *fp = reinterpret_cast<const u64 *>(wf + (wave << 4));
+        const u64 fl = fp[0], fh = fp[1];
+        if ((fl | fh) != 0) {
+            const unsigned short *top = reinterpret_cast<const unsigned short *>(srow + 3 * ((i64)1 << (E - 2))) + base;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if ((((e < 8 ? fl : fh) >> (8 * (e & 7))) & 0xffull) != 0) raw[e] |= (i64)((u64)top[(e << 8) + w] << 48);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) raw[e] = __builtin_nontemporal_load(uniform_ptr(srow + base + (e << 8)) + (unsigned)w);
+    }
+}
+
+template <bool DP>
+__device__ __forceinline__ void fwd_tile16_ws(i64 *sm, const i64 *__restrict__ srow, const unsigned char *__restrict__ wf,
+                                              i64 *__restrict__ row, int tile, const PassGeom &g, const Ctx &c,
+                                              const Tw16Last<typename FwdArith<DP, false>::type> *lastC = nullptr) {
+    const int w = lf_tid();
+    const int base = tile << 12, E = g.logN, s = g.s0;
+    i64 raw[16];
+    ws_load_tile<DP>(srow, wf, base, E, w, raw);
+    {
+        int odd = 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) odd |= ((u64)raw[e] >= (u64)c.m.q2);
+        wave_flag_set16(sm, odd, w);
+    }
+    i64 o[16];
+    bool ok;
+    if constexpr (DP) {
+        double x[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[e] = dp_from_word(raw[e]);
+        ok = fwd_tile16_steps<ArithDp, true, false>(reinterpret_cast<double *>(sm), sm, x, w, base, E, s, c, true, lastC);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = dp_to_word(dp_reduce(x[e], c.d.q2, c.d.q2inv));
+    } else {
+        ok = fwd_tile16_steps<ArithInt<false>, false, false>(sm, sm, raw, w, base, E, s, c, true, lastC);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = raw[e];
+    }
+    if (!ok) {   // a word outside [0, 2q): nothing has been stored yet; the raw words once more, into LDS, then the generic tile
+        __syncthreads();
+        ws_load_tile<DP>(srow, wf, base, E, w, raw);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sm[PAD16(w + (e << 8))] = raw[e];
+        __syncthreads();
+        tile16_slow_lds(sm, row + base, base, s, E, false, c);
+        return;
+    }
+    {
+        i64 *sp = sm + 17 * w;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sp[e] = o[e];
+    }
+    wave_lds_sync();
+    const int L0 = ((w >> 6) << 10) + ((w & 63) << 1);
+    const i64 *so = sm + PAD16(L0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        longlong2 v;
+        v.x = so[i * 136];
+        v.y = so[i * 136 + 1];
+        if constexpr (NT_EXACT) nt_store2(row + base + L0 + (i << 7), v);
         else *reinterpret_cast<longlong2 *>(row + base + L0 + (i << 7)) = v;
     }
 }
@@ -481,7 +625,7 @@ struct MulSrc {
     i64 a_stride, b_stride;
 };
 
-template <bool DP, bool RLX, bool INV, bool MUL = false>
+template <bool DP, bool RLX, bool INV, bool MUL = false, bool PLN = false>
 __device__ __forceinline__ void pass16_body(i64 *sm, int b, const i64 *src, i64 *dst, const PassGeom &g, const RowList &rl,
                                             const i64 *__restrict__ tw_br, const double *__restrict__ tw_dp,
                                             const i64 *__restrict__ ql, const i64 *__restrict__ qh,
@@ -507,7 +651,7 @@ __device__ __forceinline__ void pass16_body(i64 *sm, int b, const i64 *src, i64 
     } else if constexpr (INV) {
         inv_tile16<DP, RLX>(sm, src + off, dst + off, tile, g, c);
     } else {
-        fwd_tile16<DP, RLX>(sm, dst + off, tile, g, c);
+        fwd_tile16<DP, RLX, PLN>(sm, dst + off, tile, g, c);
     }
 }
 
@@ -523,6 +667,21 @@ __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_mixed(const i64 *
         if (b < cl.in_real) pass16_body<false, RLX, INV>(sm, b, src, dst, g, cl.in, tw_br, tw_dp, ql, qh, kl, kh);
     } else {
         pass16_body<true, RLX, INV>(sm, b - cl.in_blocks, src, dst, g, cl.dp, tw_br, tw_dp, ql, qh, kl, kh);
+    }
+}
+
+// relaxed forward pass over extended digits whose fp64-class rows are in planes format (fwd_tile16<.., PLN>), both classes
+__global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_fwd_planes(i64 *dst, PassGeom g, ClassLists cl,
+                                                                            const i64 *__restrict__ tw_br,
+                                                                            const double *__restrict__ tw_dp,
+                                                                            const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                            const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT16_LDS_WORDS + 1];
+    const int b = blockIdx.x;
+    if (b < cl.in_blocks) {
+        if (b < cl.in_real) pass16_body<false, true, false>(sm, b, dst, dst, g, cl.in, tw_br, tw_dp, ql, qh, kl, kh);
+    } else {
+        pass16_body<true, true, false, false, true>(sm, b - cl.in_blocks, dst, dst, g, cl.dp, tw_br, tw_dp, ql, qh, kl, kh);
     }
 }
 
@@ -616,6 +775,83 @@ __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_fwd_seq(i64 *dst,
     else seq16_loop<true, RLX>(sm, dst, g, cl.dp, vb0 - cl.in_blocks, total - cl.in_blocks, tpb, tw_br, tw_dp, ql, qh, kl, kh);
 }
 
+// the same two kernels for a transform through a workspace (fwd_tile16_ws): ws -> dst, wflags = 64 flag bytes per (poly, limb)
+template <bool DP>
+__device__ __forceinline__ void seq16_loop_ws(i64 *sm, const i64 *ws, const unsigned char *wflags, i64 *dst, const PassGeom &g,
+                                              const RowList &rl, int b0, int bend, int tpb, const i64 *__restrict__ tw_br,
+                                              const double *__restrict__ tw_dp, const i64 *__restrict__ ql,
+                                              const i64 *__restrict__ qh, const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    typedef typename FwdArith<DP, false>::type AC;
+    const int w = lf_tid();
+    Tw16Last<AC> last;
+    int last_crow = -1, last_tile = -1;
+    for (int i = 0; i < tpb; ++i) {
+        const int b = b0 + 8 * i;
+        const TileAt t = tile_at(g, rl, b, b < bend);
+        if (!t.live) break;
+        Ctx c;
+        c.m = load_mod(ql, qh, kl, kh, t.crow);
+        c.tw_mont = tw_br + ((i64)t.crow << g.logN);
+        set_aux<DP>(c, tw_dp, t.crow, g.logN);
+        c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
+        c.relaxed = 0;
+        c.inv_reduce = 0;
+        if (t.crow != last_crow || t.tile != last_tile) {
+            last.load(c, (1 << (g.s0 + 8)) + (((t.tile << 12) + 16 * w) >> (g.logN - g.s0 - 8)));
+            last_crow = t.crow, last_tile = t.tile;
+        }
+        if (i) lds_barrier();
+        const i64 ri = (i64)(t.poly * g.rows + t.crow);
+        fwd_tile16_ws<DP>(sm, ws + (ri << g.logN), wflags + (ri << 6), dst + (ri << g.logN), t.tile, g, c, &last);
+    }
+}
+
+__global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_fwd_seq_ws(const i64 *ws, const unsigned char *wflags, i64 *dst,
+                                                                            PassGeom g, ClassLists cl, int total, int tpb,
+                                                                            const i64 *__restrict__ tw_br,
+                                                                            const double *__restrict__ tw_dp,
+                                                                            const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                            const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT16_LDS_WORDS + 1];
+    const int vb0 = (int)(blockIdx.x & 7) + 8 * (int)(blockIdx.x >> 3) * tpb;
+    if (vb0 < cl.in_blocks) seq16_loop_ws<false>(sm, ws, wflags, dst, g, cl.in, vb0, cl.in_real, tpb, tw_br, tw_dp, ql, qh, kl, kh);
+    else seq16_loop_ws<true>(sm, ws, wflags, dst, g, cl.dp, vb0 - cl.in_blocks, total - cl.in_blocks, tpb, tw_br, tw_dp, ql, qh, kl, kh);
+}
+
+template <bool DP>
+__device__ __forceinline__ void pass16_ws_body(i64 *sm, int b, const i64 *ws, const unsigned char *wflags, i64 *dst,
+                                               const PassGeom &g, const RowList &rl, const i64 *__restrict__ tw_br,
+                                               const double *__restrict__ tw_dp, const i64 *__restrict__ ql,
+                                               const i64 *__restrict__ qh, const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    int poly, crow, tile;
+    block_coords(g, rl, b, poly, crow, tile);
+    poly = __builtin_amdgcn_readfirstlane(poly), crow = __builtin_amdgcn_readfirstlane(crow);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    Ctx c;
+    c.m = load_mod(ql, qh, kl, kh, crow);
+    c.tw_mont = tw_br + ((i64)crow << g.logN);
+    set_aux<DP>(c, tw_dp, crow, g.logN);
+    c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
+    c.relaxed = 0;
+    c.inv_reduce = 0;
+    const i64 ri = (i64)(poly * g.rows + crow);
+    fwd_tile16_ws<DP>(sm, ws + (ri << g.logN), wflags + (ri << 6), dst + (ri << g.logN), tile, g, c);
+}
+
+__global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_fwd_ws(const i64 *ws, const unsigned char *wflags, i64 *dst,
+                                                                        PassGeom g, ClassLists cl, const i64 *__restrict__ tw_br,
+                                                                        const double *__restrict__ tw_dp,
+                                                                        const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                        const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT16_LDS_WORDS + 1];
+    const int b = blockIdx.x;
+    if (b < cl.in_blocks) {
+        if (b < cl.in_real) pass16_ws_body<false>(sm, b, ws, wflags, dst, g, cl.in, tw_br, tw_dp, ql, qh, kl, kh);
+    } else {
+        pass16_ws_body<true>(sm, b - cl.in_blocks, ws, wflags, dst, g, cl.dp, tw_br, tw_dp, ql, qh, kl, kh);
+    }
+}
+
 // one arithmetic class per launch (used when a transform has a single class)
 template <bool DP, bool RLX, bool INV>
 __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16(const i64 *src, i64 *dst, PassGeom g, RowList rl,
@@ -664,7 +900,7 @@ inline void launch_pass16_class(bool inverse, int relaxed, unsigned blocks, hipS
 // ms (relaxed inverse only): the pass transforms the product of two stacks, see MulSrc.
 inline void launch_pass16(bool inverse, int relaxed, int polys, hipStream_t st, const i64 *src, i64 *dst, const PassGeom &g,
                           const RowList &in, const RowList &dp, const i64 *tw_br, const double *tw_dp, const i64 *ql,
-                          const i64 *qh, const i64 *kl, const i64 *kh, const MulSrc *ms = nullptr) {
+                          const i64 *qh, const i64 *kl, const i64 *kh, const MulSrc *ms = nullptr, bool planes = false) {
     const unsigned per_row = (unsigned)polys << (g.logN - 12);
     const bool split = !(in.n && dp.n);   // a single class: its own instantiation (no register cost of the other)
     // (launches that do not fill the chip — silver's 128 .. 1 216 tile blocks — were also tried on the 512-thread /
@@ -677,7 +913,9 @@ inline void launch_pass16(bool inverse, int relaxed, int polys, hipStream_t st, 
     }
     const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
     const dim3 grid((unsigned)cl.in_blocks + per_row * (unsigned)dp.n), block(NTT16_THREADS);
-    if (ms) {
+    if (planes) {   // forward, relaxed, both classes present (ks_forward: digit_planes())
+        hipLaunchKernelGGL(ntt_pass16_fwd_planes, grid, block, 0, st, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
+    } else if (ms) {
         hipLaunchKernelGGL(ntt_pass16_mul_mixed, grid, block, 0, st, src, dst, g, cl, *ms, tw_br, tw_dp, ql, qh, kl, kh);
     } else if (inverse) {
         if (relaxed) hipLaunchKernelGGL((ntt_pass16_mixed<true, true>), grid, block, 0, st, src, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
@@ -697,6 +935,26 @@ inline void launch_pass16(bool inverse, int relaxed, int polys, hipStream_t st, 
         if (relaxed) hipLaunchKernelGGL((ntt_pass16_mixed<true, false>), grid, block, 0, st, src, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
         else hipLaunchKernelGGL((ntt_pass16_mixed<false, false>), grid, block, 0, st, src, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
     }
+}
+
+// host: the contiguous exact forward pass of a transform through a workspace (either class list may be empty)
+inline void launch_pass16_ws(int polys, hipStream_t st, const i64 *ws, const unsigned char *wflags, i64 *dst, const PassGeom &g,
+                             const RowList &in, const RowList &dp, const i64 *tw_br, const double *tw_dp, const i64 *ql,
+                             const i64 *qh, const i64 *kl, const i64 *kh) {
+    const unsigned per_row = (unsigned)polys << (g.logN - 12);
+    const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
+    const dim3 grid((unsigned)cl.in_blocks + per_row * (unsigned)dp.n), block(NTT16_THREADS);
+    const int tpb = NTT16_SEQ_TILES;
+    if (tpb > 1 && (int)grid.x >= tpb * NTT16_SEQ_MIN_BLOCKS) {
+        ClassLists cm = cl;
+        const unsigned unit = 8u * (unsigned)tpb, dpb = per_row * (unsigned)dp.n;
+        cm.in_blocks = (int)(((unsigned)cl.in_real + unit - 1u) / unit * unit);
+        const int total = cm.in_blocks + (int)dpb;
+        const dim3 mg((unsigned)cm.in_blocks / (unsigned)tpb + 8u * ((dpb + unit - 1u) / unit));
+        hipLaunchKernelGGL(ntt_pass16_fwd_seq_ws, mg, block, 0, st, ws, wflags, dst, g, cm, total, tpb, tw_br, tw_dp, ql, qh, kl, kh);
+        return;
+    }
+    hipLaunchKernelGGL(ntt_pass16_fwd_ws, grid, block, 0, st, ws, wflags, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
 }
 
 }  // namespace

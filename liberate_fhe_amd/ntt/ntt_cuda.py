@@ -133,6 +133,23 @@ def _logN(ai):
     return N.bit_length() - 1
 
 
+# Workspace of the two-launch forward transform (lf_ntt_ws, include/ckks_hip.h: 6-byte words between its passes), one per
+# (device, stream) so that transforms on different streams never share it; grown on demand, as large as the largest stack
+# transformed on that stream.  Set ntt_cuda.USE_WORKSPACE = False to transform strictly in place (lf_ntt) at ~4 % of the rate.
+USE_WORKSPACE = True
+_WS = {}
+
+
+def _workspace(dev, st, rows, logN):
+    if not USE_WORKSPACE or logN < 13 or logN > 16:
+        return None
+    words = int(lib.lf_ntt_ws_words(1, rows, logN))
+    ws = _WS.get((dev, st))
+    if ws is None or ws.numel() < words:
+        ws = _WS[(dev, st)] = torch.empty((words,), dtype=torch.int64, device=f"cuda:{dev}")
+    return ws
+
+
 def _forward(a, Rs, psi, _2q, ql, qh, kl, kh, what):
     for i, ai in enumerate(a):
         dev, st = _dev_stream(ai)
@@ -149,8 +166,13 @@ def _forward(a, Rs, psi, _2q, ql, qh, kl, kh, what):
         dp = twiddles.dp_pointer(table, ql[i], qh[i], kl[i], kh[i], dev, st)
         _, qhost = twiddles.host_primes(ql[i], qh[i])
         # extent = ql.size(0) rows (K.cu:298, 371)
-        check(lib.lf_ntt(_ptr(w), 1, ql[i].size(0), _logN(w), _ptr(table), dp, qhost, rs, 0, _ptr(_2q[i]),
-                         _ptr(ql[i]), _ptr(qh[i]), _ptr(kl[i]), _ptr(kh[i]), dev, st), what)
+        ws = _workspace(dev, st, ql[i].size(0), _logN(w))
+        if ws is not None:
+            check(lib.lf_ntt_ws(_ptr(w), _ptr(ws), 1, ql[i].size(0), _logN(w), _ptr(table), dp, qhost, rs, 0,
+                                _ptr(ql[i]), _ptr(qh[i]), _ptr(kl[i]), _ptr(kh[i]), dev, st), what)
+        else:
+            check(lib.lf_ntt(_ptr(w), 1, ql[i].size(0), _logN(w), _ptr(table), dp, qhost, rs, 0, _ptr(_2q[i]),
+                             _ptr(ql[i]), _ptr(qh[i]), _ptr(kl[i]), _ptr(kh[i]), dev, st), what)
         if back is not None:
             back.copy_(w)
 

@@ -20,7 +20,7 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(so, n), f"{n} declared in include/ckks_hip.h but not exported"
     assert sorted(_native.EXPORTED) == names, "python binding table out of sync with the header"
-    assert _native.lib.lf_abi_version() == 13     # pure host call, no HIP runtime use
+    assert _native.lib.lf_abi_version() == 14     # pure host call, no HIP runtime use
 
 
 def test_python_binding_passes_as_many_arguments_as_the_header_declares():
@@ -175,6 +175,7 @@ def test_lf_tune_is_a_pure_host_call():
     cols = lib.lf_tune(1, -1)
     assert 0 <= cols <= 4
     assert lib.lf_tune(1, 9) == cols and lib.lf_tune(1, -1) == cols      # out of range: ignored
+    assert lib.lf_tune(3, -1) == 1 and lib.lf_tune(3, 5) == 1     # digit planes: on by default; out of range: ignored
     assert lib.lf_tune(77, 1) == -1
 
 

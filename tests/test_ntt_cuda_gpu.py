@@ -190,6 +190,96 @@ def test_ntt_tiles_with_out_of_range_words(mods, logN):
         assert (t[0].cpu().numpy() == want_i).all(), name
 
 
+@pytest.mark.parametrize("logN", [13, 14, 15, 16])
+def test_forward_transform_through_a_workspace_equals_in_place_and_oracle(mods, logN):
+    """lf_ntt_ws (what ntt_cuda.ntt / enter_ntt call at logN 13 .. 16: the two passes exchange the fp64-class limbs as 6-byte
+    planes through a workspace) against lf_ntt (USE_WORKSPACE = False) and the oracle: lazy operands; operands with arbitrary
+    words below 2^61 in magnitude sprinkled over columns and tiles (a column wave that meets one ships its words' top 16 bits in a third
+    plane and raises its flag; the tiles behind leave the fast form); a workspace full of ones before every call."""
+    nc, orc = mods
+    lim = Limbs(logN, pick_primes(logN, 3, 2))
+    C = lim.rows
+    psi, _ = lim.mont_tables()
+    d = lambda v: [dev(v)]
+    consts = [d(lim._2q), d(lim.ql), d(lim.qh), d(lim.kl), d(lim.kh)]
+    rng = np.random.default_rng(900 + logN)
+    clean = lim.uniform(31 + logN, lazy=True)
+    dirty = clean.copy()
+    for r, q in enumerate(lim.q):
+        cols = rng.integers(0, lim.N, size=24)
+        dirty[r, cols] = rng.integers(-(2 ** 61), 2 ** 61, size=24, dtype=np.int64)
+        dirty[r, 64 * r + 1] = 2 * q                 # boundary word
+        dirty[r, lim.N - 1 - 64 * r] = -1
+    one_row_clean = dirty.copy()
+    one_row_clean[1] = clean[1]                      # its flags must read 0 beside flagged neighbours
+    wild = dirty.copy()                              # any int64 at all: beyond the oracle's defined range (signed overflow in C),
+    for r in range(C):                               # the two forms are compared with each other
+        wild[r, rng.integers(0, lim.N, size=24)] = rng.integers(-(2 ** 63), 2 ** 63 - 1, size=24, dtype=np.int64)
+    assert nc.USE_WORKSPACE
+    try:
+        both = {}
+        for use in (True, False):
+            nc.USE_WORKSPACE = use
+            t = d(wild)
+            nc.enter_ntt(t, d(lim.Rs), [None], [None], d(psi), *consts)
+            both[use] = t[0].cpu().numpy()
+        assert (both[True] == both[False]).all(), "any int64 words: workspace against in place"
+        for name, x in (("lazy", clean), ("arbitrary words", dirty), ("one clean limb", one_row_clean)):
+            for entry in ("ntt", "enter_ntt"):
+                want = x.copy()
+                if entry == "enter_ntt":
+                    orc.mont_enter(want, lim.Rs, C, *lim.mont_args())
+                orc.ntt(want, psi, C, logN, lim._2q, *lim.mont_args())
+                got = {}
+                for use in (True, False):
+                    nc.USE_WORKSPACE = use
+                    for ws in nc._WS.values():
+                        ws.fill_(-1)
+                    t = d(x)
+                    if entry == "ntt":
+                        nc.ntt(t, [None], [None], d(psi), *consts)
+                    else:
+                        nc.enter_ntt(t, d(lim.Rs), [None], [None], d(psi), *consts)
+                    got[use] = t[0].cpu().numpy()
+                assert (got[True] == want).all(), f"{entry}, {name}: through the workspace"
+                assert (got[False] == want).all(), f"{entry}, {name}: in place"
+    finally:
+        nc.USE_WORKSPACE = True
+    assert any(ws.numel() >= C * lim.N for ws in nc._WS.values())
+
+
+def test_workspace_entry_argument_checks(mods):
+    """lf_ntt_ws: relaxed transforms are refused before anything is launched; without a workspace, and at sizes with one
+    launch (logN <= 12) or the LDS-tiled first pass (logN 17), it IS lf_ntt."""
+    from liberate_fhe_amd._native import lib
+    from liberate_fhe_amd.ntt import twiddles
+    nc, orc = mods
+    for logN in (12, 13, 17):
+        lim = Limbs(logN, pick_primes(logN, 2, 1))
+        psi, _ = lim.mont_tables()
+        x = lim.uniform(3, lazy=True)
+        want = x.copy()
+        orc.ntt(want, psi, lim.rows, logN, lim._2q, *lim.mont_args())
+        c = [dev(v) for v in (psi, lim.ql, lim.qh, lim.kl, lim.kh)]
+        st = torch.cuda.current_stream().cuda_stream
+        dp = twiddles.dp_pointer(c[0], c[1], c[2], c[3], c[4], 0, st)
+        qh = np.asarray(lim.q, dtype=np.int64)
+        words = lib.lf_ntt_ws_words(1, lim.rows, logN)
+        assert words == lim.rows * lim.N + 8 * lim.rows
+        ws = torch.full((words,), -1, dtype=torch.int64, device="cuda")
+        for wsp in (ws.data_ptr(), 0):
+            t = dev(x)
+            assert lib.lf_ntt_ws(t.data_ptr(), wsp, 1, lim.rows, logN, c[0].data_ptr(), dp, qh.ctypes.data, 0, 0,
+                                 c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(), c[4].data_ptr(), 0, st) == 0
+            assert (t.cpu().numpy() == want).all(), (logN, wsp != 0)
+        t = dev(x)
+        assert lib.lf_ntt_ws(t.data_ptr(), ws.data_ptr(), 1, lim.rows, logN, c[0].data_ptr(), dp, qh.ctypes.data, 0, 1,
+                             c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(), c[4].data_ptr(), 0, st) != 0
+        torch.cuda.synchronize()
+        assert (t.cpu().numpy() == x).all()          # refused: nothing ran
+    assert lib.lf_ntt_ws_words(-1, 1, 13) == -1 and lib.lf_ntt_ws_words(1, 1, 99) == -1
+
+
 def test_ntt_extent_is_constant_rows(mods):
     """NTT-family ops transform ql.size(0) rows and leave further rows of `a` alone (K.cu:298)."""
     nc, orc = mods

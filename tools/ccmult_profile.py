@@ -1,4 +1,4 @@
-"""Kernel-level timing of one engine op (development aid): python tools/ccmult_profile.py gold cc_mult [--mark]
+"""Kernel-level timing of one engine op (development aid): python tools/ccmult_profile.py gold cc_mult [--mark] [--tune=<knob>:<value>]
 
 --mark: bracket the timed loop with two tiny marker kernels (torch fill of a 1-element tensor with 12345 / 54321 is
 not distinguishable in a trace, so the markers are lf_reduce_2q launches on a [1, 2] tensor — `ew_kernel<...>` with
@@ -12,6 +12,11 @@ from liberate_fhe_amd.utils import synth
 name = sys.argv[1] if len(sys.argv) > 1 else "gold"
 op = sys.argv[2] if len(sys.argv) > 2 else "cc_mult"
 mark = "--mark" in sys.argv
+for arg in sys.argv:                       # --tune=<knob>:<value> (lf_tune, include/ckks_hip.h) before anything runs
+    if arg.startswith("--tune="):
+        from liberate_fhe_amd._native import lib as _lib
+        _k, _v = arg[7:].split(":")
+        _lib.lf_tune(int(_k), int(_v))
 eng = ckks_engine(**{**presets.params[name], "devices": ["cuda:0"]})
 a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
 evk = synth.key_switch_key(eng, 5)

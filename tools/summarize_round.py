@@ -52,9 +52,9 @@ try:
     r = bench["roofline"]
     lines += ["", f"# bench.py (un-profiled run of the same box): value {bench['value']:.0f} poly-NTT/s, ms_per_step {bench['ms_per_step']:.4f};",
               f"# roofline leg (lf_ntt_pass which = 2, {r['launches_timed']} launches): avg_launch_ms {r['avg_launch_ms']:.4f} from HIP events;",
-              f"# the last {r['launches_timed']} tiled-pass dispatches (ntt_pass16_fwd_seq<false>) of the trace above are that leg."]
+              f"# the last {r['launches_timed']} tiled-pass dispatches (ntt_pass16_fwd_seq_ws) of the trace above are that leg."]
     durs = [d[0] / 1e3 for d in q(os.path.join(src, f"prof_{TAG}", "stats_results.db"),
-                                  "select duration from kernels where (name like '%ntt_fwd_pass_mixed<false>%' or name like '%ntt_pass16_mixed<false, false>%' or name like '%ntt_pass16_fwd_seq<false>%') order by start")]
+                                  "select duration from kernels where (name like '%ntt_fwd_pass_mixed<false>%' or name like '%ntt_pass16_mixed<false, false>%' or name like '%ntt_pass16_fwd_seq<false>%' or name like '%ntt_pass16_fwd_seq_ws%') order by start")]
     tail = durs[-int(r["launches_timed"]):]
     lines.append(f"# their average under rocprofv3: {sum(tail) / len(tail):.2f} us (min {min(tail):.2f}, max {max(tail):.2f})")
 except Exception as e:
@@ -68,7 +68,7 @@ pm = [f"# rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --no-ext
       "# kernel/grid | us | FETCH_SIZE KiB (raw) | read MB (x2, gfx950) | WRITE_SIZE KiB | write MB | moved TB/s | VALU wave-instr | VALU busy | CU busy", ""]
 traffic = {"batch_per_gpu": 128, "library_digest": DIGEST}
 for key in sorted(f):
-    if "ntt_" not in key[0] or "cols_mixed" not in key[0] and "pass16" not in key[0] and "fwd_pass" not in key[0]:
+    if "ntt_" not in key[0] or "cols_mixed" not in key[0] and "cols_ws" not in key[0] and "pass16" not in key[0] and "fwd_pass" not in key[0]:
         continue
     rd, wr = 2 * f[key]["FETCH_SIZE"] * 1024, w[key]["WRITE_SIZE"] * 1024
     us = v[key]["us"]
