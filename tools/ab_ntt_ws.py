@@ -15,6 +15,13 @@ from liberate_fhe_amd.fhe.context.ckks_context import ckks_context
 from liberate_fhe_amd.utils import synth
 
 L = _native.lib
+VARIANT = None      # argv[5]: a second build (tools/mkvariant.sh) whose workspace form is timed beside the other two
+if len(sys.argv) > 5:
+    import ctypes
+    VARIANT = ctypes.CDLL(os.path.abspath(sys.argv[5]))
+    for fn in ("lf_ntt_ws", "lf_ntt_pass_ws"):
+        getattr(VARIANT, fn).argtypes = _native._SIGNATURES[fn]
+        getattr(VARIANT, fn).restype = ctypes.c_int
 LOGN = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 LIMBS = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 128
@@ -42,14 +49,14 @@ def plain(x, rs=0):
                     qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), 0, st) == 0
 
 
-def through(x, rs=0):
+def through(x, rs=0, L=L):
     assert L.lf_ntt_ws(x.data_ptr(), ws.data_ptr(), B, LIMBS, LOGN, psi.data_ptr(), psi_dp, q_host.ctypes.data, rs, 0, ql.data_ptr(),
                        qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), 0, st) == 0
 
 
 def one_pass(x, which, w):
     if w:
-        assert L.lf_ntt_pass_ws(x.data_ptr(), ws.data_ptr(), B, LIMBS, LOGN, psi.data_ptr(), psi_dp, q_host.ctypes.data, 0, 0, which,
+        assert (VARIANT if w == 2 else L).lf_ntt_pass_ws(x.data_ptr(), ws.data_ptr(), B, LIMBS, LOGN, psi.data_ptr(), psi_dp, q_host.ctypes.data, 0, 0, which,
                                 ql.data_ptr(), qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), 0, st) == 0
     else:
         assert L.lf_ntt_pass(x.data_ptr(), B, LIMBS, LOGN, psi.data_ptr(), psi_dp, q_host.ctypes.data, 0, 0, which, ql.data_ptr(),
@@ -68,6 +75,9 @@ for name, src in cases.items():
         plain(a, rs); through(b, rs)
         torch.cuda.synchronize()
         same = torch.equal(a, b)
+        if VARIANT is not None:
+            b2 = src.clone(); through(b2, rs, VARIANT); torch.cuda.synchronize()
+            same = same and torch.equal(a, b2)
         print(f"{rs_name:9s} {name}: {'equal' if same else 'DIFFERENT'}  ({int((a != b).sum())} words differ)", flush=True)
         assert same
 
@@ -95,13 +105,16 @@ def timed_passes(w, n):
 for _ in range(10):
     plain(x); through(x)
 torch.cuda.synchronize()
-res = {0: [], 1: []}
+forms = (0, 1) if VARIANT is None else (0, 1, 2)
+res = {w: [] for w in forms}
 for r in range(ROUNDS):
-    for w in (0, 1):
-        t = timed((lambda: through(x)) if w else (lambda: plain(x)), 20)
+    for w in forms:
+        t = timed((lambda: through(x, 0, VARIANT if w == 2 else L)) if w else (lambda: plain(x)), 20)
         c, p = timed_passes(w, 20)
         res[w].append((t, c, p))
-        print(f"round {r} {'workspace' if w else 'in place '}: step {t:.4f} ms  column pass {c:.4f}  tiled pass {p:.4f}   {B / t * 1e3:9.0f} poly-NTT/s", flush=True)
+        print(f"round {r} {('in place ', 'workspace', 'ws variant')[w]}: step {t:.4f} ms  column pass {c:.4f}  tiled pass {p:.4f}   {B / t * 1e3:9.0f} poly-NTT/s", flush=True)
 med = lambda w, i: float(np.median([v[i] for v in res[w]]))
+if VARIANT is not None:
+    print(f"variant: step {med(2, 0):.4f} ms ({med(2, 0) / med(1, 0):.4f} x the base workspace form);  column pass {med(2, 1):.4f};  tiled pass {med(2, 2):.4f}")
 print(f"median step: in place {med(0, 0):.4f} ms, workspace {med(1, 0):.4f} ms ({med(1, 0) / med(0, 0):.4f} x);  column pass "
       f"{med(0, 1):.4f} -> {med(1, 1):.4f};  tiled pass {med(0, 2):.4f} -> {med(1, 2):.4f}")
