@@ -345,6 +345,10 @@ def ntt_rates_preset(name, dev, batch, iters=20):
                             qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), d, st), "lf_ntt_ws")
 
     def inv():
+        check(lib.lf_intt_ws(x.data_ptr(), ws.data_ptr(), batch, L, logN, ipsi.data_ptr(), idp, q_host.ctypes.data, ninv.data_ptr(), 2, 0,
+                             ql.data_ptr(), qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), d, st), "lf_intt_ws")
+
+    def inv_in_place():
         check(lib.lf_intt(x.data_ptr(), batch, L, logN, ipsi.data_ptr(), idp, q_host.ctypes.data, ninv.data_ptr(), 2, 0, q2.data_ptr(),
                           ql.data_ptr(), qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), d, st), "lf_intt")
 
@@ -359,7 +363,7 @@ def ntt_rates_preset(name, dev, batch, iters=20):
     ok = bool(torch.equal(x[0], one % qcol))
     out = {"limbs": L, "logN": logN, "batch": batch, "round_trip_identity": ok}
     nbytes = 16 * N * L * batch
-    for key, fn, prep in (("forward", fwd, None), ("inverse_exit_reduce", inv, fwd)):
+    for key, fn, prep in (("forward", fwd, None), ("inverse_exit_reduce", inv, fwd), ("inverse_exit_reduce_in_place_lf_intt", inv_in_place, fwd)):
         x[:] = one
         if prep:
             prep()
@@ -372,7 +376,7 @@ def ntt_rates_preset(name, dev, batch, iters=20):
                     "roofline": {"bound": "valu_issue" if logN >= 13 else "latency", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_step": nbytes,
                                  "note": "whole transform (both launches), 16 N bytes per limb; no PMC table for this shape"}}
-    del x
+    del x, ws
     torch.cuda.empty_cache()
     return out
 

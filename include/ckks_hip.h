@@ -165,6 +165,12 @@ int64_t lf_ntt_ws_words(int batch, int rows, int logN);
 int lf_ntt_ws(int64_t *a, int64_t *ws, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
               const int64_t *q_host, const int64_t *Rs, int flags, const int64_t *ql, const int64_t *qh, const int64_t *kl,
               const int64_t *kh, int device, void *stream);
+/* The inverse chains the same way (lf_intt with tail 0 .. 3 = intt / intt_exit / intt_exit_reduce / intt_exit_reduce_signed): the
+ * tiled pass comes first and writes the workspace, the column pass with the chain tail reads it; a tile that meets an operand
+ * outside [0, 2q) ships the third plane and raises its flag.  Same words as lf_intt on any input; same `ws` rules as lf_ntt_ws. */
+int lf_intt_ws(int64_t *a, int64_t *ws, int batch, int rows, int logN, const int64_t *ipsi_br, const double *ipsi_dp,
+               const int64_t *q_host, const int64_t *Ninv, int tail, int flags, const int64_t *ql, const int64_t *qh,
+               const int64_t *kl, const int64_t *kh, int device, void *stream);
 /* (measurement, as lf_ntt_pass: one of the two launches of lf_ntt_ws; which = 1 reads `a` and writes `ws`, 2 the reverse) */
 int lf_ntt_pass_ws(int64_t *a, int64_t *ws, int batch, int rows, int logN, const int64_t *psi_br, const double *psi_dp,
                    const int64_t *q_host, const int64_t *Rs, int flags, int which, const int64_t *ql, const int64_t *qh,

@@ -33,6 +33,7 @@ _SIGNATURES = {
     "lf_ntt_pass": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
     "lf_ntt_ws_words": [_I, _I, _I],
     "lf_ntt_ws": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P],
+    "lf_intt_ws": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
     "lf_ntt_pass_ws": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
     "lf_mont_mult": [_P, _P, _P, _I, _L, _P, _P, _P, _P, _I, _P],
     "lf_mont_enter": [_P, _P, _I, _L, _P, _P, _P, _P, _I, _P],

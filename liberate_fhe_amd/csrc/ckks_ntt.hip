@@ -180,6 +180,14 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
                 int64_t *ws = nullptr);
 
 template <int K>
+void launch_inv_cols_ws_k(unsigned blocks, hipStream_t st, const i64 *ws, const unsigned char *wflags, i64 *base,
+                                 const PassGeom &g, const ClassLists &cl, const i64 *ipsi_br, const double *ipsi_dp, const i64 *Ninv,
+                                 int tail, const i64 *ql, const i64 *qh, const i64 *kl, const i64 *kh) {
+    hipLaunchKernelGGL((ntt_inv_cols_ws<K>), dim3(blocks), dim3(NTT_COL_THREADS), 0, st, ws, wflags, base, g, cl, ipsi_br, ipsi_dp,
+                       Ninv, tail, ql, qh, kl, kh);
+}
+
+template <int K>
 void launch_cols_ws_k(unsigned blocks, hipStream_t st, const i64 *a, i64 *ws, unsigned char *wflags, const PassGeom &g,
                       const ClassLists &cl, const int64_t *psi_br, const double *psi_dp, const i64 *rs, const int64_t *ql,
                       const int64_t *qh, const int64_t *kl, const int64_t *kh) {
@@ -367,7 +375,7 @@ extern "C" {
 // element-wise product of two stacks, read from `src` / ms->b by the first pass and written to `a`
 static int intt_impl(int64_t *a, const int64_t *src, const MulSrc *ms, int batch, int rows, int logN, const int64_t *ipsi_br,
                      const double *ipsi_dp, const int64_t *q_host, const int64_t *Ninv, int tail, int flags, const int64_t *ql,
-                     const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
+                     const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream, int64_t *ws = nullptr) {
     if (batch < 0 || rows < 0 || rows > MAX_LIST_ROWS || logN < 1 || logN > 2 * NTT_TILE_LOG_MAX || tail < 0 || tail > 3)
         return LF_ERR_ARG;
     const int relaxed = flags & LF_NTT_RELAXED;
@@ -392,6 +400,26 @@ static int intt_impl(int64_t *a, const int64_t *src, const MulSrc *ms, int batch
         const PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, nb, relaxed, SB == 0, plain}
                                      : PassGeom{logN, tl, 1, SB, tl, tl - SB, rows, nb, relaxed, 1, plain};
         const int t = g.last ? tail : TAIL_NONE;
+        // through a workspace (lf_intt_ws): exact two-launch sizes; the tiled pass writes it, the column pass reads it
+        if (ws && !relaxed && !ms && SB >= 1 && SB <= 4) {
+            unsigned char *wflags = reinterpret_cast<unsigned char *>(ws + ((i64)nb * rows << logN));
+            if (pass == 0) {
+                const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
+                hipLaunchKernelGGL(ntt_pass16_inv_ws, dim3((unsigned)cl.in_blocks + per_row * (unsigned)dp.n), dim3(NTT16_THREADS), 0, st,
+                                   (const i64 *)base, (i64 *)ws, wflags, g, cl, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)ql,
+                                   (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+            } else {
+                const unsigned per_limb = (unsigned)nb * ((1u << (logN - SB)) / NTT_COL_THREADS);
+                const ClassLists cl = class_lists(in, dp, per_limb * (unsigned)in.n);
+                const unsigned blocks = (unsigned)cl.in_blocks + per_limb * (unsigned)dp.n;
+#define LF_ICW(KK)                                                                                                             \
+    launch_inv_cols_ws_k<KK>(blocks, st, (const i64 *)ws, wflags, base, g, cl, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t, \
+                             (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh)
+                if (SB == 1) LF_ICW(1); else if (SB == 2) LF_ICW(2); else if (SB == 3) LF_ICW(3); else LF_ICW(4);
+#undef LF_ICW
+            }
+            continue;
+        }
         if (pass == 1 && SB <= 4) {   // trailing stages + chain tail: one register step per column
             if (mixed) {
                 launch_inv_cols_mixed(SB, nb, st, base, g, in, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t,
@@ -435,6 +463,13 @@ int lf_intt(int64_t *a, int batch, int rows, int logN, const int64_t *ipsi_br, c
             const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
     (void)_2q;
     return intt_impl(a, nullptr, nullptr, batch, rows, logN, ipsi_br, ipsi_dp, q_host, Ninv, tail, flags, ql, qh, kl, kh, device, stream);
+}
+
+int lf_intt_ws(int64_t *a, int64_t *ws, int batch, int rows, int logN, const int64_t *ipsi_br, const double *ipsi_dp,
+               const int64_t *q_host, const int64_t *Ninv, int tail, int flags, const int64_t *ql, const int64_t *qh,
+               const int64_t *kl, const int64_t *kh, int device, void *stream) {
+    if (flags & LF_NTT_RELAXED) return LF_ERR_ARG;
+    return intt_impl(a, nullptr, nullptr, batch, rows, logN, ipsi_br, ipsi_dp, q_host, Ninv, tail, flags, ql, qh, kl, kh, device, stream, ws);
 }
 
 /* lf_intt_mul followed by lf_ks_digits of its result, the coefficient-domain product never written: the first inverse pass forms

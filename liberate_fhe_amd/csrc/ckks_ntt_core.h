@@ -1559,12 +1559,15 @@ __device__ __forceinline__ void cols_inv_stages(typename A::T (&x)[1 << K], cons
 
 // the column of lane `lane` of chunk `chunk` of limb (poly, crow): its 2^K words through the trailing stages and the chain
 // tail, returned in out[] (word k belongs at coefficient (k << logC) + chunk * NTT_COL_THREADS + lane)
-template <bool DP, int K>
+// WS (lf_intt_ws): `a` is the workspace the tiled pass wrote — fp64-class rows as planes, tflags = the row's flag bytes, one per
+// tile (= per held word k), set where the tile left the fast form and shipped a third plane (inv_tile16_ws, ckks_ntt_tile16.h)
+template <bool DP, int K, bool WS = false>
 __device__ __forceinline__ void inv_cols_compute(int poly, int crow, int chunk, const i64 *__restrict__ a, const PassGeom &g,
                                                  const i64 *__restrict__ ipsi_br, const double *__restrict__ ipsi_dp,
                                                  const i64 *__restrict__ Ninv, int tail, const i64 *__restrict__ ql,
                                                  const i64 *__restrict__ qh, const i64 *__restrict__ kl,
-                                                 const i64 *__restrict__ kh, i64 (&out)[1 << K]) {
+                                                 const i64 *__restrict__ kh, i64 (&out)[1 << K],
+                                                 const unsigned char *__restrict__ tflags = nullptr) {
     constexpr int R = 1 << K;
     const int logC = g.logN - K;
     Ctx c;
@@ -1581,8 +1584,29 @@ __device__ __forceinline__ void inv_cols_compute(int poly, int crow, int chunk, 
     const unsigned lane = threadIdx.x;
 
     i64 w[R];
+    if constexpr (WS && DP) {
+        const i64 *rowb = a + ((i64)(poly * g.rows + crow) << g.logN);
+        const i64 col0 = (i64)chunk * NTT_COL_THREADS;
+        const unsigned *lo = reinterpret_cast<const unsigned *>(rowb) + col0;
+        const unsigned short *mid = reinterpret_cast<const unsigned short *>(rowb + ((i64)1 << (g.logN - 1))) + col0;
 #pragma unroll
-    for (int k = 0; k < R; ++k) w[k] = INV_LD(uniform_row(colu, (i64)k << logC) + lane);
+        for (int k = 0; k < R; ++k) {
+            const unsigned l = __builtin_nontemporal_load(uniform_ptr(lo + ((i64)k << logC)) + lane);
+            const unsigned m = __builtin_nontemporal_load(uniform_ptr(mid + ((i64)k << logC)) + lane);
+            w[k] = (i64)(((u64)m << 32) | (u64)l);
+        }
+        const u64 *fp = reinterpret_cast<const u64 *>(tflags);
+        const u64 fl = fp[0], fh = R > 8 ? fp[1] : 0;
+        if ((fl | fh) != 0) {
+            const unsigned short *top = reinterpret_cast<const unsigned short *>(rowb + 3 * ((i64)1 << (g.logN - 2))) + col0;
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                if ((((k < 8 ? fl : fh) >> (8 * (k & 7))) & 0xffull) != 0) w[k] |= (i64)((u64)top[((i64)k << logC) + lane] << 48);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < R; ++k) w[k] = INV_LD(uniform_row(colu, (i64)k << logC) + lane);
+    }
     int odd = 0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -1649,6 +1673,43 @@ __device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const 
     const unsigned lane = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < R; ++k) INV_ST(uniform_row(colu, (i64)k << logC) + lane, out[k]);
+}
+
+// last pass of an exact inverse transform through a workspace (lf_intt_ws): reads the workspace, writes the tensor
+template <bool DP, int K>
+__device__ __forceinline__ void inv_cols_ws_body(int b, const i64 *__restrict__ ws, const unsigned char *__restrict__ wflags,
+                                                 i64 *__restrict__ a, const PassGeom &g, const RowList &rl,
+                                                 const i64 *__restrict__ ipsi_br, const double *__restrict__ ipsi_dp,
+                                                 const i64 *__restrict__ Ninv, int tail, const i64 *__restrict__ ql,
+                                                 const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                                 const i64 *__restrict__ kh) {
+    constexpr int R = 1 << K;
+    const int logC = g.logN - K;
+    const int chunks = (1 << logC) / NTT_COL_THREADS;
+    const int chunk = b % chunks, r = b / chunks;
+    const int poly = __builtin_amdgcn_readfirstlane(r % g.batch), crow = __builtin_amdgcn_readfirstlane((int)rl.id[r / g.batch]);
+    i64 out[R];
+    inv_cols_compute<DP, K, true>(poly, crow, chunk, ws, g, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh, out,
+                                  wflags + ((i64)(poly * g.rows + crow) << 6));
+    i64 *colu = a + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS;
+    const unsigned lane = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < R; ++k) INV_ST(uniform_row(colu, (i64)k << logC) + lane, out[k]);
+}
+
+template <int K>
+__global__ void __launch_bounds__(NTT_COL_THREADS) ntt_inv_cols_ws(const i64 *__restrict__ ws, const unsigned char *__restrict__ wflags,
+                                                                  i64 *__restrict__ a, PassGeom g, ClassLists cl,
+                                                                  const i64 *__restrict__ ipsi_br,
+                                                                  const double *__restrict__ ipsi_dp, const i64 *__restrict__ Ninv,
+                                                                  int tail, const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                  const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    const int b = blockIdx.x;
+    if (b < cl.in_blocks) {
+        if (b < cl.in_real) inv_cols_ws_body<false, K>(b, ws, wflags, a, g, cl.in, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh);
+    } else {
+        inv_cols_ws_body<true, K>(b - cl.in_blocks, ws, wflags, a, g, cl.dp, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh);
+    }
 }
 
 template <bool DP, int K>

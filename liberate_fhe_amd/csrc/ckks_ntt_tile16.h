@@ -201,8 +201,8 @@ __device__ __forceinline__ void inv_regs16_exact(double (&x)[16], int il, const 
 }
 
 // ---- odd tiles: the reference's signed arithmetic, stage by stage (rare; any thread count) -------------------------
-// (the tile's words are in LDS at PAD16(L), a barrier behind them)
-__device__ __forceinline__ void tile16_slow_lds(i64 *sm, i64 *dst, int base, int s0, int logN, bool inverse, const Ctx &c) {
+// (the tile's words are in LDS at PAD16(L), a barrier behind them — and again on return)
+__device__ __forceinline__ void tile16_slow_compute(i64 *sm, int base, int s0, int logN, bool inverse, const Ctx &c) {
     for (int j = 0; j < 12; ++j) {
         const int st = s0 + j;
         const int logd = inverse ? j : 11 - j;
@@ -221,6 +221,9 @@ __device__ __forceinline__ void tile16_slow_lds(i64 *sm, i64 *dst, int base, int
         }
         __syncthreads();
     }
+}
+__device__ __forceinline__ void tile16_slow_lds(i64 *sm, i64 *dst, int base, int s0, int logN, bool inverse, const Ctx &c) {
+    tile16_slow_compute(sm, base, s0, logN, inverse, c);
     for (int L = threadIdx.x; L < 4096; L += NTT16_THREADS) dst[L] = sm[PAD16(L)];
 }
 __device__ __forceinline__ void tile16_slow(i64 *sm, const i64 *src, i64 *dst, int base, int s0, int logN, bool inverse, const Ctx &c) {
@@ -614,6 +617,116 @@ __device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst
     if (!ok) {
         __syncthreads();
         tile16_slow(sm, src_row + base, dst_row + base, base, s, logN, true, c);
+    }
+}
+
+// ---- inverse tile of an EXACT transform through a workspace (lf_intt_ws): tensor in, workspace out -----------------------
+// The mirror image of fwd_tile16_ws: the tiled pass comes first and leaves the fp64-class rows in the workspace as planes for the
+// column pass (inv_cols_compute<.., WS>).  A tile that left the fast form (an operand outside [0, 2q): the reference's signed
+// arithmetic, whose words can be anything) writes all three planes and raises tflags[tile]; every other tile clears it.
+template <bool DP>
+__device__ __forceinline__ void inv_tile16_ws(i64 *sm, const i64 *src_row, i64 *ws_row, unsigned char *tflags, int tile,
+                                              const PassGeom &g, const Ctx &c) {
+    const int w = lf_tid();
+    const int base = tile << 12, logN = g.logN, s = g.s0;
+    const int L0 = ((w >> 6) << 10) + ((w & 63) << 1);
+    {
+        longlong2 in[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) in[i] = INV_LD2(src_row + base + L0 + (i << 7));
+        int odd = 0;
+        i64 *sp = sm + PAD16(L0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            odd |= ((u64)in[i].x >= (u64)c.m.q2) | ((u64)in[i].y >= (u64)c.m.q2);
+            sp[i * 136] = in[i].x;
+            sp[i * 136 + 1] = in[i].y;
+        }
+        wave_flag_set16(sm, odd, w);
+    }
+    wave_lds_sync();
+    i64 raw[16];
+    {
+        const i64 *sp = sm + 17 * w;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) raw[e] = sp[e];
+    }
+    Ctx cc = c;
+    cc.inv_reduce = 1;
+    unsigned *lo = reinterpret_cast<unsigned *>(ws_row) + base;
+    unsigned short *mid = reinterpret_cast<unsigned short *>(ws_row + ((i64)1 << (logN - 1))) + base;
+    bool ok;
+    if constexpr (DP) {
+        double x[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[e] = dp_from_word(raw[e]);
+        ok = inv_tile16_steps<ArithDp, true, false>(reinterpret_cast<double *>(sm), sm, x, w, base, logN, s, cc, true);
+        if (ok) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const i64 v = dp_to_word(x[e]);
+                __builtin_nontemporal_store((unsigned)v, uniform_ptr(lo + (e << 8)) + (unsigned)w);
+                __builtin_nontemporal_store((unsigned short)((u64)v >> 32), uniform_ptr(mid + (e << 8)) + (unsigned)w);
+            }
+            if (w == 0) tflags[tile] = 0;
+        }
+    } else {
+        ok = inv_tile16_steps<ArithInt<false>, false, false>(sm, sm, raw, w, base, logN, s, cc, true);
+        if (ok) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) INV_ST(uniform_ptr(ws_row + base + (e << 8)) + (unsigned)w, raw[e]);
+        }
+    }
+    if (!ok) {
+        __syncthreads();
+        if constexpr (DP) {
+            for (int L = threadIdx.x; L < 4096; L += NTT16_THREADS) sm[PAD16(L)] = src_row[base + L];
+            __syncthreads();
+            tile16_slow_compute(sm, base, s, logN, true, c);
+            unsigned short *top = reinterpret_cast<unsigned short *>(ws_row + 3 * ((i64)1 << (logN - 2))) + base;
+            for (int L = threadIdx.x; L < 4096; L += NTT16_THREADS) {
+                const u64 v = (u64)sm[PAD16(L)];
+                lo[L] = (unsigned)v, mid[L] = (unsigned short)(v >> 32), top[L] = (unsigned short)(v >> 48);
+            }
+            if (threadIdx.x == 0) tflags[tile] = 1;
+        } else {
+            tile16_slow(sm, src_row + base, ws_row + base, base, s, logN, true, c);
+        }
+    }
+}
+
+template <bool DP>
+__device__ __forceinline__ void pass16_inv_ws_body(i64 *sm, int b, const i64 *src, i64 *ws, unsigned char *wflags, const PassGeom &g,
+                                                   const RowList &rl, const i64 *__restrict__ tw_br,
+                                                   const double *__restrict__ tw_dp, const i64 *__restrict__ ql,
+                                                   const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                                   const i64 *__restrict__ kh) {
+    int poly, crow, tile;
+    block_coords(g, rl, b, poly, crow, tile);
+    poly = __builtin_amdgcn_readfirstlane(poly), crow = __builtin_amdgcn_readfirstlane(crow);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    Ctx c;
+    c.m = load_mod(ql, qh, kl, kh, crow);
+    c.tw_mont = tw_br + ((i64)crow << g.logN);
+    set_aux<DP>(c, tw_dp, crow, g.logN);
+    c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
+    c.relaxed = 0;
+    c.inv_reduce = 0;
+    const i64 ri = (i64)(poly * g.rows + crow);
+    inv_tile16_ws<DP>(sm, src + (ri << g.logN), ws + (ri << g.logN), wflags + (ri << 6), tile, g, c);
+}
+
+__global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_inv_ws(const i64 *src, i64 *ws, unsigned char *wflags, PassGeom g,
+                                                                        ClassLists cl, const i64 *__restrict__ tw_br,
+                                                                        const double *__restrict__ tw_dp,
+                                                                        const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                        const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT16_LDS_WORDS + 1];
+    const int b = blockIdx.x;
+    if (b < cl.in_blocks) {
+        if (b < cl.in_real) pass16_inv_ws_body<false>(sm, b, src, ws, wflags, g, cl.in, tw_br, tw_dp, ql, qh, kl, kh);
+    } else {
+        pass16_inv_ws_body<true>(sm, b - cl.in_blocks, src, ws, wflags, g, cl.dp, tw_br, tw_dp, ql, qh, kl, kh);
     }
 }
 

@@ -133,9 +133,9 @@ def _logN(ai):
     return N.bit_length() - 1
 
 
-# Workspace of the two-launch forward transform (lf_ntt_ws, include/ckks_hip.h: 6-byte words between its passes), one per
+# Workspace of the two-launch transforms (lf_ntt_ws / lf_intt_ws, include/ckks_hip.h: 6-byte words between their passes), one per
 # (device, stream) so that transforms on different streams never share it; grown on demand, as large as the largest stack
-# transformed on that stream.  Set ntt_cuda.USE_WORKSPACE = False to transform strictly in place (lf_ntt) at ~4 % of the rate.
+# transformed on that stream.  Set ntt_cuda.USE_WORKSPACE = False to transform strictly in place (lf_ntt / lf_intt), ~8 % slower on large stacks.
 USE_WORKSPACE = True
 _WS = {}
 
@@ -199,8 +199,13 @@ def _inverse(a, psi, Ninv, _2q, ql, qh, kl, kh, tail, what):
             continue
         dp = twiddles.dp_pointer(table, ql[i], qh[i], kl[i], kh[i], dev, st)
         _, qhost = twiddles.host_primes(ql[i], qh[i])
-        check(lib.lf_intt(_ptr(w), 1, ql[i].size(0), _logN(w), _ptr(table), dp, qhost, _ptr(Ninv[i].contiguous()), tail, 0,
-                          _ptr(_2q[i]), _ptr(ql[i]), _ptr(qh[i]), _ptr(kl[i]), _ptr(kh[i]), dev, st), what)
+        ws = _workspace(dev, st, ql[i].size(0), _logN(w))
+        if ws is not None:
+            check(lib.lf_intt_ws(_ptr(w), _ptr(ws), 1, ql[i].size(0), _logN(w), _ptr(table), dp, qhost, _ptr(Ninv[i].contiguous()), tail, 0,
+                                 _ptr(ql[i]), _ptr(qh[i]), _ptr(kl[i]), _ptr(kh[i]), dev, st), what)
+        else:
+            check(lib.lf_intt(_ptr(w), 1, ql[i].size(0), _logN(w), _ptr(table), dp, qhost, _ptr(Ninv[i].contiguous()), tail, 0,
+                              _ptr(_2q[i]), _ptr(ql[i]), _ptr(qh[i]), _ptr(kl[i]), _ptr(kh[i]), dev, st), what)
         if back is not None:
             back.copy_(w)
 

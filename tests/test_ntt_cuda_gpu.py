@@ -191,15 +191,15 @@ def test_ntt_tiles_with_out_of_range_words(mods, logN):
 
 
 @pytest.mark.parametrize("logN", [13, 14, 15, 16])
-def test_forward_transform_through_a_workspace_equals_in_place_and_oracle(mods, logN):
-    """lf_ntt_ws (what ntt_cuda.ntt / enter_ntt call at logN 13 .. 16: the two passes exchange the fp64-class limbs as 6-byte
-    planes through a workspace) against lf_ntt (USE_WORKSPACE = False) and the oracle: lazy operands; operands with arbitrary
+def test_transforms_through_a_workspace_equal_in_place_and_oracle(mods, logN):
+    """lf_ntt_ws / lf_intt_ws (what ntt_cuda.ntt / enter_ntt / intt* call at logN 13 .. 16: the two passes exchange the fp64-class
+    limbs as 6-byte planes through a workspace) against lf_ntt / lf_intt (USE_WORKSPACE = False) and the oracle: lazy operands; operands with arbitrary
     words below 2^61 in magnitude sprinkled over columns and tiles (a column wave that meets one ships its words' top 16 bits in a third
     plane and raises its flag; the tiles behind leave the fast form); a workspace full of ones before every call."""
     nc, orc = mods
     lim = Limbs(logN, pick_primes(logN, 3, 2))
     C = lim.rows
-    psi, _ = lim.mont_tables()
+    psi, ipsi = lim.mont_tables()
     d = lambda v: [dev(v)]
     consts = [d(lim._2q), d(lim.ql), d(lim.qh), d(lim.kl), d(lim.kh)]
     rng = np.random.default_rng(900 + logN)
@@ -224,6 +224,12 @@ def test_forward_transform_through_a_workspace_equals_in_place_and_oracle(mods, 
             nc.enter_ntt(t, d(lim.Rs), [None], [None], d(psi), *consts)
             both[use] = t[0].cpu().numpy()
         assert (both[True] == both[False]).all(), "any int64 words: workspace against in place"
+        for use in (True, False):
+            nc.USE_WORKSPACE = use
+            t = d(wild)
+            nc.intt_exit(t, [None], [None], d(ipsi), d(lim.Ninv), *consts)
+            both[use] = t[0].cpu().numpy()
+        assert (both[True] == both[False]).all(), "any int64 words, inverse: workspace against in place"
         for name, x in (("lazy", clean), ("arbitrary words", dirty), ("one clean limb", one_row_clean)):
             for entry in ("ntt", "enter_ntt"):
                 want = x.copy()
@@ -243,6 +249,22 @@ def test_forward_transform_through_a_workspace_equals_in_place_and_oracle(mods, 
                     got[use] = t[0].cpu().numpy()
                 assert (got[True] == want).all(), f"{entry}, {name}: through the workspace"
                 assert (got[False] == want).all(), f"{entry}, {name}: in place"
+            for tail, chain in enumerate(("intt", "intt_exit", "intt_exit_reduce", "intt_exit_reduce_signed")):
+                want = x.copy()
+                orc.intt(want, ipsi, lim.Ninv, C, logN, lim._2q, *lim.mont_args())
+                if tail >= 1:
+                    orc.mont_redc(want, C, *lim.mont_args())
+                if tail >= 2:
+                    orc.reduce_2q(want, C, lim._2q)
+                if tail >= 3:
+                    orc.make_signed(want, C, lim._2q)
+                for use in (True, False):
+                    nc.USE_WORKSPACE = use
+                    for ws in nc._WS.values():
+                        ws.fill_(-1)
+                    t = d(x)
+                    getattr(nc, chain)(t, [None], [None], d(ipsi), d(lim.Ninv), *consts)
+                    assert (t[0].cpu().numpy() == want).all(), f"{chain}, {name}: {'through the workspace' if use else 'in place'}"
     finally:
         nc.USE_WORKSPACE = True
     assert any(ws.numel() >= C * lim.N for ws in nc._WS.values())
