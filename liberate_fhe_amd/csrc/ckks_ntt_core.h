@@ -1325,11 +1325,17 @@ __device__ __forceinline__ void fwd_cols_ws_body(int b, const i64 *__restrict__ 
         else cols_fwd_stages<ArithInt<false>, K>(w, c);
     }
     i64 *orow = ws + (ri << g.logN);
+    // the wave's flag: one of its lanes met an operand outside [0, 2q) — only then can a word it writes lie outside [0, 2q)
+    // (the tiled pass tests its words for that only behind a raised flag) or, on an fp64-class row, need more than 48 bits
+    const bool wide = __builtin_amdgcn_ballot_w64(odd != 0) != 0;
+    if ((lane & 63u) == 0) {   // this wave's 64 columns c0 .. c0 + 63 are words 256 e + 64 v + (0 .. 63) of every tile: wave v, index e
+        const unsigned c0 = (unsigned)col0 + lane;
+        wflags[(ri << 6) + (((c0 >> 6) & 3u) << 4) + (c0 >> 8)] = wide ? 1 : 0;
+    }
     if constexpr (!DP) {
 #pragma unroll
         for (int k = 0; k < R; ++k) __builtin_nontemporal_store(w[k], uniform_ptr(orow + col0 + ((i64)k << logC)) + lane);
     } else {
-        const bool wide = __builtin_amdgcn_ballot_w64(odd != 0) != 0;   // (a lane of the fast branch holds words below 2^42)
         unsigned *lo = reinterpret_cast<unsigned *>(orow) + col0;
         unsigned short *mid = reinterpret_cast<unsigned short *>(orow + ((i64)1 << (g.logN - 1))) + col0;
 #pragma unroll
@@ -1343,10 +1349,6 @@ __device__ __forceinline__ void fwd_cols_ws_body(int b, const i64 *__restrict__ 
             unsigned short *top = reinterpret_cast<unsigned short *>(orow + 3 * ((i64)1 << (g.logN - 2))) + col0;
 #pragma unroll
             for (int k = 0; k < R; ++k) top[((i64)k << logC) + lane] = (unsigned short)((u64)w[k] >> 48);
-        }
-        if ((lane & 63u) == 0) {   // this wave's 64 columns c0 .. c0 + 63 are words 256 e + 64 v + (0 .. 63) of every tile: wave v, index e
-            const unsigned c0 = (unsigned)col0 + lane;
-            wflags[(ri << 6) + (((c0 >> 6) & 3u) << 4) + (c0 >> 8)] = wide ? 1 : 0;
         }
     }
 }
@@ -1584,6 +1586,12 @@ __device__ __forceinline__ void inv_cols_compute(int poly, int crow, int chunk, 
     const unsigned lane = threadIdx.x;
 
     i64 w[R];
+    u64 fl = 0, fh = 0;
+    if constexpr (WS) {
+        const u64 *fp = reinterpret_cast<const u64 *>(tflags);
+        fl = fp[0], fh = R > 8 ? fp[1] : 0;
+        if (R < 8) fl &= (1ull << (8 * (R & 7))) - 1;      // flag bytes of this row's 2^K tiles only
+    }
     if constexpr (WS && DP) {
         const i64 *rowb = a + ((i64)(poly * g.rows + crow) << g.logN);
         const i64 col0 = (i64)chunk * NTT_COL_THREADS;
@@ -1595,8 +1603,6 @@ __device__ __forceinline__ void inv_cols_compute(int poly, int crow, int chunk, 
             const unsigned m = __builtin_nontemporal_load(uniform_ptr(mid + ((i64)k << logC)) + lane);
             w[k] = (i64)(((u64)m << 32) | (u64)l);
         }
-        const u64 *fp = reinterpret_cast<const u64 *>(tflags);
-        const u64 fl = fp[0], fh = R > 8 ? fp[1] : 0;
         if ((fl | fh) != 0) {
             const unsigned short *top = reinterpret_cast<const unsigned short *>(rowb + 3 * ((i64)1 << (g.logN - 2))) + col0;
 #pragma unroll
@@ -1608,10 +1614,12 @@ __device__ __forceinline__ void inv_cols_compute(int poly, int crow, int chunk, 
         for (int k = 0; k < R; ++k) w[k] = INV_LD(uniform_row(colu, (i64)k << logC) + lane);
     }
     int odd = 0;
+    if (!WS || (fl | fh) != 0) {   // (WS: the words of unflagged tiles are lazy words by construction)
 #pragma unroll
-    for (int k = 0; k < R; ++k) {
-        // (relaxed: the words come from this library's relaxed tiled pass — canonical / lazy [0, 2q), never negative)
-        odd |= ((u64)w[k] >= (u64)c.m.q2);
+        for (int k = 0; k < R; ++k) {
+            // (relaxed: the words come from this library's relaxed tiled pass — canonical / lazy [0, 2q), never negative)
+            odd |= ((u64)w[k] >= (u64)c.m.q2);
+        }
     }
     if (DP && !odd) {
         double x[R];

@@ -422,10 +422,16 @@ __device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int t
 // Words the reference's arithmetic produces from operands outside [0, 2q) can be anything: a column wave that met such an
 // operand also writes the words' top 16 bits (third plane at byte 6 N) and raises its flag byte wf[v][e] (columns 256 e + 64 v
 // .. + 63); the tile's wave v reads exactly the words of those column waves, e = 0 .. 15, so it tests its own 16 flag bytes
-// (two scalar loads) and fetches the top plane only where one is set.  Integer-class rows are raw words in the workspace.
+// (two scalar loads), fetches the top plane only where one is set — and tests its words against 2q only then: the words of an
+// unflagged column wave are lazy words by construction.  Integer-class rows are raw words in the workspace, flagged alike.
+// returns whether one of the column waves behind this wave's words raised its flag (wave-uniform): only then can a word lie
+// outside [0, 2q)
 template <bool DP>
-__device__ __forceinline__ void ws_load_tile(const i64 *__restrict__ srow, const unsigned char *__restrict__ wf, int base, int E,
+__device__ __forceinline__ bool ws_load_tile(const i64 *__restrict__ srow, const unsigned char *__restrict__ wf, int base, int E,
                                              int w, i64 (&raw)[16]) {
+    const int wave = __builtin_amdgcn_readfirstlane(w >> 6);
+    const u64 *fp = reinterpret_cast<const u64 *>(wf + (wave << 4));
+    const u64 fl = fp[0], fh = fp[1];
     if constexpr (DP) {
         const unsigned *lo = reinterpret_cast<const unsigned *>(srow) + base;
         const unsigned short *mid = reinterpret_cast<const unsigned short *>(srow + ((i64)1 << (E - 1))) + base;
@@ -435,9 +441,6 @@ __device__ __forceinline__ void ws_load_tile(const i64 *__restrict__ srow, const
             const unsigned m = __builtin_nontemporal_load(uniform_ptr(mid + (e << 8)) + (unsigned)w);
             raw[e] = (i64)(((u64)m << 32) | (u64)l);
         }
-        const int wave = __builtin_amdgcn_readfirstlane(w >> 6);
-        const u64 *fp = reinterpret_cast<const u64 *>(wf + (wave << 4));
-        const u64 fl = fp[0], fh = fp[1];
         if ((fl | fh) != 0) {
             const unsigned short *top = reinterpret_cast<const unsigned short *>(srow + 3 * ((i64)1 << (E - 2))) + base;
 #pragma unroll
@@ -448,6 +451,7 @@ __device__ __forceinline__ void ws_load_tile(const i64 *__restrict__ srow, const
 #pragma unroll
         for (int e = 0; e < 16; ++e) raw[e] = __builtin_nontemporal_load(uniform_ptr(srow + base + (e << 8)) + (unsigned)w);
     }
+    return (fl | fh) != 0;
 }
 
 template <bool DP>
@@ -457,11 +461,13 @@ __device__ __forceinline__ void fwd_tile16_ws(i64 *sm, const i64 *__restrict__ s
     const int w = lf_tid();
     const int base = tile << 12, E = g.logN, s = g.s0;
     i64 raw[16];
-    ws_load_tile<DP>(srow, wf, base, E, w, raw);
+    const bool flagged = ws_load_tile<DP>(srow, wf, base, E, w, raw);
     {
         int odd = 0;
+        if (flagged) {   // (words of unflagged column waves are lazy words by construction: no test)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) odd |= ((u64)raw[e] >= (u64)c.m.q2);
+            for (int e = 0; e < 16; ++e) odd |= ((u64)raw[e] >= (u64)c.m.q2);
+        }
         wave_flag_set16(sm, odd, w);
     }
     i64 o[16];
@@ -623,7 +629,8 @@ __device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst
 // ---- inverse tile of an EXACT transform through a workspace (lf_intt_ws): tensor in, workspace out -----------------------
 // The mirror image of fwd_tile16_ws: the tiled pass comes first and leaves the fp64-class rows in the workspace as planes for the
 // column pass (inv_cols_compute<.., WS>).  A tile that left the fast form (an operand outside [0, 2q): the reference's signed
-// arithmetic, whose words can be anything) writes all three planes and raises tflags[tile]; every other tile clears it.
+// arithmetic, whose words can be anything) writes all three planes and raises tflags[tile]; every other tile clears it, and
+// the column pass tests the words of unflagged tiles neither for their top plane nor against 2q.
 template <bool DP>
 __device__ __forceinline__ void inv_tile16_ws(i64 *sm, const i64 *src_row, i64 *ws_row, unsigned char *tflags, int tile,
                                               const PassGeom &g, const Ctx &c) {
@@ -675,6 +682,7 @@ __device__ __forceinline__ void inv_tile16_ws(i64 *sm, const i64 *src_row, i64 *
         if (ok) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) INV_ST(uniform_ptr(ws_row + base + (e << 8)) + (unsigned)w, raw[e]);
+            if (w == 0) tflags[tile] = 0;
         }
     }
     if (!ok) {
@@ -691,6 +699,7 @@ __device__ __forceinline__ void inv_tile16_ws(i64 *sm, const i64 *src_row, i64 *
             if (threadIdx.x == 0) tflags[tile] = 1;
         } else {
             tile16_slow(sm, src_row + base, ws_row + base, base, s, logN, true, c);
+            if (threadIdx.x == 0) tflags[tile] = 1;
         }
     }
 }
