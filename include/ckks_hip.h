@@ -59,8 +59,8 @@ int lf_limits(int which);
  *                             where a digit's limbs fit a column thread (lf_intt_mul_digits); 0: always the two launches.
  *   LF_TUNE_DIGIT_PLANES      1 (default): between the halves of a key switch (lf_ks_fwd -> lf_ks_tail and every entry built on
  *                             them) the fp64-class rows of the scratch `tmp` hold their words as two planes, 6 bytes per word
- *                             (u32 low[N], u16 high[N] behind them) instead of 8, wherever the column kernel extends and the
- *                             limbs are of both classes; 0: raw words.  `tmp` is scratch either way; the knob must not change
+ *                             (u32 low[N], u16 high[N] behind them) instead of 8, at logN >= 13 when the limbs are of both
+ *                             classes; 0: raw words.  `tmp` is scratch either way; the knob must not change
  *                             between an lf_ks_fwd and its lf_ks_tail.
  *   (knob 0 was the one-launch key-switch transform of round 3: slower at every preset size on MI355X, removed.) */
 #define LF_TUNE_KS_EXT_COLS_MAX 1

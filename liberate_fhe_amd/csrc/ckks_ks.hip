@@ -153,7 +153,15 @@ __device__ __forceinline__ void ks_ext_body(i64 *sm, int b, const i64 *__restric
             longlong2 o;
             o.x = dp_to_word(dp_reduce(smd[PAD(L)], c.d.q, c.d.qinv));
             o.y = dp_to_word(dp_reduce(smd[PAD(L + 1)], c.d.q, c.d.qinv));
-            *reinterpret_cast<longlong2 *>(row + tile_gaddr(g, tile, L)) = o;
+            const i64 j = tile_gaddr(g, tile, L);   // even: words j, j + 1 are neighbours
+            if (kg.planes) {   // 8 + 4 bytes for the pair (digit_planes(): fwd_tile16<.., PLN> and the inner product read planes)
+                const lf_u2_t lo = {(unsigned)o.x, (unsigned)o.y};
+                *reinterpret_cast<lf_u2_t *>(reinterpret_cast<unsigned *>(row) + j) = lo;
+                *reinterpret_cast<unsigned *>(reinterpret_cast<unsigned short *>(row + (kg.N >> 1)) + j) =
+                    (unsigned)((u64)o.x >> 32) | ((unsigned)((u64)o.y >> 32) << 16);
+            } else {
+                *reinterpret_cast<longlong2 *>(row + j) = o;
+            }
         }
     } else {
         i64 cst[KS_MAX_ALPHA];
@@ -662,13 +670,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCT ==
 int g_ks_ext_cols_max = 4;
 
 // The extended digits between ks_forward and ks_tail (tmp: scratch of the key switch, opaque to the caller) keep the
-// fp64-class rows in planes format — 6 bytes per word on each of their three trips — wherever the column kernel extends
-// (logN 13 .. 12 + g_ks_ext_cols_max) and both classes are present.  BOTH halves decide with this function: the knobs must
-// not change between an lf_ks_fwd and its lf_ks_tail (lf_tune is a start-up / A-B facility, see the header).
+// fp64-class rows in planes format — 6 bytes per word on each of their three trips — at every two-pass ring degree (the column
+// kernel and the LDS-tiled extension both write it) where both classes are present.  BOTH halves decide with this function: the
+// knob must not change between an lf_ks_fwd and its lf_ks_tail (lf_tune is a start-up / A-B facility, see the header).
 int g_digit_planes = 1;
 bool digit_planes(int logN, const RowList &dp, const RowList &in) {
-    const int S1 = logN - NTT_TILE_LOG_MAX;
-    return g_digit_planes && S1 >= 1 && S1 <= g_ks_ext_cols_max && dp.n && in.n;
+    return g_digit_planes && logN > NTT_TILE_LOG_MAX && dp.n && in.n;
 }
 
 void classify_rows(int rows, const int64_t *q_host, RowList &dp, RowList &in) {

@@ -603,10 +603,12 @@ def test_key_switch_extension_in_horner_form_equals_the_sum_form(params):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("params", [dict(logN=13, num_scales=9, num_special_primes=2, is_secured=False), dict(logN=14), dict(logN=15, num_special_primes=2),
-                                    dict(logN=16, num_special_primes=4), dict(logN=13, scale_bits=45, num_scales=6, num_special_primes=4, is_secured=False)])
+                                    dict(logN=16, num_special_primes=4), dict(logN=13, scale_bits=45, num_scales=6, num_special_primes=4, is_secured=False),
+                                    dict(logN=17, num_scales=11, num_special_primes=3, is_secured=False)])
 def test_extended_digits_in_planes_format_equal_raw_words(params):
     """Between the halves of a key switch the fp64-class rows of the scratch hold 6-byte words in two planes (lf_tune
-    LF_TUNE_DIGIT_PLANES = 1, the default: ks_ext_cols -> fwd_tile16<.., PLN> -> ks_inner2_kernel<.., DPL>) or raw words (0): same
+    LF_TUNE_DIGIT_PLANES = 1, the default: ks_ext_cols or the LDS-tiled ks_ext_pass1 (logN 17; LF_TUNE_KS_EXT_COLS_MAX = 0) ->
+    fwd_tile16<.., PLN> -> ks_inner2_kernel<.., DPL>) or raw words (0): same
     words from cc_mult, rotate and the batches (launch sets of 4, 2 and 1 ciphertexts) at two levels."""
     from liberate_fhe_amd._native import lib
     from liberate_fhe_amd.fhe import ckks_engine
@@ -614,8 +616,9 @@ def test_extended_digits_in_planes_format_equal_raw_words(params):
     evk, rotk = synth.key_switch_key(eng, 5), synth.key_switch_key(eng, 6, origin="rotation key:3")
     outs = []
     try:
-        for planes in (1, 0, 1):
+        for planes, cols_max in ((1, 4), (0, 4), (1, 0), (0, 0), (1, 4)):   # cols_max 0: the LDS-tiled extension writes the planes
             assert lib.lf_tune(3, planes) in (0, 1)
+            lib.lf_tune(1, cols_max)
             res = []
             for level in (0, 2):
                 a, b = synth.ciphertext(eng, 50 + level, level), synth.ciphertext(eng, 60 + level, level)
@@ -624,7 +627,8 @@ def test_extended_digits_in_planes_format_equal_raw_words(params):
             outs.append([digest(x) for x in res])
     finally:
         lib.lf_tune(3, 1)
-    assert outs[0] == outs[1] == outs[2]
+        lib.lf_tune(1, 4)
+    assert outs[0] == outs[1] == outs[2] == outs[3] == outs[4]
     assert lib.lf_tune(3, -1) == 1 and lib.lf_tune(3, 2) == 1 and lib.lf_tune(3, -1) == 1      # query; out of range: unchanged
 
 
