@@ -6,20 +6,22 @@
 
 One "step" = one forward negacyclic NTT (ntt_cuda.ntt semantics, bit-exact lazy outputs) of a batch of
 B polynomials x 30 RNS limbs at logN = 16 — the gold preset's with-special row set at level 9 (25 scale
-primes + base + 4 special primes).  B = 128 by default (3.75 GiB-class working set: B x 30 MiB, far beyond the
+primes + base + 4 special primes) — through the C ABI entry lf_ntt_ws: lf_ntt with a resident workspace of the operands' size
+between its two launches, what ntt_cuda.ntt does for a caller (LF_BENCH_NTT_INPLACE=1: lf_ntt; extra.poly_ntt_per_s_in_place_lf_ntt
+reports that form beside the metric).  B = 128 by default (3.75 GiB-class working set: B x 30 MiB, far beyond the
 256 MiB Infinity Cache; at B = 16 the column pass still finds part of its input there and the launch tail of the
 tiled pass is 10 block rounds instead of 80).  Inputs are synthetic (splitmix64 -> mod 2q), resident in HBM before the timed region.
 Polynomials are independent, so ranks shard them with no data-path collective: weak scaling.
 
 The JSON line also carries
-  roofline     : the dominant kernel (ntt_pass16_fwd_seq: the tiled pass of all 30 limbs, the second of the two
+  roofline     : the dominant kernel (ntt_pass16_fwd_seq_ws: the tiled pass of all 30 limbs, the second of the two
                  launches of a transform, 12 of its 16 stages) against the 8 TB/s HBM peak; algorithmic bytes
                  per launch = 8*N*limbs (a transform is 16*N bytes per limb, SURVEY.md §8d, spread over its two
                  launches); its launch duration is measured live with HIP events on the launch stream, the
-                 kernel launched alone (lf_ntt_pass, the measurement entry) with the grid it has inside the full step;
+                 kernel launched alone (lf_ntt_pass_ws, the measurement entry) with the grid it has inside the full step;
                  `shader_clock_mhz` = the clock the CUs run at beside each kernel (lf_clock_probe on a second stream) and
-                 `package_power` = the amdgpu hwmon reading while the dominant kernel runs: both passes sit at the 1 400 W
-                 package cap and the tiled pass runs at ~1.9 of 2.4 GHz — `frac` is what that clock allows (DESIGN.md §4);
+                 `package_power` = the amdgpu hwmon reading while the dominant kernel runs: the tiled pass runs at ~1.93 of
+                 2.4 GHz with its VALUs 91 % busy — `frac` is what that clock allows (DESIGN.md §4);
   cpu_baseline : the C oracle (strict reference-kernel semantics) on this box's host cores, same workload,
                  bounded sample;
   roofline_engine_ops : cc_mult_evk / rotate_single per preset against the same HBM peak with SURVEY.md §8(d)'s
