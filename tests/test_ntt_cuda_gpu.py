@@ -270,6 +270,32 @@ def test_transforms_through_a_workspace_equal_in_place_and_oracle(mods, logN):
     assert any(ws.numel() >= C * lim.N for ws in nc._WS.values())
 
 
+@pytest.mark.parametrize("small,large", [(3, 0), (0, 2), (1, 0)])
+def test_workspace_transforms_with_one_arithmetic_class_only(mods, small, large):
+    """The workspace kernels take both class lists in one launch; either may be empty (only 40-bit primes / only 60-bit primes)."""
+    nc, orc = mods
+    for logN in (13, 16):
+        lim = Limbs(logN, pick_primes(logN, small, large))
+        C = lim.rows
+        psi, ipsi = lim.mont_tables()
+        d = lambda v: [dev(v)]
+        consts = [d(lim._2q), d(lim.ql), d(lim.qh), d(lim.kl), d(lim.kh)]
+        x = lim.uniform(41 + logN)
+        x[0, 7] = 2 * lim.q[0] + 3                       # one word outside [0, 2q)
+        want = x.copy()
+        orc.mont_enter(want, lim.Rs, C, *lim.mont_args())
+        orc.ntt(want, psi, C, logN, lim._2q, *lim.mont_args())
+        t = d(x)
+        nc.enter_ntt(t, d(lim.Rs), [None], [None], d(psi), *consts)
+        assert (t[0].cpu().numpy() == want).all(), (logN, "enter_ntt")
+        back = want.copy()
+        orc.intt(back, ipsi, lim.Ninv, C, logN, lim._2q, *lim.mont_args())
+        orc.mont_redc(back, C, *lim.mont_args())
+        orc.reduce_2q(back, C, lim._2q)
+        nc.intt_exit_reduce(t, [None], [None], d(ipsi), d(lim.Ninv), *consts)
+        assert (t[0].cpu().numpy() == back).all(), (logN, "intt_exit_reduce")
+
+
 def test_workspace_entry_argument_checks(mods):
     """lf_ntt_ws: relaxed transforms are refused before anything is launched; without a workspace, and at sizes with one
     launch (logN <= 12) or the LDS-tiled first pass (logN 17), it IS lf_ntt."""
