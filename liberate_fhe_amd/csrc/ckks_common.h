@@ -110,6 +110,20 @@ static __device__ __forceinline__ u64 csub_u(u64 x, u64 m) {
     return ((u64)th << 32) | tl;
 }
 
+// U - V + (U < V ? m : 0) for 0 <= U, V < m: subtract, select the modulus on the borrow, add — the value of
+// csub(U + m - V, m) in 6 instructions instead of 8
+static __device__ __forceinline__ u64 sub_lazy_u(u64 U, u64 V, u64 m) {
+    const unsigned ul = (unsigned)U, uh = (unsigned)(U >> 32), vl = (unsigned)V, vh = (unsigned)(V >> 32), ml = (unsigned)m, mh = (unsigned)(m >> 32);
+    unsigned tl, th, sl, sh;
+    asm("v_sub_co_u32 %0, vcc, %4, %6\n\tv_subb_co_u32 %1, vcc, %5, %7, vcc\n\t"
+        "v_cndmask_b32 %2, 0, %8, vcc\n\tv_cndmask_b32 %3, 0, %9, vcc\n\t"
+        "v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %3, vcc"
+        : "=&v"(tl), "=&v"(th), "=&v"(sl), "=&v"(sh)
+        : "v"(ul), "v"(uh), "v"(vl), "v"(vh), "v"(ml), "v"(mh)
+        : "vcc");
+    return ((u64)th << 32) | tl;
+}
+
 // lazy word below 8q -> canonical residue
 static __device__ __forceinline__ u64 shoup_canon(u64 x, u64 q) { return csub_u(csub_u(csub_u(x, q << 2), q << 1), q); }
 

@@ -251,16 +251,28 @@ struct ArithInt {
     static __device__ __forceinline__ T mul(const Ctx &c, W S, T O) {
         return SIGNED ? mm62s(S, O, c.m.q, c.m.k) : mm62u((u64)S, (u64)O, c.m.q, c.m.k);
     }
+    // (unsigned form — every word in [0, 2q) — : the same values from the borrow-select helpers, 4 instructions fewer per butterfly)
     static __device__ __forceinline__ void fwd(const Ctx &c, T &a, T &b, W S, int) {
         const T U = a, V = mul(c, S, b);
-        a = csub(U + V, c.m.q2);
-        b = csub(U + c.m.q2 - V, c.m.q2);
+        if constexpr (SIGNED) {
+            a = csub(U + V, c.m.q2);
+            b = csub(U + c.m.q2 - V, c.m.q2);
+        } else {
+            a = (T)csub_u((u64)U + (u64)V, (u64)c.m.q2);
+            b = (T)sub_lazy_u((u64)U, (u64)V, (u64)c.m.q2);
+        }
     }
     static __device__ __forceinline__ void inv(const Ctx &c, T &a, T &b, W S, int) {
         const T U = a, V = b;
-        const T O = csub(U + c.m.q2 - V, c.m.q2);
-        b = mul(c, S, O);
-        a = csub(U + V, c.m.q2);
+        if constexpr (SIGNED) {
+            const T O = csub(U + c.m.q2 - V, c.m.q2);
+            b = mul(c, S, O);
+            a = csub(U + V, c.m.q2);
+        } else {
+            const T O = (T)sub_lazy_u((u64)U, (u64)V, (u64)c.m.q2);
+            b = mul(c, S, O);
+            a = (T)csub_u((u64)U + (u64)V, (u64)c.m.q2);
+        }
     }
     template <int NN>
     static __device__ __forceinline__ void fwd_end(const Ctx &, T (&)[NN]) {}
