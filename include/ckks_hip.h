@@ -53,8 +53,8 @@ int lf_limits(int which);
  * unknown `which`; value < 0 only reads.  PROCESS-WIDE mutable state, read by every entry at launch time on whatever
  * thread calls it and not synchronised: set it once, before any other thread launches (the engine never touches it; only
  * the A/B tools under tools/ do).
- *   LF_TUNE_KS_EXT_COLS_MAX   largest logN - 12 (0 .. 4) for which the key switch's extension + leading stages run as the
- *                             column kernel (one register step per column, no LDS); above it the LDS-tiled form.
+ *   LF_TUNE_KS_EXT_COLS_MAX   largest logN - 12 (0 .. 5, default 5) for which the key switch's extension + leading stages run as
+ *                             the column kernel (one register step per column, no LDS); above it the LDS-tiled form.
  *   LF_TUNE_INTT_DIGITS       1 (default): lf_cc_mult_evk(_batch / _pre) form the digits of x1 * y1 inside the last inverse pass
  *                             where a digit's limbs fit a column thread (lf_intt_mul_digits); 0: always the two launches.
  *   LF_TUNE_DIGIT_PLANES      1 (default): between the halves of a key switch (lf_ks_fwd -> lf_ks_tail and every entry built on
@@ -158,7 +158,7 @@ int lf_ntt(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br, con
  * pass reads those — 12.5 % fewer bytes per pass; operands outside [0, 2q), whose words can be anything, travel with a third
  * plane and a flag per column wave, so the reference's result on ANY int64 input is reproduced as by lf_ntt.
  * ws: lf_ntt_ws_words(batch, rows, logN) words of device memory, 16-byte aligned, contents irrelevant before and scratch
- * after; it must not be used by another stream while the call runs.  ws = NULL, logN <= 12 or > 16: lf_ntt.  The reference's
+ * after; it must not be used by another stream while the call runs.  ws = NULL, logN <= 12 or > 17: lf_ntt.  The reference's
  * ntt (ntt.cpp:421-437) allocates nothing because it makes logN passes in place; the workspace is this design's price for
  * making two.  LF_NTT_RELAXED: LF_ERR_ARG. */
 int64_t lf_ntt_ws_words(int batch, int rows, int logN);

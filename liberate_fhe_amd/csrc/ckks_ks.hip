@@ -397,7 +397,7 @@ __device__ __forceinline__ void ks_ext_cols_body(int b, const i64 *__restrict__ 
 #define KS_EXT_COLS_WAVES 4
 #endif
 template <int K>
-__global__ void __launch_bounds__(NTT_COL_THREADS) __attribute__((amdgpu_waves_per_eu(KS_EXT_COLS_WAVES))) ks_ext_cols_mixed(const i64 *__restrict__ state, i64 *__restrict__ tmp,
+__global__ void __launch_bounds__(NTT_COL_THREADS) __attribute__((amdgpu_waves_per_eu(K == 5 ? 2 : KS_EXT_COLS_WAVES))) ks_ext_cols_mixed(const i64 *__restrict__ state, i64 *__restrict__ tmp,
                                                                      KsGeom kg, ClassLists cl, const i64 *__restrict__ desc,
                                                                      const i64 *__restrict__ E, const double *__restrict__ Ed,
                                                                      const i64 *__restrict__ psi_br,
@@ -667,7 +667,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCT ==
 // With the digit loop as a runtime loop (R loads in flight, 100 VGPRs at R = 16) the column form also wins at logN 16:
 // gold cc_mult 2 104-2 130 -> 2 168-2 183 ops/s, rotate 2 653-2 695 -> 2 733-2 763, 64 rotations under one key
 // 3 110 -> 3 300 /s (tools/eo.py --ext-cols-max 3 | 4, one box); round 2's fully unrolled form had lost there (116 vs 95 us).
-int g_ks_ext_cols_max = 4;
+// And at logN 17 (platinum, 32 words per thread: 173 VGPRs, 2 waves per SIMD — the kernel's waves_per_eu follows K), together with
+// the column form of the sums' last inverse pass: cc_mult 2 163 -> 2 054 us, rotate 1 845 -> 1 740 us, same words.
+int g_ks_ext_cols_max = 5;
 
 // The extended digits between ks_forward and ks_tail (tmp: scratch of the key switch, opaque to the caller) keep the
 // fp64-class rows in planes format — 6 bytes per word on each of their three trips — at every two-pass ring degree (the column
@@ -712,7 +714,7 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
                            (const i64 *)desc, (const i64 *)E, Ed, (const i64 *)psi_br, psi_dp, (const i64 *)ql,         \
                            (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);                                         \
         break;
-        switch (S1) { LF_EXT_COLS_CASE(1) LF_EXT_COLS_CASE(2) LF_EXT_COLS_CASE(3) LF_EXT_COLS_CASE(4) }
+        switch (S1) { LF_EXT_COLS_CASE(1) LF_EXT_COLS_CASE(2) LF_EXT_COLS_CASE(3) LF_EXT_COLS_CASE(4) LF_EXT_COLS_CASE(5) }
 #undef LF_EXT_COLS_CASE
     } else if (mixed) {
         const ClassLists cl = class_lists(in, dp, tiles * in.n * polys);
@@ -789,7 +791,7 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
                           (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
             continue;
         }
-        if (pass == 1 && S1 <= 4) {
+        if (pass == 1 && (S1 <= 4 || (S1 == 5 && mixed && g_ks_ext_cols_max > 4))) {   // (logN 17: the column form of both ends goes with the knob)
             if (mixed) {
                 launch_inv_cols_mixed(S1, inv_polys, st, (i64 *)s, g, in, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,
                                       (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
@@ -835,7 +837,7 @@ int lf_tune(int which, int value) {
     if (!knob) return -1;
     const int old = *knob;
     if (value < 0) return old;
-    if (which == LF_TUNE_KS_EXT_COLS_MAX && value > 4) return old;
+    if (which == LF_TUNE_KS_EXT_COLS_MAX && value > 5) return old;
     if ((which == LF_TUNE_INTT_DIGITS || which == LF_TUNE_DIGIT_PLANES) && value > 1) return old;
     *knob = value;
     return old;

@@ -106,6 +106,7 @@ void launch_cols_mixed_rs(int K, unsigned per_limb, hipStream_t st, i64 *base, c
         case 2: launch_cols_mixed_rs_k<2>(blocks, st, base, g, cl, rsrc, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
         case 3: launch_cols_mixed_rs_k<3>(blocks, st, base, g, cl, rsrc, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
         case 4: launch_cols_mixed_rs_k<4>(blocks, st, base, g, cl, rsrc, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+        case 5: launch_cols_mixed_rs_k<5>(blocks, st, base, g, cl, rsrc, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
     }
 }
 
@@ -258,8 +259,8 @@ int lf_rescale_ntt(const int64_t *const *in, const int64_t *const *row0, int cou
     if ((flags & LF_NTT_RELAXED) && (!psi_dp || !q_host)) return LF_ERR_ARG;   // before anything is launched
     if (count == 0 || rows == 0) return 0;
     const int S1 = logN - NTT_TILE_LOG_MAX;
-    if ((flags & (LF_NTT_ONLY_COLS | LF_NTT_ONLY_TILED)) && !(S1 >= 1 && S1 <= 4)) return LF_ERR_ARG;   // two-launch sizes only
-    if (S1 >= 1 && S1 <= 4) {
+    if ((flags & (LF_NTT_ONLY_COLS | LF_NTT_ONLY_TILED)) && !(S1 >= 1 && S1 <= 5)) return LF_ERR_ARG;   // two-launch sizes only
+    if (S1 >= 1 && S1 <= 5) {
         RescaleSrc rsrc;
         for (int i = 0; i < count; ++i) rsrc.in[i] = (const i64 *)in[i], rsrc.row0[i] = (const i64 *)row0[i];
         rsrc.scales = (const i64 *)scales;
@@ -304,7 +305,7 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
     const int nb = batch;
     const unsigned per_row = (unsigned)nb << (logN - tl);
     // through a workspace (lf_ntt_ws): exact two-launch sizes whose tiled pass is the 4096-word one; anything else ignores `ws`
-    const bool through_ws = ws && !relaxed && !rsrc && S1 >= 1 && S1 <= 4 && tl == NTT_TILE_LOG_MAX;
+    const bool through_ws = ws && !relaxed && !rsrc && S1 >= 1 && S1 <= 5 && tl == NTT_TILE_LOG_MAX;
     unsigned char *wflags = through_ws ? reinterpret_cast<unsigned char *>(ws + ((i64)nb * rows << logN)) : nullptr;
     for (int pass = (S1 > 0 ? 0 : 1); pass < 2; ++pass) {
         if (only_pass && pass + 1 != only_pass) continue;   // measurement only: time one pass kernel by itself
@@ -321,6 +322,7 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
                     case 2: launch_cols_ws_k<2>(blocks, st, base, (i64 *)ws, wflags, g, cl, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
                     case 3: launch_cols_ws_k<3>(blocks, st, base, (i64 *)ws, wflags, g, cl, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
                     case 4: launch_cols_ws_k<4>(blocks, st, base, (i64 *)ws, wflags, g, cl, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
+                    case 5: launch_cols_ws_k<5>(blocks, st, base, (i64 *)ws, wflags, g, cl, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
                 }
             } else {
                 launch_pass16_ws(nb, st, (const i64 *)ws, wflags, base, g, in, dp, (const i64 *)psi_br, psi_dp, (const i64 *)ql,
@@ -328,7 +330,8 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
             }
             continue;
         }
-        if (pass == 0 && S1 <= 4) {   // leading stages: one register step per column
+        if (pass == 0 && (S1 <= 4 || (S1 == 5 && rsrc))) {   // leading stages: one register step per column (logN 17: only the
+            // rescale form — the general in-place body needs 256 registers at 32 words per thread; lf_ntt_ws has its own)
             const unsigned col_blocks = (unsigned)nb * ((1u << (logN - S1)) / NTT_COL_THREADS);
             if (rsrc) {
                 launch_cols_mixed_rs(S1, col_blocks, st, base, g, in, dp, *rsrc, psi_br, psi_dp, rs, ql, qh, kl, kh);
@@ -401,7 +404,7 @@ static int intt_impl(int64_t *a, const int64_t *src, const MulSrc *ms, int batch
                                      : PassGeom{logN, tl, 1, SB, tl, tl - SB, rows, nb, relaxed, 1, plain};
         const int t = g.last ? tail : TAIL_NONE;
         // through a workspace (lf_intt_ws): exact two-launch sizes; the tiled pass writes it, the column pass reads it
-        if (ws && !relaxed && !ms && SB >= 1 && SB <= 4) {
+        if (ws && !relaxed && !ms && SB >= 1 && SB <= 5) {
             unsigned char *wflags = reinterpret_cast<unsigned char *>(ws + ((i64)nb * rows << logN));
             if (pass == 0) {
                 const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
@@ -415,12 +418,12 @@ static int intt_impl(int64_t *a, const int64_t *src, const MulSrc *ms, int batch
 #define LF_ICW(KK)                                                                                                             \
     launch_inv_cols_ws_k<KK>(blocks, st, (const i64 *)ws, wflags, base, g, cl, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t, \
                              (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh)
-                if (SB == 1) LF_ICW(1); else if (SB == 2) LF_ICW(2); else if (SB == 3) LF_ICW(3); else LF_ICW(4);
+                if (SB == 1) LF_ICW(1); else if (SB == 2) LF_ICW(2); else if (SB == 3) LF_ICW(3); else if (SB == 4) LF_ICW(4); else LF_ICW(5);
 #undef LF_ICW
             }
             continue;
         }
-        if (pass == 1 && SB <= 4) {   // trailing stages + chain tail: one register step per column
+        if (pass == 1 && (SB <= 4 || (SB == 5 && mixed))) {   // trailing stages + chain tail: one register step per column
             if (mixed) {
                 launch_inv_cols_mixed(SB, nb, st, base, g, in, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, t,
                                       (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);

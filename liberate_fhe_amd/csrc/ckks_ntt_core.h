@@ -1598,11 +1598,16 @@ __device__ __forceinline__ void inv_cols_compute(int poly, int crow, int chunk, 
     const unsigned lane = threadIdx.x;
 
     i64 w[R];
-    u64 fl = 0, fh = 0;
+    constexpr int FW = (R + 7) / 8;                          // flag bytes of this row's 2^K tiles, eight per scalar load
+    u64 fw[FW];
+    u64 fany = 0;
     if constexpr (WS) {
         const u64 *fp = reinterpret_cast<const u64 *>(tflags);
-        fl = fp[0], fh = R > 8 ? fp[1] : 0;
-        if (R < 8) fl &= (1ull << (8 * (R & 7))) - 1;      // flag bytes of this row's 2^K tiles only
+#pragma unroll
+        for (int i = 0; i < FW; ++i) fw[i] = fp[i];
+        if (R < 8) fw[0] &= (1ull << (8 * (R & 7))) - 1;
+#pragma unroll
+        for (int i = 0; i < FW; ++i) fany |= fw[i];
     }
     if constexpr (WS && DP) {
         const i64 *rowb = a + ((i64)(poly * g.rows + crow) << g.logN);
@@ -1615,18 +1620,18 @@ __device__ __forceinline__ void inv_cols_compute(int poly, int crow, int chunk, 
             const unsigned m = __builtin_nontemporal_load(uniform_ptr(mid + ((i64)k << logC)) + lane);
             w[k] = (i64)(((u64)m << 32) | (u64)l);
         }
-        if ((fl | fh) != 0) {
+        if (fany != 0) {
             const unsigned short *top = reinterpret_cast<const unsigned short *>(rowb + 3 * ((i64)1 << (g.logN - 2))) + col0;
 #pragma unroll
             for (int k = 0; k < R; ++k)
-                if ((((k < 8 ? fl : fh) >> (8 * (k & 7))) & 0xffull) != 0) w[k] |= (i64)((u64)top[((i64)k << logC) + lane] << 48);
+                if (((fw[k >> 3] >> (8 * (k & 7))) & 0xffull) != 0) w[k] |= (i64)((u64)top[((i64)k << logC) + lane] << 48);
         }
     } else {
 #pragma unroll
         for (int k = 0; k < R; ++k) w[k] = INV_LD(uniform_row(colu, (i64)k << logC) + lane);
     }
     int odd = 0;
-    if (!WS || (fl | fh) != 0) {   // (WS: the words of unflagged tiles are lazy words by construction)
+    if (!WS || fany != 0) {   // (WS: the words of unflagged tiles are lazy words by construction)
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             // (relaxed: the words come from this library's relaxed tiled pass — canonical / lazy [0, 2q), never negative)
@@ -1807,6 +1812,7 @@ inline void launch_inv_cols_mixed(int K, int polys, hipStream_t st, i64 *base, c
         case 2: launch_inv_cols_mixed_k<2>(blocks, st, base, g, cl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh); break;
         case 3: launch_inv_cols_mixed_k<3>(blocks, st, base, g, cl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh); break;
         case 4: launch_inv_cols_mixed_k<4>(blocks, st, base, g, cl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh); break;
+        case 5: launch_inv_cols_mixed_k<5>(blocks, st, base, g, cl, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh); break;
     }
 }
 

@@ -141,7 +141,7 @@ _WS = {}
 
 
 def _workspace(dev, st, rows, logN):
-    if not USE_WORKSPACE or logN < 13 or logN > 16:
+    if not USE_WORKSPACE or logN < 13 or logN > 17:
         return None
     words = int(lib.lf_ntt_ws_words(1, rows, logN))
     ws = _WS.get((dev, st))

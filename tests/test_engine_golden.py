@@ -616,7 +616,7 @@ def test_extended_digits_in_planes_format_equal_raw_words(params):
     evk, rotk = synth.key_switch_key(eng, 5), synth.key_switch_key(eng, 6, origin="rotation key:3")
     outs = []
     try:
-        for planes, cols_max in ((1, 4), (0, 4), (1, 0), (0, 0), (1, 4)):   # cols_max 0: the LDS-tiled extension writes the planes
+        for planes, cols_max in ((1, 5), (0, 5), (1, 0), (0, 0), (1, 5)):   # cols_max 0: the LDS-tiled extension writes the planes
             assert lib.lf_tune(3, planes) in (0, 1)
             lib.lf_tune(1, cols_max)
             res = []
@@ -627,7 +627,7 @@ def test_extended_digits_in_planes_format_equal_raw_words(params):
             outs.append([digest(x) for x in res])
     finally:
         lib.lf_tune(3, 1)
-        lib.lf_tune(1, 4)
+        lib.lf_tune(1, 5)
     assert outs[0] == outs[1] == outs[2] == outs[3] == outs[4]
     assert lib.lf_tune(3, -1) == 1 and lib.lf_tune(3, 2) == 1 and lib.lf_tune(3, -1) == 1      # query; out of range: unchanged
 
@@ -682,7 +682,7 @@ def test_public_key_switch_step_methods_hip(params):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,cols_max", [("gold", 3), ("silver", 0), ("bronze", 0)])
+@pytest.mark.parametrize("name,cols_max", [("gold", 3), ("silver", 0), ("bronze", 0), ("platinum", 4)])
 def test_key_switch_extension_column_and_tiled_forms(name, cols_max):
     """The key switch's extension + leading stages as the column kernel (one register step per column) and as the LDS-tiled
     kernel, forced through lf_tune for the size whose default is the other one: the reference digests either way."""

@@ -190,9 +190,9 @@ def test_ntt_tiles_with_out_of_range_words(mods, logN):
         assert (t[0].cpu().numpy() == want_i).all(), name
 
 
-@pytest.mark.parametrize("logN", [13, 14, 15, 16])
+@pytest.mark.parametrize("logN", [13, 14, 15, 16, 17])
 def test_transforms_through_a_workspace_equal_in_place_and_oracle(mods, logN):
-    """lf_ntt_ws / lf_intt_ws (what ntt_cuda.ntt / enter_ntt / intt* call at logN 13 .. 16: the two passes exchange the fp64-class
+    """lf_ntt_ws / lf_intt_ws (what ntt_cuda.ntt / enter_ntt / intt* call at logN 13 .. 17: the two passes exchange the fp64-class
     limbs as 6-byte planes through a workspace) against lf_ntt / lf_intt (USE_WORKSPACE = False) and the oracle: lazy operands; operands with arbitrary
     words below 2^61 in magnitude sprinkled over columns and tiles (a column wave that meets one ships its words' top 16 bits in a third
     plane and raises its flag; the tiles behind leave the fast form); a workspace full of ones before every call."""
@@ -298,7 +298,7 @@ def test_workspace_transforms_with_one_arithmetic_class_only(mods, small, large)
 
 def test_workspace_entry_argument_checks(mods):
     """lf_ntt_ws: relaxed transforms are refused before anything is launched; without a workspace, and at sizes with one
-    launch (logN <= 12) or the LDS-tiled first pass (logN 17), it IS lf_ntt."""
+    launch (logN <= 12), it IS lf_ntt."""
     from liberate_fhe_amd._native import lib
     from liberate_fhe_amd.ntt import twiddles
     nc, orc = mods
