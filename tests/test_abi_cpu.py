@@ -173,7 +173,7 @@ def test_lf_tune_is_a_pure_host_call():
     from liberate_fhe_amd._native import lib
     assert lib.lf_tune(0, -1) == -1     # the round-3 one-launch knob is gone
     cols = lib.lf_tune(1, -1)
-    assert 0 <= cols <= 4
+    assert 0 <= cols <= 5
     assert lib.lf_tune(1, 9) == cols and lib.lf_tune(1, -1) == cols      # out of range: ignored
     assert lib.lf_tune(3, -1) == 1 and lib.lf_tune(3, 5) == 1     # digit planes: on by default; out of range: ignored
     assert lib.lf_tune(77, 1) == -1
