@@ -62,10 +62,14 @@ int lf_limits(int which);
  *                             (u32 low[N], u16 high[N] behind them) instead of 8, at logN >= 13 when the limbs are of both
  *                             classes; 0: raw words.  `tmp` is scratch either way; the knob must not change
  *                             between an lf_ks_fwd and its lf_ks_tail.
+ *   LF_TUNE_WS_EXTRA_STAGE    1 (default): in lf_ntt_ws at logN 13 .. 16 the column pass takes one stage more than logN - 12 (it is
+ *                             HBM-bound with issue slots to spare) and the tiled pass, which is issue-bound, skips its first; 0: the
+ *                             split of lf_ntt.  The knob must not change between the two launches of a transform (lf_ntt_pass_ws).
  *   (knob 0 was the one-launch key-switch transform of round 3: slower at every preset size on MI355X, removed.) */
 #define LF_TUNE_KS_EXT_COLS_MAX 1
 #define LF_TUNE_INTT_DIGITS 2
 #define LF_TUNE_DIGIT_PLANES 3
+#define LF_TUNE_WS_EXTRA_STAGE 4
 int lf_tune(int which, int value);
 
 /* Measurement entry (not one of the reference's ops; the engine never calls it): ONE wave, launched on `stream`, takes

@@ -828,17 +828,18 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
 
 // cc_mult's product -> digits in one launch behind the tiled pass where it qualifies (ckks_ops.hip: product_digits): 0 = never
 int lf_g_intt_digits = 1;
+extern int lf_g_ws_extra_stage;   // ckks_ntt.hip
 
 extern "C" {
 
 int lf_tune(int which, int value) {
     int *knob = which == LF_TUNE_KS_EXT_COLS_MAX ? &g_ks_ext_cols_max : which == LF_TUNE_INTT_DIGITS ? &lf_g_intt_digits
-                : which == LF_TUNE_DIGIT_PLANES ? &g_digit_planes : nullptr;
+                : which == LF_TUNE_DIGIT_PLANES ? &g_digit_planes : which == LF_TUNE_WS_EXTRA_STAGE ? &lf_g_ws_extra_stage : nullptr;
     if (!knob) return -1;
     const int old = *knob;
     if (value < 0) return old;
     if (which == LF_TUNE_KS_EXT_COLS_MAX && value > 5) return old;
-    if ((which == LF_TUNE_INTT_DIGITS || which == LF_TUNE_DIGIT_PLANES) && value > 1) return old;
+    if ((which == LF_TUNE_INTT_DIGITS || which == LF_TUNE_DIGIT_PLANES || which == LF_TUNE_WS_EXTRA_STAGE) && value > 1) return old;
     *knob = value;
     return old;
 }

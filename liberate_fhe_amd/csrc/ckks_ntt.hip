@@ -36,6 +36,8 @@
 #include "ckks_ntt_tile16.h"
 #include <stdlib.h>
 
+int lf_g_ws_extra_stage = 1;   // lf_ntt_ws: the column pass takes the tiles' first stage too (ntt_forward; lf_tune in ckks_ks.hip)
+
 namespace {
 
 // split the rows into the two arithmetic classes (host side; q_host may be NULL = all integer)
@@ -313,11 +315,16 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
                                      : PassGeom{logN, tl, 0, tl, S1, 0, rows, nb, relaxed, 1, plain};
         const i64 *rs = (pass == 0 || S1 == 0) ? (const i64 *)Rs : nullptr;
         if (through_ws) {
+            // the column pass is HBM-bound with half its issue slots free, the tiled pass issue-bound: through a workspace the
+            // column pass takes ONE STAGE MORE (up to 5: 32 words per thread, 141 registers, still at the HBM rate) and the
+            // tiles skip their first (lf_tune LF_TUNE_WS_EXTRA_STAGE)
+            const bool extra = lf_g_ws_extra_stage && S1 <= 4;
+            const int Kc = S1 + (extra ? 1 : 0);
             if (pass == 0) {
-                const unsigned per_limb = (unsigned)nb * ((1u << (logN - S1)) / NTT_COL_THREADS);
+                const unsigned per_limb = (unsigned)nb * ((1u << (logN - Kc)) / NTT_COL_THREADS);
                 const ClassLists cl = class_lists(in, dp, per_limb * (unsigned)in.n);
                 const unsigned blocks = (unsigned)cl.in_blocks + per_limb * (unsigned)dp.n;
-                switch (S1) {
+                switch (Kc) {
                     case 1: launch_cols_ws_k<1>(blocks, st, base, (i64 *)ws, wflags, g, cl, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
                     case 2: launch_cols_ws_k<2>(blocks, st, base, (i64 *)ws, wflags, g, cl, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
                     case 3: launch_cols_ws_k<3>(blocks, st, base, (i64 *)ws, wflags, g, cl, psi_br, psi_dp, rs, ql, qh, kl, kh); break;
@@ -326,7 +333,7 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
                 }
             } else {
                 launch_pass16_ws(nb, st, (const i64 *)ws, wflags, base, g, in, dp, (const i64 *)psi_br, psi_dp, (const i64 *)ql,
-                                 (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+                                 (const i64 *)qh, (const i64 *)kl, (const i64 *)kh, extra);
             }
             continue;
         }

@@ -59,11 +59,13 @@ struct Tw16Last {
     __device__ __forceinline__ void load(const Ctx &c, int i) { A::tw_group(c, i << 3, 8, w8); }
 };
 
-template <class A>
+// U0 = 1: the step's first stage (the one pairing word e with e + 8) has been taken by the pass in front (a column pass of one
+// stage more, lf_ntt_ws): stages 1 .. 3 only, same table entries
+template <class A, int U0 = 0>
 __device__ __forceinline__ void fwd_regs16(typename A::T (&x)[16], int i0, const Ctx &c, const Tw16Early<A> *early = nullptr,
                                            const Tw16Last<A> *last = nullptr) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = U0; u < 4; ++u) {
         const int du = 1 << (3 - u);
         typename A::W wv[8];
         if (early && u < 3) early->get(1 << u, wv);
@@ -82,10 +84,11 @@ __device__ __forceinline__ void fwd_regs16(typename A::T (&x)[16], int i0, const
 }
 
 // exact fp64 class (ArithDp semantics, bit for bit): products of a stage first, one uniform test, then add / sub
+template <int U0 = 0>
 __device__ __forceinline__ void fwd_regs16_exact(double (&x)[16], int i0, const Ctx &c, const Tw16Early<ArithDp> *early = nullptr,
                                                  const Tw16Last<ArithDp> *last = nullptr) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = U0; u < 4; ++u) {
         const int du = 1 << (3 - u);
         double wv[8];
         if (early && u < 3) early->get(1 << u, wv);
@@ -202,8 +205,10 @@ __device__ __forceinline__ void inv_regs16_exact(double (&x)[16], int il, const 
 
 // ---- odd tiles: the reference's signed arithmetic, stage by stage (rare; any thread count) -------------------------
 // (the tile's words are in LDS at PAD16(L), a barrier behind them — and again on return)
-__device__ __forceinline__ void tile16_slow_compute(i64 *sm, int base, int s0, int logN, bool inverse, const Ctx &c) {
-    for (int j = 0; j < 12; ++j) {
+// (j0 .. j1 - 1 of the tile's 12 stages: a pass in front / behind may have taken the first / will take the last)
+__device__ __forceinline__ void tile16_slow_compute(i64 *sm, int base, int s0, int logN, bool inverse, const Ctx &c, int j0 = 0,
+                                                    int j1 = 12) {
+    for (int j = j0; j < j1; ++j) {
         const int st = s0 + j;
         const int logd = inverse ? j : 11 - j;
         for (int i = threadIdx.x; i < 2048; i += NTT16_THREADS) {
@@ -222,8 +227,9 @@ __device__ __forceinline__ void tile16_slow_compute(i64 *sm, int base, int s0, i
         __syncthreads();
     }
 }
-__device__ __forceinline__ void tile16_slow_lds(i64 *sm, i64 *dst, int base, int s0, int logN, bool inverse, const Ctx &c) {
-    tile16_slow_compute(sm, base, s0, logN, inverse, c);
+__device__ __forceinline__ void tile16_slow_lds(i64 *sm, i64 *dst, int base, int s0, int logN, bool inverse, const Ctx &c, int j0 = 0,
+                                                int j1 = 12) {
+    tile16_slow_compute(sm, base, s0, logN, inverse, c, j0, j1);
     for (int L = threadIdx.x; L < 4096; L += NTT16_THREADS) dst[L] = sm[PAD16(L)];
 }
 __device__ __forceinline__ void tile16_slow(i64 *sm, const i64 *src, i64 *dst, int base, int s0, int logN, bool inverse, const Ctx &c) {
@@ -243,11 +249,11 @@ template <bool RLX> struct DpArith { typedef ArithDp type; };
 template <> struct DpArith<true> { typedef ArithDpR type; };
 
 // one radix-16 step of arithmetic class A in mode RLX (the exact fp64 class has its own stage-wise routine)
-template <class A, bool EXACT_DP>
+template <class A, bool EXACT_DP, int U0 = 0>
 __device__ __forceinline__ void fwd_step16(typename A::T (&x)[16], int i0, const Ctx &c, const Tw16Early<A> *early,
                                            const Tw16Last<A> *last = nullptr) {
-    if constexpr (EXACT_DP) fwd_regs16_exact(x, i0, c, early, last);
-    else fwd_regs16<A>(x, i0, c, early, last);
+    if constexpr (EXACT_DP) fwd_regs16_exact<U0>(x, i0, c, early, last);
+    else fwd_regs16<A, U0>(x, i0, c, early, last);
 }
 template <class A, bool EXACT_DP>
 __device__ __forceinline__ void inv_step16(typename A::T (&x)[16], int il, const Ctx &c, const Tw16Early<A> *early) {
@@ -258,7 +264,7 @@ __device__ __forceinline__ void inv_step16(typename A::T (&x)[16], int il, const
 // ---- forward tile: words w + 256 e in, 16 w + e out ------------------------------------------------------------------
 // A = arithmetic class of the limb; T = its word type in LDS (double / i64).  The twiddles of the next step's first
 // three stages are requested before the barrier that ends the current one.
-template <class A, bool DP, bool RLX>
+template <class A, bool DP, bool RLX, int U0 = 0>
 __device__ __forceinline__ bool fwd_tile16_steps(typename A::T *smt, const i64 *sm, typename A::T (&x)[16], int w, int base,
                                                  int E, int s, const Ctx &c, bool check, const Tw16Last<A> *lastC = nullptr) {
     constexpr bool EX = DP && !RLX;
@@ -267,7 +273,7 @@ __device__ __forceinline__ bool fwd_tile16_steps(typename A::T *smt, const i64 *
     const int iB = (1 << (s + 4)) + ((base + pB) >> (E - s - 4));
     const int iC = (1 << (s + 8)) + ((base + 16 * w) >> (E - s - 8));
     Tw16Early<A> twB, twC;
-    fwd_step16<A, EX>(x, iA, c, nullptr);
+    fwd_step16<A, EX, U0>(x, iA, c, nullptr);
     {
         typename A::T *sp = smt + PAD16(w);                      // PAD16(w + 256 e) = PAD16(w) + 272 e
 #pragma unroll
@@ -426,12 +432,14 @@ __device__ __forceinline__ void fwd_tile16(i64 *sm, i64 *__restrict__ row, int t
 // unflagged column wave are lazy words by construction.  Integer-class rows are raw words in the workspace, flagged alike.
 // returns whether one of the column waves behind this wave's words raised its flag (wave-uniform): only then can a word lie
 // outside [0, 2q)
-template <bool DP>
+// SKIP0: the column pass took one stage more (columns are 2048 wide: word e and word e + 8 of a thread come from the same
+// column wave, flag index e & 7)
+template <bool DP, bool SKIP0>
 __device__ __forceinline__ bool ws_load_tile(const i64 *__restrict__ srow, const unsigned char *__restrict__ wf, int base, int E,
                                              int w, i64 (&raw)[16]) {
     const int wave = __builtin_amdgcn_readfirstlane(w >> 6);
     const u64 *fp = reinterpret_cast<const u64 *>(wf + (wave << 4));
-    const u64 fl = fp[0], fh = fp[1];
+    const u64 fl = fp[0], fh = SKIP0 ? fp[0] : fp[1];
     if constexpr (DP) {
         const unsigned *lo = reinterpret_cast<const unsigned *>(srow) + base;
         const unsigned short *mid = reinterpret_cast<const unsigned short *>(srow + ((i64)1 << (E - 1))) + base;
@@ -454,14 +462,14 @@ __device__ __forceinline__ bool ws_load_tile(const i64 *__restrict__ srow, const
     return (fl | fh) != 0;
 }
 
-template <bool DP>
+template <bool DP, bool SKIP0>
 __device__ __forceinline__ void fwd_tile16_ws(i64 *sm, const i64 *__restrict__ srow, const unsigned char *__restrict__ wf,
                                               i64 *__restrict__ row, int tile, const PassGeom &g, const Ctx &c,
                                               const Tw16Last<typename FwdArith<DP, false>::type> *lastC = nullptr) {
     const int w = lf_tid();
     const int base = tile << 12, E = g.logN, s = g.s0;
     i64 raw[16];
-    const bool flagged = ws_load_tile<DP>(srow, wf, base, E, w, raw);
+    const bool flagged = ws_load_tile<DP, SKIP0>(srow, wf, base, E, w, raw);
     {
         int odd = 0;
         if (flagged) {   // (words of unflagged column waves are lazy words by construction: no test)
@@ -476,21 +484,21 @@ __device__ __forceinline__ void fwd_tile16_ws(i64 *sm, const i64 *__restrict__ s
         double x[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) x[e] = dp_from_word(raw[e]);
-        ok = fwd_tile16_steps<ArithDp, true, false>(reinterpret_cast<double *>(sm), sm, x, w, base, E, s, c, true, lastC);
+        ok = fwd_tile16_steps<ArithDp, true, false, SKIP0 ? 1 : 0>(reinterpret_cast<double *>(sm), sm, x, w, base, E, s, c, true, lastC);
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[e] = dp_to_word(dp_reduce(x[e], c.d.q2, c.d.q2inv));
     } else {
-        ok = fwd_tile16_steps<ArithInt<false>, false, false>(sm, sm, raw, w, base, E, s, c, true, lastC);
+        ok = fwd_tile16_steps<ArithInt<false>, false, false, SKIP0 ? 1 : 0>(sm, sm, raw, w, base, E, s, c, true, lastC);
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[e] = raw[e];
     }
     if (!ok) {   // a word outside [0, 2q): nothing has been stored yet; the raw words once more, into LDS, then the generic tile
         __syncthreads();
-        ws_load_tile<DP>(srow, wf, base, E, w, raw);
+        ws_load_tile<DP, SKIP0>(srow, wf, base, E, w, raw);
 #pragma unroll
         for (int e = 0; e < 16; ++e) sm[PAD16(w + (e << 8))] = raw[e];
         __syncthreads();
-        tile16_slow_lds(sm, row + base, base, s, E, false, c);
+        tile16_slow_lds(sm, row + base, base, s, E, false, c, SKIP0 ? 1 : 0);
         return;
     }
     {
@@ -898,7 +906,7 @@ __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_fwd_seq(i64 *dst,
 }
 
 // the same two kernels for a transform through a workspace (fwd_tile16_ws): ws -> dst, wflags = 64 flag bytes per (poly, limb)
-template <bool DP>
+template <bool DP, bool SKIP0>
 __device__ __forceinline__ void seq16_loop_ws(i64 *sm, const i64 *ws, const unsigned char *wflags, i64 *dst, const PassGeom &g,
                                               const RowList &rl, int b0, int bend, int tpb, const i64 *__restrict__ tw_br,
                                               const double *__restrict__ tw_dp, const i64 *__restrict__ ql,
@@ -924,10 +932,11 @@ __device__ __forceinline__ void seq16_loop_ws(i64 *sm, const i64 *ws, const unsi
         }
         if (i) lds_barrier();
         const i64 ri = (i64)(t.poly * g.rows + t.crow);
-        fwd_tile16_ws<DP>(sm, ws + (ri << g.logN), wflags + (ri << 6), dst + (ri << g.logN), t.tile, g, c, &last);
+        fwd_tile16_ws<DP, SKIP0>(sm, ws + (ri << g.logN), wflags + (ri << 6), dst + (ri << g.logN), t.tile, g, c, &last);
     }
 }
 
+template <bool SKIP0>
 __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_fwd_seq_ws(const i64 *ws, const unsigned char *wflags, i64 *dst,
                                                                             PassGeom g, ClassLists cl, int total, int tpb,
                                                                             const i64 *__restrict__ tw_br,
@@ -936,11 +945,11 @@ __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_fwd_seq_ws(const 
                                                                             const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
     __shared__ i64 sm[NTT16_LDS_WORDS + 1];
     const int vb0 = (int)(blockIdx.x & 7) + 8 * (int)(blockIdx.x >> 3) * tpb;
-    if (vb0 < cl.in_blocks) seq16_loop_ws<false>(sm, ws, wflags, dst, g, cl.in, vb0, cl.in_real, tpb, tw_br, tw_dp, ql, qh, kl, kh);
-    else seq16_loop_ws<true>(sm, ws, wflags, dst, g, cl.dp, vb0 - cl.in_blocks, total - cl.in_blocks, tpb, tw_br, tw_dp, ql, qh, kl, kh);
+    if (vb0 < cl.in_blocks) seq16_loop_ws<false, SKIP0>(sm, ws, wflags, dst, g, cl.in, vb0, cl.in_real, tpb, tw_br, tw_dp, ql, qh, kl, kh);
+    else seq16_loop_ws<true, SKIP0>(sm, ws, wflags, dst, g, cl.dp, vb0 - cl.in_blocks, total - cl.in_blocks, tpb, tw_br, tw_dp, ql, qh, kl, kh);
 }
 
-template <bool DP>
+template <bool DP, bool SKIP0>
 __device__ __forceinline__ void pass16_ws_body(i64 *sm, int b, const i64 *ws, const unsigned char *wflags, i64 *dst,
                                                const PassGeom &g, const RowList &rl, const i64 *__restrict__ tw_br,
                                                const double *__restrict__ tw_dp, const i64 *__restrict__ ql,
@@ -957,9 +966,10 @@ __device__ __forceinline__ void pass16_ws_body(i64 *sm, int b, const i64 *ws, co
     c.relaxed = 0;
     c.inv_reduce = 0;
     const i64 ri = (i64)(poly * g.rows + crow);
-    fwd_tile16_ws<DP>(sm, ws + (ri << g.logN), wflags + (ri << 6), dst + (ri << g.logN), tile, g, c);
+    fwd_tile16_ws<DP, SKIP0>(sm, ws + (ri << g.logN), wflags + (ri << 6), dst + (ri << g.logN), tile, g, c);
 }
 
+template <bool SKIP0>
 __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_fwd_ws(const i64 *ws, const unsigned char *wflags, i64 *dst,
                                                                         PassGeom g, ClassLists cl, const i64 *__restrict__ tw_br,
                                                                         const double *__restrict__ tw_dp,
@@ -968,9 +978,9 @@ __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_fwd_ws(const i64 
     __shared__ i64 sm[NTT16_LDS_WORDS + 1];
     const int b = blockIdx.x;
     if (b < cl.in_blocks) {
-        if (b < cl.in_real) pass16_ws_body<false>(sm, b, ws, wflags, dst, g, cl.in, tw_br, tw_dp, ql, qh, kl, kh);
+        if (b < cl.in_real) pass16_ws_body<false, SKIP0>(sm, b, ws, wflags, dst, g, cl.in, tw_br, tw_dp, ql, qh, kl, kh);
     } else {
-        pass16_ws_body<true>(sm, b - cl.in_blocks, ws, wflags, dst, g, cl.dp, tw_br, tw_dp, ql, qh, kl, kh);
+        pass16_ws_body<true, SKIP0>(sm, b - cl.in_blocks, ws, wflags, dst, g, cl.dp, tw_br, tw_dp, ql, qh, kl, kh);
     }
 }
 
@@ -1060,9 +1070,10 @@ inline void launch_pass16(bool inverse, int relaxed, int polys, hipStream_t st, 
 }
 
 // host: the contiguous exact forward pass of a transform through a workspace (either class list may be empty)
+// skip0: the column pass in front took the tile's first stage too
 inline void launch_pass16_ws(int polys, hipStream_t st, const i64 *ws, const unsigned char *wflags, i64 *dst, const PassGeom &g,
                              const RowList &in, const RowList &dp, const i64 *tw_br, const double *tw_dp, const i64 *ql,
-                             const i64 *qh, const i64 *kl, const i64 *kh) {
+                             const i64 *qh, const i64 *kl, const i64 *kh, bool skip0) {
     const unsigned per_row = (unsigned)polys << (g.logN - 12);
     const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
     const dim3 grid((unsigned)cl.in_blocks + per_row * (unsigned)dp.n), block(NTT16_THREADS);
@@ -1073,10 +1084,12 @@ inline void launch_pass16_ws(int polys, hipStream_t st, const i64 *ws, const uns
         cm.in_blocks = (int)(((unsigned)cl.in_real + unit - 1u) / unit * unit);
         const int total = cm.in_blocks + (int)dpb;
         const dim3 mg((unsigned)cm.in_blocks / (unsigned)tpb + 8u * ((dpb + unit - 1u) / unit));
-        hipLaunchKernelGGL(ntt_pass16_fwd_seq_ws, mg, block, 0, st, ws, wflags, dst, g, cm, total, tpb, tw_br, tw_dp, ql, qh, kl, kh);
+        if (skip0) hipLaunchKernelGGL(ntt_pass16_fwd_seq_ws<true>, mg, block, 0, st, ws, wflags, dst, g, cm, total, tpb, tw_br, tw_dp, ql, qh, kl, kh);
+        else hipLaunchKernelGGL(ntt_pass16_fwd_seq_ws<false>, mg, block, 0, st, ws, wflags, dst, g, cm, total, tpb, tw_br, tw_dp, ql, qh, kl, kh);
         return;
     }
-    hipLaunchKernelGGL(ntt_pass16_fwd_ws, grid, block, 0, st, ws, wflags, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
+    if (skip0) hipLaunchKernelGGL(ntt_pass16_fwd_ws<true>, grid, block, 0, st, ws, wflags, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
+    else hipLaunchKernelGGL(ntt_pass16_fwd_ws<false>, grid, block, 0, st, ws, wflags, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
 }
 
 }  // namespace

@@ -176,6 +176,7 @@ def test_lf_tune_is_a_pure_host_call():
     assert 0 <= cols <= 5
     assert lib.lf_tune(1, 9) == cols and lib.lf_tune(1, -1) == cols      # out of range: ignored
     assert lib.lf_tune(3, -1) == 1 and lib.lf_tune(3, 5) == 1     # digit planes: on by default; out of range: ignored
+    assert lib.lf_tune(4, -1) == 1 and lib.lf_tune(4, 7) == 1     # extra column stage of lf_ntt_ws: on; out of range: ignored
     assert lib.lf_tune(77, 1) == -1
 
 

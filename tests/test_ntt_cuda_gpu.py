@@ -270,6 +270,39 @@ def test_transforms_through_a_workspace_equal_in_place_and_oracle(mods, logN):
     assert any(ws.numel() >= C * lim.N for ws in nc._WS.values())
 
 
+@pytest.mark.parametrize("logN", [13, 14, 15, 16])
+def test_workspace_split_with_and_without_the_extra_column_stage(mods, logN):
+    """lf_ntt_ws splits a transform as (logN - 12 + 1) column stages + 11 tile stages (LF_TUNE_WS_EXTRA_STAGE = 1, the default: the
+    tiles skip their first stage, flags are indexed by 2048-wide columns) or as lf_ntt does (0): the oracle's words either way,
+    with out-of-range words in both halves of a tile."""
+    from liberate_fhe_amd._native import lib
+    nc, orc = mods
+    lim = Limbs(logN, pick_primes(logN, 2, 1))
+    C = lim.rows
+    psi, _ = lim.mont_tables()
+    d = lambda v: [dev(v)]
+    consts = [d(lim._2q), d(lim.ql), d(lim.qh), d(lim.kl), d(lim.kh)]
+    x = lim.uniform(61 + logN, lazy=True)
+    for r, q in enumerate(lim.q):
+        x[r, 100 + r] = 2 * q + 1                    # first half of tile 0
+        x[r, 2048 + 300 + r] = -5                    # second half of tile 0: the same column wave's partner word
+        x[r, lim.N - 1] = 3 * q
+    want = x.copy()
+    orc.mont_enter(want, lim.Rs, C, *lim.mont_args())
+    orc.ntt(want, psi, C, logN, lim._2q, *lim.mont_args())
+    assert lib.lf_tune(4, -1) == 1
+    try:
+        for extra in (1, 0, 1):
+            assert lib.lf_tune(4, extra) in (0, 1)
+            for ws in nc._WS.values():
+                ws.fill_(-1)
+            t = d(x)
+            nc.enter_ntt(t, d(lim.Rs), [None], [None], d(psi), *consts)
+            assert (t[0].cpu().numpy() == want).all(), f"extra column stage {extra}"
+    finally:
+        lib.lf_tune(4, 1)
+
+
 @pytest.mark.parametrize("small,large", [(3, 0), (0, 2), (1, 0)])
 def test_workspace_transforms_with_one_arithmetic_class_only(mods, small, large):
     """The workspace kernels take both class lists in one launch; either may be empty (only 40-bit primes / only 60-bit primes)."""
