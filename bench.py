@@ -15,7 +15,7 @@ Polynomials are independent, so ranks shard them with no data-path collective: w
 
 The JSON line also carries
   roofline     : the dominant kernel (ntt_pass16_fwd_seq_ws: the tiled pass of all 30 limbs, the second of the two
-                 launches of a transform, 12 of its 16 stages) against the 8 TB/s HBM peak; algorithmic bytes
+                 launches of a transform, 11 of its 16 stages) against the 8 TB/s HBM peak; algorithmic bytes
                  per launch = 8*N*limbs (a transform is 16*N bytes per limb, SURVEY.md §8d, spread over its two
                  launches); its launch duration is measured live with HIP events on the launch stream, the
                  kernel launched alone (lf_ntt_pass_ws, the measurement entry) with the grid it has inside the full step;
@@ -1120,7 +1120,9 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "issue_frac": valu_busy, "traffic": traffic,
                      "issue_ceiling_frac": None if issue_ceiling is None else issue_ceiling["kernel_frac"],
                      "issue_ceiling": issue_ceiling,
-                     "kernel": ("ntt_pass16_fwd_seq<false>" if in_place else "ntt_pass16_fwd_seq_ws") + " (tiled pass = 12 of 16 stages, 16 words per thread, 8 tiles per block, all 30 limbs: 5 integer-class + 25 fp64-class)",
+                     "kernel": ("ntt_pass16_fwd_seq<false> (tiled pass = 12 of 16 stages" if in_place or lib.lf_tune(4, -1) != 1 else
+                                "ntt_pass16_fwd_seq_ws<true> (tiled pass = 11 of 16 stages behind a 5-stage column pass")
+                               + ", 16 words per thread, 8 tiles per block, all 30 limbs: 5 integer-class + 25 fp64-class)",
                      "launches_per_transform": 2, "avg_launch_ms": k_ms, "launches_timed": n_roof,
                      "column_pass_launch_ms": cols_ms,
                      "column_pass_algorithmic_GBps": alg_bytes_per_launch / (cols_ms * 1e-3) / 1e9,
