@@ -329,6 +329,42 @@ def test_workspace_transforms_with_one_arithmetic_class_only(mods, small, large)
         assert (t[0].cpu().numpy() == back).all(), (logN, "intt_exit_reduce")
 
 
+def test_workspace_is_per_stream(mods):
+    """ntt_cuda keeps one workspace per (device, stream): transforms enqueued on two streams at once use two buffers and both
+    equal the oracle (one shared buffer would be written by both column passes before either tiled pass read it)."""
+    nc, orc = mods
+    logN = 14
+    lim = Limbs(logN, pick_primes(logN, 3, 1))
+    psi, _ = lim.mont_tables()
+    d = lambda v: [dev(v)]
+    consts = [d(lim._2q), d(lim.ql), d(lim.qh), d(lim.kl), d(lim.kh)]
+    xs = [lim.uniform(70 + i, lazy=True) for i in range(2)]
+    wants = []
+    for x in xs:
+        w = x.copy()
+        orc.ntt(w, psi, lim.rows, logN, lim._2q, *lim.mont_args())
+        wants.append(w)
+    table = d(psi)
+    nc.ntt(d(xs[0]), [None], [None], table, *consts)     # builds the table's auxiliary twin once, on the default stream
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for _ in range(8):                                   # several rounds of two transforms in flight
+        ts = [d(x) for x in xs]
+        torch.cuda.synchronize()
+        for st, t in zip(streams, ts):
+            with torch.cuda.stream(st):
+                nc.ntt(t, [None], [None], table, *consts)
+        torch.cuda.synchronize()
+        outs.append(ts)
+    for ts in outs:
+        for t, w in zip(ts, wants):
+            assert (t[0].cpu().numpy() == w).all()
+    keys = {(0, st.cuda_stream) for st in streams}
+    assert keys <= set(nc._WS), "one workspace per stream"
+    assert nc._WS[(0, streams[0].cuda_stream)].data_ptr() != nc._WS[(0, streams[1].cuda_stream)].data_ptr()
+
+
 def test_workspace_entry_argument_checks(mods):
     """lf_ntt_ws: relaxed transforms are refused before anything is launched; without a workspace, and at sizes with one
     launch (logN <= 12), it IS lf_ntt."""
