@@ -848,7 +848,7 @@ def main():
             gloo_device_p2p.install()
         else:
             try:
-                rccl = dist.new_group(ranks=list(range(world)), backend="nccl", timeout=datetime.timedelta(seconds=180))
+                rccl = dist.new_group(ranks=list(range(world)), backend="nccl", timeout=datetime.timedelta(seconds=900))
                 probe = torch.ones(1, dtype=torch.int64, device=dev)
                 dist.all_reduce(probe, group=rccl)             # first RCCL collective of the process: communicator set-up
                 torch.cuda.synchronize()
@@ -941,12 +941,26 @@ def main():
     # Parity spot check of what the timed kernel computes, on THIS box, outside the timed region: polynomial 0 is reloaded
     # from its seed, the whole batch goes through one more step, and two of its limbs — the first integer-class one (a
     # 60-bit prime, REDC62 path) and the first fp64-class one (a 40-bit prime) — are compared word for word with the C oracle.
+    # The WHOLE batch of that step is also compared, on the device, with the strictly in-place lf_ntt of the same input
+    # (tests/test_fullsize_gpu.py holds both forms to the oracle at this shape, all 30 limbs, out-of-range words included).
+    # The WHOLE batch of that step is also compared, on the device, with the strictly in-place lf_ntt of the same input
+    # (tests/test_fullsize_gpu.py holds both forms to the oracle at this shape, all 30 limbs, out-of-range words included).
     def parity_spot_check():
         from oracle import oracle as orc      # the checker, never the thing measured
         src = synth.uniform_rows(1000 * rank, rows_idx, ctx.q, N, lazy=True)
         x[0] = torch.from_numpy(src).to(dev)
+        before = None if in_place else x.clone()     # the whole batch again through the strictly in-place lf_ntt, on the device
         step()
         torch.cuda.synchronize()
+        if before is not None:
+            check(lib.lf_ntt(before.data_ptr(), B, L_LIMBS, LOGN, psi.data_ptr(), psi_dp, q_host.ctypes.data, 0, 0, q2.data_ptr(), ql.data_ptr(),
+                             qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), local_rank, stream), "lf_ntt")
+            torch.cuda.synchronize()
+            same = torch.equal(before, x)
+            n_diff = 0 if same else int((before != x).sum().item())
+            del before
+            if not same:
+                return f"MISMATCH: {n_diff} words of the whole batch differ between lf_ntt_ws and lf_ntt"
         got = x[0].cpu().numpy()
         h = lambda v, i: np.asarray([v[i]], dtype=np.int64)
         picks = [next(r for r, i in enumerate(rows_idx) if ctx.q[i] >= (1 << 41)), next(r for r, i in enumerate(rows_idx) if ctx.q[i] < (1 << 41))]

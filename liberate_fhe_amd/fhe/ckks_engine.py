@@ -61,7 +61,11 @@ class ckks_engine(EvaluatorOps):
             raise ValueError("ckks_engine: the engine's ops exist for buffer_bit_length = 62; the 30-bit word mode is served by "
                              "ckks_context / ntt_context / ntt_cuda only (as far as the reference itself works in it)")
 
-        if comm is not None and comm.world_size > 1:
+        # one process per GPU: the limb-sharded code path.  A communicator of ONE rank takes the ordinary single-device path unless
+        # it says `solo_sharded` (comm.py): then the rank runs the sharded halves and issues both exchange steps to the
+        # communicator — the form a one-GPU lease can execute against a real RCCL communicator
+        self._multi = comm is not None and (comm.world_size > 1 or bool(getattr(comm, "solo_sharded", False)))
+        if self._multi:
             local = devices[0] if devices else comm.local_device
             logical, local_ids = [local] * comm.world_size, [comm.rank]
         else:
@@ -73,7 +77,7 @@ class ckks_engine(EvaluatorOps):
 
         # Every rank runs the same ChaCha20 key / nonce; the counters make the streams distinct (csprng.py:216-223).
         seed_words = None
-        if comm is not None and comm.world_size > 1:
+        if self._multi:
             fresh = torch.tensor([int.from_bytes(os.urandom(4), "big") for _ in range(10)], dtype=torch.int64)
             seed_words = comm.broadcast(fresh.to(comm.local_device), src=0, shape=(10,), device=comm.local_device).tolist()
         self.rng = getattr(backend, "csprng_class", Csprng)(self.ctx.N, [len(di) for di in self.ntt.p.d], max(self.ntt.num_special_primes, 2),
@@ -457,8 +461,23 @@ class ckks_engine(EvaluatorOps):
         # rebuilt when any of its tensors has been modified in place since (torch's version counters)
         self._key_packs[key] = {"ref": weakref.ref(anchor), "packs": packs, "own": own,
                                 "versions": None if own else self._key_versions(ksk)}
-        weakref.finalize(anchor, self._key_packs.pop, key, None)
+        weakref.finalize(anchor, self._forget_key, self._key_packs, self._tables, key)
         return packs
+
+    @staticmethod
+    def _purge_graphs(tables, tensors):
+        """Captured segments of a sharded rank hold the pack they were captured on (its address is baked into the graphs, the
+        entry keeps the tensor alive): drop those of `tensors`."""
+        ptrs = {t.data_ptr() for t in tensors}
+        for k in [k for k in tables if isinstance(k, tuple) and k and k[0] == "sgraph" and k[5] in ptrs]:
+            del tables[k]
+
+    @staticmethod
+    def _forget_key(key_packs, tables, key):
+        """A key's anchor tensor died: its pack, its planes copy and the graphs captured on either go with it."""
+        gone = key_packs.pop(key, None)
+        if gone:
+            ckks_engine._purge_graphs(tables, list(gone.get("packs") or []) + list(gone.get("planes") or []))
 
     def _planes_wanted(self):
         """Fused key switches (two-pass ring degrees) read the key in the planes format (include/ckks_hip.h LF_KEY_PLANES:
@@ -491,6 +510,7 @@ class ckks_engine(EvaluatorOps):
                     return hit["packs"]
                 ver = tuple(p._version for p in hit["packs"])
                 if hit.get("planes_ver") != ver:
+                    self._purge_graphs(self._tables, hit.get("planes") or [])     # graphs captured on the copy being replaced
                     hit["planes"] = [self._planes_of([(pk[q_, 0], pk[q_, 1]) for q_ in range(pk.size(0))], i, d)
                                      for i, (d, pk) in enumerate(zip(loc, hit["packs"]))]
                     hit["planes_ver"] = ver
@@ -519,10 +539,7 @@ class ckks_engine(EvaluatorOps):
         else:
             gone = self._key_packs.pop(id(self._key_anchor(ksk)), None)
             dropped = (gone or {}).get("packs", [])
-        # captured segments of a sharded rank hold the pack they were captured on (its address is baked into the graphs)
-        ptrs = {t.data_ptr() for t in dropped}
-        for k in [k for k in self._tables if isinstance(k, tuple) and k and k[0] == "sgraph" and k[5] in ptrs]:
-            del self._tables[k]
+        self._purge_graphs(self._tables, dropped)
 
     def invalidate_key(self, ksk):
         """Tell the engine that a key's words were changed behind torch's back (a write through a raw pointer does not move
@@ -736,7 +753,7 @@ class ckks_engine(EvaluatorOps):
         round_at = self.ctx.q[self.ntt.p.destination_arrays[level][owner][0]] // 2 if exact_rounding else (1 << 62)
         # the dropped limb's row of every polynomial, on every local target device
         rows0 = []                                   # rows0[k][comp] = {device: [N] tensor}
-        multi = self.comm is not None and self.comm.world_size > 1
+        multi = self._multi
         if multi:
             # the dropped limb's rows of ALL operands (cc_mult: both ciphertexts, both components) in ONE message, in
             # place on a buffer kept per operand count
@@ -800,7 +817,7 @@ class ckks_engine(EvaluatorOps):
         entries; None otherwise (several devices / ranks: the exchange steps sit between the launches)."""
         if not getattr(self.backend, "native_ops", False) or self.ctx.logN < self.backend.fused_ks_min_logN:
             return None
-        if self.len_devices[level] != 1:
+        if self.len_devices[level] != 1 or (self._multi and self.comm.world_size == 1):   # (solo_sharded: the halves, not the one call)
             return None
         loc = self._loc(level)
         return loc[0] if len(loc) == 1 else None
@@ -865,12 +882,12 @@ class ckks_engine(EvaluatorOps):
     def _sharded_native(self, level):
         """This rank's device if the level is limb-sharded over ranks (one process per GPU), this rank holds rows of it and
         the backend has the native halves of an op (lf_*_pre / lf_ks_plan_fwd / lf_*_post); None otherwise."""
-        if self.comm is None or self.comm.world_size <= 1 or not getattr(self.backend, "native_ops", False):
+        if not self._multi or not getattr(self.backend, "native_ops", False):
             return None
         if self.ctx.logN < self.backend.fused_ks_min_logN or not hasattr(self.backend, "cc_mult_pre"):
             return None
         loc = self._loc(level)
-        return loc[0] if len(loc) == 1 and self.len_devices[level] > 1 else None
+        return loc[0] if len(loc) == 1 and (self.len_devices[level] > 1 or self.comm.world_size == 1) else None
 
     def _sharded_schedule(self, level, d):
         """The digit exchange of this rank at `level` as plain data: (digit buffer in storage order, pieces and peers of
@@ -922,7 +939,7 @@ class ckks_engine(EvaluatorOps):
             fn()
         return g
 
-    def _sharded_segments(self, kind, level, d, plan, kpack, first_part, row_off):
+    def _sharded_segments(self, kind, level, d, plan, kpack, first_part, row_off, capture=False):
         """The launches of a rank's half-ops that only touch the plan's scratch, the tables and the key, captured ONCE per
         (op kind, level, lane, key pack) into three HIP graphs around the digit exchange:
             a1  cc_mult: the rest of `pre` (tiled pass of the operands, x1 * y1, inverse NTT, digits); both kinds: this rank's
@@ -932,14 +949,17 @@ class ckks_engine(EvaluatorOps):
         What stays eager is what reads or writes caller tensors: the first launch (operands) and the mod-down (result), and
         the exchange itself.  A replay costs 6-8 us of host time whatever it holds (tools/graph_host_cost.py) against 4.4 us per
         launch: a rank of a gold cc_mult over 8 GPUs enqueues in ~55 us instead of 140 (profiles/r05_host_overhead.txt).
-        None when the device is not a HIP device (the CPU checker backend)."""
+        None when the device is not a HIP device (the CPU checker backend), and — unless `capture` — when the segments of this
+        (kind, level, lane, key) have not been captured yet: the FIRST op of each runs eagerly and captures when it is
+        complete (capture=True, after its mod-down) — the warm-up run then works on the valid scratch that op left, and the
+        device-wide synchronisation of a capture never falls between the two exchanges of an op its peers are inside."""
         dev = self.ntt.devices[d]
         if not self.graph_sharded or not str(dev).startswith("cuda") or not hasattr(torch.cuda, "CUDAGraph"):
             return None
         fmt = getattr(kpack, "lf_key_format", 0)
         key = ("sgraph", kind, level, d, self._lane, kpack.data_ptr(), tuple(kpack.stride()), fmt, first_part, row_off)
         hit = self._tables.get(key)
-        if hit is not None:
+        if hit is not None or not capture:
             return hit
         relin = kind == "mult"
         pieces, peers, own_rows, own_runs, foreign, total_rows = self._sharded_schedule(level, d)
@@ -1035,6 +1055,7 @@ class ckks_engine(EvaluatorOps):
         self.backend.cc_mult_pre(plan, ins, row0s, _ds(srcs[0])[1])
         self._sharded_forward(plan, d, level, True)                      # exchange 2: the digits
         self.backend.cc_mult_post(plan, kpack, first_part, row_off, out)
+        self._sharded_segments("mult", level, d, plan, kpack, first_part, row_off, capture=True)   # the next op replays
         return self._new(([out[0]], [out[1]]), types.origins["ct"], level=level)
 
     # =============================================================================================
@@ -1244,11 +1265,11 @@ class ckks_engine(EvaluatorOps):
         n_alive = self.len_devices[level]
         loc = self._loc(level)
         nparts = len(tabs["order"])
-        if n_alive == 1:
+        if n_alive == 1 and not (self._multi and self.comm.world_size == 1):
             return {loc[0]: (states[loc[0]], [(None, 0, nparts)])} if loc else {}
         N = self.ctx.N
         groups = tabs["groups"]
-        if self.comm is not None and self.comm.world_size > 1:
+        if self._multi:
             me = self.local_ids[0]
             if not loc:   # no rows at this level: nothing to switch, nothing to send, nothing to receive ..
                 if getattr(self.comm, "whole_group_exchange", False):   # .. unless the exchange is a whole-group collective
@@ -1473,6 +1494,7 @@ class ckks_engine(EvaluatorOps):
                 else:
                     self._sharded_forward(plan, d, level, False)
                     self.backend.switch_key_post(plan, ct.data[0][0], pinv, canonical, kpack, first_part, row_off, out)
+                    self._sharded_segments("switch", level, d, plan, kpack, first_part, row_off, capture=True)   # the next op replays
                 return data_struct(data=([out[0]], [out[1]]), include_special=False, ntt_state=False,
                                    montgomery_state=ct.montgomery_state, origin=types.origins["ct"], level=level, hash=self.hash)
             c0, c1 = self.create_switcher(ct.data[1], key, level, addends=(ct.data[0], None), galois=(pinv, canonical))

@@ -58,16 +58,23 @@ class DistComm:
     §8(e) and BASELINE's north star name.  Same words land in the same rows either way (tests/test_distributed_cpu.py);
     which one is faster on xGMI is a measurement (`bench.py --gpus N` times both)."""
 
-    def __init__(self, group=None, local_device=None, exchange="p2p"):
+    def __init__(self, group=None, local_device=None, exchange="p2p", solo_sharded=False):
         if not dist.is_initialized():
             raise RuntimeError("DistComm needs an initialised torch.distributed process group")
         if exchange not in ("p2p", "allgather"):
             raise ValueError("DistComm: exchange must be 'p2p' or 'allgather'")
         self.exchange = exchange
+        # A group of ONE rank: the engine normally takes its single-device path and never calls the communicator.  solo_sharded
+        # = True keeps the limb-sharded code path — the native halves around the two exchange steps, HIP-graph replay, and
+        # every exchange issued to the backend (the all-gather form is a real collective of one rank; the point-to-point
+        # batches are empty) — which is how a one-GPU lease exercises a real RCCL communicator underneath the engine.
+        self.solo_sharded = bool(solo_sharded)
         self._slabs = {}
         self.group = group
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
+        if self.solo_sharded and self.world_size != 1:
+            raise ValueError("DistComm: solo_sharded is for a group of one rank")
         self._ops = {}
         self.local_device = local_device if local_device is not None else (
             f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cpu")

@@ -154,7 +154,7 @@ class EvaluatorOps:
         # per GPU: with several GPUs the host tensor carries that many unused trailing rows (zeros here,
         # uninitialised memory in the reference); upload_to_gpu never reads them.
         out = torch.zeros((sum(len(d) for d in dest), self.ctx.N), dtype=torch.int64, device="cpu")
-        if self.comm is not None and self.comm.world_size > 1:
+        if getattr(self, "_multi", False):
             max_rows = max(len(dest[d]) for d in alive)
             mine = torch.zeros((max_rows, self.ctx.N), dtype=torch.int64, device=self.ntt.devices[self.local_ids[0]])
             if loc:

@@ -138,3 +138,123 @@ def test_gold_cc_mult_batch_of_8_equals_loop():
         for comp in range(2):
             assert torch.equal(one.data[comp][0], batch[i].data[comp][0]), (i, comp)
         del one
+
+
+def _chain_tables(ctx, ntt, total, L):
+    """Device tables of the last L limbs of the chain + the host constants the oracle takes for the same limbs."""
+    from liberate_fhe_amd.ntt import twiddles
+    sl = lambda t: t[0][total - L:]
+    psi, q2, ql, qh, kl, kh = (sl(t) for t in (ntt.psi, ntt._2q, ntt.ql, ntt.qh, ntt.kl, ntt.kh))
+    st = torch.cuda.current_stream().cuda_stream
+    psi_dp = twiddles.dp_pointer(psi, ql, qh, kl, kh, 0, st)
+    h = lambda v: np.asarray(v, dtype=np.int64)[total - L:]
+    cs = (h(ctx.q_lower_bits), h(ctx.q_higher_bits), h(ctx.k_lower_bits), h(ctx.k_higher_bits))
+    return dict(psi=psi, q2=q2, ql=ql, qh=qh, kl=kl, kh=kh, psi_dp=psi_dp, st=st, cs=cs, q2_h=h(ctx.q_double), Rs_h=h(ctx.R_square))
+
+
+@pytest.mark.parametrize("LOGN,L,B,ctx_kw", [(16, 30, 70, dict(num_special_primes=4)),
+                                              (13, 28, 600, dict(num_scales=23, num_special_primes=4, is_secured=False))])
+def test_line_of_record_kernel_through_the_workspace_vs_oracle_and_in_place(LOGN, L, B, ctx_kw):
+    """The kernel bench.py times — ntt_pass16_fwd_seq_ws<SKIP0>, reached by lf_ntt_ws from 8 x 4096 tiles on (K.cu:236-323) —
+    at the bench shape (logN 16, 30 limbs, B = 70: 33 600 tiles, tile pairs per class multiples of 8 -> XCD-aware block order, a
+    block's 8 tiles are 8 consecutive polynomials of one (limb, tile) pair, B % 8 != 0 so blocks straddle pairs and reload
+    their last-stage twiddles mid-loop) and at logN 13 with 23 + 5 limbs (pairs not multiples of 8: plain order, a block's
+    tiles are polynomials 8 apart; class padding leaves dead tiles).  Words outside [0, 2q) — signed-lazy, exactly 2q,
+    arbitrary below 2^61, and any int64 at all — sit in polynomials that are the FIRST, a MIDDLE and the LAST tile of a
+    block's loop and on both sides of the integer / fp64 class boundary, so flagged column waves (third plane) are met inside
+    the loop beside unflagged neighbours.  Checked: every limb of 8 polynomials word for word against the C oracle; the whole
+    batch against the strictly in-place lf_ntt; lf_ntt_pass_ws(1) + (2) against lf_ntt_ws; all of it with the column pass
+    taking the tiles' first stage (LF_TUNE_WS_EXTRA_STAGE = 1: seq_ws<true>) and not (0: seq_ws<false>)."""
+    from liberate_fhe_amd._native import lib, check
+    from liberate_fhe_amd.fhe.context.ckks_context import ckks_context
+    from liberate_fhe_amd.ntt import ntt_context
+    from oracle import oracle as orc
+    ctx = ckks_context(logN=LOGN, **ctx_kw)
+    ntt = ntt_context(ctx, devices=["cuda:0"])
+    total, N = len(ctx.q), ctx.N
+    tiles = B * L * (N >> 12)
+    assert total >= L and tiles >= 8 * 4096, tiles
+    q = np.array(ctx.q[total - L:], dtype=np.int64)
+    n_int = int((q >= (1 << 41)).sum())
+    assert 0 < n_int < L                                            # both arithmetic classes in one launch
+    T = _chain_tables(ctx, ntt, total, L)
+
+    gen = torch.Generator(device="cuda").manual_seed(1600 + LOGN)
+    x0 = torch.empty((B, L, N), dtype=torch.int64, device="cuda")
+    for r in range(L):
+        x0[:, r] = torch.randint(0, 2 * int(q[r]), (B, N), generator=gen, device="cuda", dtype=torch.int64)
+
+    # polynomials by their place in a block's 8-tile loop: XCD-aware order -> tile i of block k is polynomial (8 k + i) % B;
+    # plain order (logN 13 shape) -> polynomial (x + 64 k + 8 i) % B for XCD lane x
+    xcd_order = ((n_int << (LOGN - 12)) & 7) == 0 and (((L - n_int) << (LOGN - 12)) & 7) == 0
+    assert xcd_order == (LOGN == 16)
+    first, mid, last = (0, 3, 7) if xcd_order else (0, 24, 56)
+    straddle = B - 1                                                # last polynomial of a pair, followed by polynomial 0 of the next
+    dirty = [first, mid, last, straddle, B // 2 + 1]               # oracle-defined out-of-range words
+    wild = [first + 8 * 2 + 1, B - 2]                               # any int64: the two forms against each other only
+    clean_checked = [1, B // 2]                                     # unflagged polynomials beside flagged ones
+    rng = np.random.default_rng(77 + LOGN)
+    host = {b: x0[b].cpu().numpy() for b in dirty + wild + clean_checked}
+    for b in dirty:
+        for r in range(L):
+            qq = int(q[r])
+            cols = rng.integers(0, N, size=6)
+            host[b][r, cols[0]] -= 2 * qq                           # signed-lazy (D.4)
+            host[b][r, cols[1]] = 2 * qq                            # boundary word
+            host[b][r, cols[2:4]] = rng.integers(-(2 ** 61), 2 ** 61, size=2, dtype=np.int64)
+            host[b][r, (r * 37) % N] = -1                           # low columns: another wave of the column pass
+            host[b][r, N - 1 - r] = 3 * qq
+        host[b][L - 1] = x0[b, L - 1].cpu().numpy()                 # one limb of a dirty polynomial stays clean
+    for b in wild:
+        for r in range(L):
+            host[b][r, rng.integers(0, N, size=5)] = rng.integers(-(2 ** 63), 2 ** 63 - 1, size=5, dtype=np.int64)
+    for b in dirty + wild:
+        x0[b] = torch.from_numpy(host[b]).cuda()
+
+    words = int(lib.lf_ntt_ws_words(B, L, LOGN))
+    ws = torch.empty((words,), dtype=torch.int64, device="cuda")
+    qh_ = q.ctypes.data
+
+    def in_place(x):
+        check(lib.lf_ntt(x.data_ptr(), B, L, LOGN, T["psi"].data_ptr(), T["psi_dp"], qh_, 0, 0, T["q2"].data_ptr(), T["ql"].data_ptr(),
+                         T["qh"].data_ptr(), T["kl"].data_ptr(), T["kh"].data_ptr(), 0, T["st"]), "lf_ntt")
+
+    def through_ws(x):
+        check(lib.lf_ntt_ws(x.data_ptr(), ws.data_ptr(), B, L, LOGN, T["psi"].data_ptr(), T["psi_dp"], qh_, 0, 0, T["ql"].data_ptr(),
+                            T["qh"].data_ptr(), T["kl"].data_ptr(), T["kh"].data_ptr(), 0, T["st"]), "lf_ntt_ws")
+
+    def two_passes(x):
+        for which in (1, 2):
+            check(lib.lf_ntt_pass_ws(x.data_ptr(), ws.data_ptr(), B, L, LOGN, T["psi"].data_ptr(), T["psi_dp"], qh_, 0, 0, which,
+                                     T["ql"].data_ptr(), T["qh"].data_ptr(), T["kl"].data_ptr(), T["kh"].data_ptr(), 0, T["st"]), "lf_ntt_pass_ws")
+
+    ref = x0.clone()
+    in_place(ref)
+    torch.cuda.synchronize()
+
+    psi_h = np.ascontiguousarray(ctx.psi_br[total - L:].copy())
+    orc.mont_enter(psi_h, T["Rs_h"], L, *T["cs"])
+    want = {}
+    for b in dirty + clean_checked:
+        w = host[b].copy()
+        orc.ntt(w, psi_h, L, LOGN, T["q2_h"], *T["cs"])
+        want[b] = w
+        assert (ref[b].cpu().numpy() == w).all(), f"lf_ntt, polynomial {b}: differs from the oracle"
+
+    assert lib.lf_tune(4, -1) == 1
+    try:
+        for extra in (1, 0):
+            assert lib.lf_tune(4, extra) in (0, 1)
+            for name, run in (("lf_ntt_ws", through_ws), ("lf_ntt_pass_ws 1 + 2", two_passes)):
+                ws.fill_(-1)                                        # a hostile workspace: stale flags raised, stale planes
+                x = x0.clone()
+                run(x)
+                torch.cuda.synchronize()
+                for b, w in want.items():
+                    got = x[b].cpu().numpy()
+                    bad = np.argwhere(got != w)
+                    assert bad.size == 0, f"{name}, extra stage {extra}, polynomial {b}: {len(bad)} words differ from the oracle, first at limb/word {bad[0].tolist()}"
+                assert torch.equal(x, ref), f"{name}, extra stage {extra}: whole batch differs from lf_ntt in place"
+                del x
+    finally:
+        lib.lf_tune(4, 1)
