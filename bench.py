@@ -150,16 +150,33 @@ def cpu_baseline(ctx, rows_idx, batch_cap=64, budget_s=12.0):
         psi = orc.place_rows(psi1, n)                       # row r's twiddles beside row r's thread
         rng = np.random.default_rng(5)
         x = orc.place_rows(rng.integers(0, 1 << 40, size=(L, ctx.N), dtype=np.int64), n)
-        orc.ntt(x, psi, n, ctx.logN, q2, ql, qh, kl, kh)   # warm (thread pool)
-        t0, reps = time.time(), 0
-        while True:
-            orc.ntt(x, psi, n, ctx.logN, q2, ql, qh, kl, kh)
-            reps += 1
-            if time.time() - t0 > budget_s or reps >= 200:
-                break
-        dt = (time.time() - t0) / reps
-        out = {"value": batch / dt, "unit": "poly-NTT(L=30,logN=16)/s", "cores": threads, "kind": "port",
-               "sample": f"{reps} x forward NTT of {batch} polys x {L} limbs, N=65536, C oracle, OpenMP static over limb rows, "
+        def threaded(budget):
+            orc.ntt(x, psi, n, ctx.logN, q2, ql, qh, kl, kh)   # warm (thread pool)
+            t0, reps = time.time(), 0
+            while True:
+                orc.ntt(x, psi, n, ctx.logN, q2, ql, qh, kl, kh)
+                reps += 1
+                if time.time() - t0 > budget or reps >= 200:
+                    break
+            return (time.time() - t0) / reps, reps
+        # two builds of the same C text (oracle/oracle.py): the portable -O2 one every test uses, and -O3 -march=native compiled
+        # on THIS box — the fair port; `value` is the faster of the two, both are in the line
+        builds = {}
+        dt_p, reps_p = threaded(0.4 * budget_s)
+        builds["portable"] = {"value": batch / dt_p, "flags": orc.build_flags("portable"), "reps": reps_p}
+        try:
+            orc.use_build("native")
+            dt_n, reps_n = threaded(0.6 * budget_s)
+            builds["native"] = {"value": batch / dt_n, "flags": orc.build_flags("native"), "reps": reps_n}
+        except Exception as e:
+            builds["native"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+            orc.use_build("portable")
+        best = max((k for k in builds if "value" in builds[k]), key=lambda k: builds[k]["value"])
+        orc.use_build(best)
+        dt, reps = batch / builds[best]["value"], builds[best]["reps"]
+        out = {"value": batch / dt, "unit": "poly-NTT(L=30,logN=16)/s", "cores": threads, "kind": "port", "build": builds[best]["flags"],
+               "builds": builds,
+               "sample": f"{reps} x forward NTT of {batch} polys x {L} limbs, N=65536, C oracle ({builds[best]['flags']}), OpenMP static over limb rows, "
                          f"{threads} threads pinned one per physical core ({cores} usable: {visible} visible, "
                          f"cgroup CPU quota {quota if quota is not None else 'none'}; {unpinned} not pinned), "
                          "rows and twiddles first-touched by their thread"}
@@ -178,6 +195,7 @@ def cpu_baseline(ctx, rows_idx, batch_cap=64, budget_s=12.0):
         out["threads_speedup_over_one"] = out["value"] / out["single_thread"]["value"]
         return out
     finally:
+        orc.use_build("portable")             # the checker build for everything after this leg
         orc.omp_threads(before)
         os.sched_setaffinity(0, affinity)     # thread 0 of the team is this thread: give it its CPUs back
 
@@ -807,6 +825,25 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def run_rccl_world1(timeout=420):
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    script = os.path.join(ROOT, "tools", "rccl_world1.py")
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=timeout)
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        block = json.loads(lines[-1]) if lines else {"ok": False, "error": "no JSON line", "stderr_tail": r.stderr[-400:]}
+        block["exit_code"] = r.returncode
+    except Exception as e:
+        block = {"ok": False, "error": f"{type(e).__name__}: {e}"[:300]}
+    block["wall_s"] = round(time.perf_counter() - t0, 1)
+    return block
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -825,6 +862,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # N = 1: the only RCCL evidence a one-GPU lease allows — tools/rccl_world1.py as a CHILD process, started and finished before
+    # this process touches the GPU (nothing is exec'ed over a GPU process, nothing runs beside the timed region): a real
+    # communicator of one rank under the engine's sharded code path, both exchange forms, graphs on and off, the stream-ordering
+    # semantics of work.wait(); its JSON becomes comm.rccl_world1 of the line.
+    rccl_world1 = None
+    if world == 1 and not args.no_extra and os.environ.get("LF_BENCH_RCCL_WORLD1", "1") != "0" and torch.cuda.device_count() >= 1:
+        rccl_world1 = run_rccl_world1()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     # development aid (never set by the driver): LF_BENCH_REHEARSE=1 runs the N > 1 code path on a ONE-GPU box —
@@ -941,8 +985,6 @@ def main():
     # Parity spot check of what the timed kernel computes, on THIS box, outside the timed region: polynomial 0 is reloaded
     # from its seed, the whole batch goes through one more step, and two of its limbs — the first integer-class one (a
     # 60-bit prime, REDC62 path) and the first fp64-class one (a 40-bit prime) — are compared word for word with the C oracle.
-    # The WHOLE batch of that step is also compared, on the device, with the strictly in-place lf_ntt of the same input
-    # (tests/test_fullsize_gpu.py holds both forms to the oracle at this shape, all 30 limbs, out-of-range words included).
     # The WHOLE batch of that step is also compared, on the device, with the strictly in-place lf_ntt of the same input
     # (tests/test_fullsize_gpu.py holds both forms to the oracle at this shape, all 30 limbs, out-of-range words included).
     def parity_spot_check():
@@ -1256,6 +1298,10 @@ def main():
                 result["sharded"] = "ok: parity-gated against the unsharded engine on every rank, then timed (extra.*limb_sharded*)"
             else:
                 result["sharded"] = "failed: " + str(extra.get("multi_gpu_limb_sharded_error") or result.get("comm", {}).get("error") or "no rate produced")
+    if rccl_world1 is not None:
+        result["comm"] = {"rccl_world1": rccl_world1,
+                          "note": "one GPU: RCCL executed at world size 1 only (library, communicator, collectives, stream ordering, the "
+                                  "engine's sharded code path on it); xGMI traffic needs N > 1"}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

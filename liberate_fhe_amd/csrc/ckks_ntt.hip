@@ -493,7 +493,8 @@ int lf_intt_mul_digits(int64_t *scratch, const int64_t *a, int64_t a_stride, con
                        const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
     const int S1 = logN - NTT_TILE_LOG_MAX;
     if (!scratch || !a || !b || !state || !desc || !tab || !ipsi_dp || !q_host || batch < 1 || batch > LF_BATCH_MAX || rows < 1 ||
-        rows > MAX_LIST_ROWS || nparts < 1 || max_alpha < 1 || S1 < 1 || S1 > 4 || (max_alpha << S1) > 32 || !(flags & LF_NTT_RELAXED))
+        rows > MAX_LIST_ROWS || nparts < 1 || max_alpha < 1 || max_alpha > KS_MAX_ALPHA || S1 < 1 || S1 > 4 || (max_alpha << S1) > 32 ||
+        !(flags & LF_NTT_RELAXED))
         return LF_ERR_ARG;
     if (int e = lf_set_device(device)) return e;
     const int tl = NTT_TILE_LOG_MAX;

@@ -156,8 +156,10 @@ def _forward(a, Rs, psi, _2q, ql, qh, kl, kh, what):
         w, back = _inplace(ai)
         table = _compact(psi[i], inverse=False)
         rs = 0 if Rs is None else _ptr(Rs[i].contiguous())
+        # one word mode per call, whichever it is: int64 data with int32 constants would be READ as int64 (wrong words, reads
+        # past the end of the constants)
+        _same_words(what, w, table, None if Rs is None else Rs[i], _2q[i], ql[i], qh[i], kl[i], kh[i])
         if _w30(w):   # 30-bit word mode: the plain per-stage transform (no fp64 class, no auxiliary table)
-            _same_words(what, w, table, _2q[i], ql[i], qh[i], kl[i], kh[i])
             check(lib.lf30_ntt(_ptr(w), 1, ql[i].size(0), _logN(w), _ptr(table), rs, _ptr(_2q[i]), _ptr(ql[i]), _ptr(qh[i]),
                                _ptr(kl[i]), _ptr(kh[i]), dev, st), what)
             if back is not None:
@@ -190,8 +192,8 @@ def _inverse(a, psi, Ninv, _2q, ql, qh, kl, kh, tail, what):
         dev, st = _dev_stream(ai)
         w, back = _inplace(ai)
         table = _compact(psi[i], inverse=True)
+        _same_words(what, w, table, Ninv[i], _2q[i], ql[i], qh[i], kl[i], kh[i])
         if _w30(w):
-            _same_words(what, w, table, Ninv[i], _2q[i], ql[i], qh[i], kl[i], kh[i])
             check(lib.lf30_intt(_ptr(w), 1, ql[i].size(0), _logN(w), _ptr(table), _ptr(Ninv[i].contiguous()), tail, _ptr(_2q[i]),
                                 _ptr(ql[i]), _ptr(qh[i]), _ptr(kl[i]), _ptr(kh[i]), dev, st), what)
             if back is not None:

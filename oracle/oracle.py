@@ -19,32 +19,76 @@ _SRC = os.path.join(_HERE, "ckks_oracle.c")
 _LIB = os.path.join(_HERE, "_build", "libckks_oracle.so")
 
 
-def build(force: bool = False) -> str:
+# Two builds of the same C text.  "portable" (-O2, no -march): what the checker uses everywhere — it is prebuilt in the build
+# container and must run on whatever host the GPU box has.  "native" (-O3 -march=native): the fair CPU port for bench.py's
+# cpu_baseline — compiled ON the box that times it (never shipped: another CPU could fault on its instructions), -fwrapv kept
+# (the reference's signed arithmetic wraps), same words as the portable build (tests/test_oracle_cpu.py).
+_FLAGS = {"portable": ["-O2"], "native": ["-O3", "-march=native", "-funroll-loops"]}
+
+
+def _lib_path(flavor):
+    if flavor == "portable":
+        return _LIB
+    import hashlib
+    import platform
+    try:
+        cpu = next((ln for ln in open("/proc/cpuinfo") if ln.startswith("flags")), "")
+    except OSError:
+        cpu = ""
+    tag = hashlib.sha256((platform.machine() + cpu).encode()).hexdigest()[:12]
+    return os.path.join(_HERE, "_build", f"libckks_oracle_native_{tag}.so")
+
+
+def build(force: bool = False, flavor: str = "portable") -> str:
+    path = _lib_path(flavor)
     newest = max(os.path.getmtime(_SRC), os.path.getmtime(os.path.join(_HERE, "ckks_oracle_impl.h")))
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < newest:
-        os.makedirs(os.path.dirname(_LIB), exist_ok=True)
-        subprocess.check_call(
-            ["gcc", "-O2", "-fwrapv", "-fopenmp", "-shared", "-fPIC", "-o", _LIB, _SRC])
-    return _LIB
+    if force or not os.path.exists(path) or os.path.getmtime(path) < newest:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        subprocess.check_call(["gcc"] + _FLAGS[flavor] + ["-fwrapv", "-fopenmp", "-shared", "-fPIC", "-o", path, _SRC])
+    return path
 
 
 _lib = None
+_libs = {}
+_flavor = "portable"
+
+
+def _load(flavor):
+    got = _libs.get(flavor)
+    if got is None:
+        got = ctypes.CDLL(build(flavor=flavor))
+        i64 = ctypes.c_int64
+        got.lfo_mm_scalar.restype = i64
+        got.lfo_mm_scalar.argtypes = [i64] * 6
+        got.lfo_redc_scalar.restype = i64
+        got.lfo_redc_scalar.argtypes = [i64] * 5
+        i32 = ctypes.c_int32
+        got.lfo30_mm_scalar.restype = i32
+        got.lfo30_mm_scalar.argtypes = [i32] * 6
+        got.lfo30_redc_scalar.restype = i32
+        got.lfo30_redc_scalar.argtypes = [i32] * 5
+        _libs[flavor] = got
+    return got
+
+
+def use_build(flavor: str) -> str:
+    """Select the build every call below goes to ("portable" | "native"); returns the previous selection."""
+    global _lib, _flavor
+    if flavor not in _FLAGS:
+        raise ValueError(flavor)
+    before, _flavor = _flavor, flavor
+    _lib = _load(flavor)
+    return before
+
+
+def build_flags(flavor=None):
+    return "gcc " + " ".join(_FLAGS[flavor or _flavor] + ["-fwrapv", "-fopenmp"])
 
 
 def lib():
     global _lib
     if _lib is None:
-        _lib = ctypes.CDLL(build())
-        i64 = ctypes.c_int64
-        _lib.lfo_mm_scalar.restype = i64
-        _lib.lfo_mm_scalar.argtypes = [i64] * 6
-        _lib.lfo_redc_scalar.restype = i64
-        _lib.lfo_redc_scalar.argtypes = [i64] * 5
-        i32 = ctypes.c_int32
-        _lib.lfo30_mm_scalar.restype = i32
-        _lib.lfo30_mm_scalar.argtypes = [i32] * 6
-        _lib.lfo30_redc_scalar.restype = i32
-        _lib.lfo30_redc_scalar.argtypes = [i32] * 5
+        _lib = _load(_flavor)
     return _lib
 
 

@@ -34,7 +34,7 @@ def _ops(eng, synth):
             "cc_mult(prod,prod,evk)": eng.cc_mult(prod, prod, evk)}
 
 
-def _worker(rank, world, port, outdir, exchange="p2p"):
+def _worker(rank, world, port, outdir, exchange="p2p", solo=False):
     warnings.filterwarnings("ignore")
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -45,8 +45,9 @@ def _worker(rank, world, port, outdir, exchange="p2p"):
     from liberate_fhe_amd.fhe.comm import DistComm
     from liberate_fhe_amd.utils import synth
     from tests.oracle_backend import OracleBackend
-    eng = ckks_engine(devices=["cpu"], backend=OracleBackend(), comm=DistComm(local_device="cpu", exchange=exchange), **PARAMS)
-    assert eng.local_ids == [rank]
+    eng = ckks_engine(devices=["cpu"], backend=OracleBackend(),
+                      comm=DistComm(local_device="cpu", exchange=exchange, solo_sharded=solo), **PARAMS)
+    assert eng.local_ids == [rank] and eng._multi == (world > 1 or solo)
     for name, ct in _ops(eng, synth).items():
         for comp, shards in enumerate(ct.data):
             assert len(shards) <= 1
@@ -56,10 +57,10 @@ def _worker(rank, world, port, outdir, exchange="p2p"):
     dist.destroy_process_group()
 
 
-def _run(world, exchange="p2p"):
+def _run(world, exchange="p2p", solo=False):
     port = 29500 + (os.getpid() % 2000) + world + (50 if exchange != "p2p" else 0)
     with tempfile.TemporaryDirectory() as outdir:
-        mp.spawn(_worker, args=(world, port, outdir, exchange), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, outdir, exchange, solo), nprocs=world, join=True)
         out = {}
         for f in os.listdir(outdir):
             name, comp, rank, _ = f.rsplit(".", 3)
@@ -84,6 +85,19 @@ def test_two_ranks_reproduce_reference_two_device_digests(exchange):
     for name, comps in want.items():
         for comp, rec in enumerate(comps):
             assert _digest(got[name][comp]) == rec["sha256"], (name, comp)
+
+
+@pytest.mark.parametrize("exchange", ["p2p", "allgather"])
+def test_one_rank_on_the_sharded_code_path_reproduces_single_device_digests(exchange):
+    """DistComm(solo_sharded=True): a group of ONE rank keeps the limb-sharded code path and issues both exchange steps to the
+    communicator (what tools/rccl_world1.py runs on a real RCCL communicator on the GPU box); the words are the one-device
+    reference digests.  Without the flag a one-rank communicator is ignored (same digests, the ordinary path)."""
+    want = GOLD["small"]["ops"]
+    for solo in (True, False):
+        got = _run(1, exchange, solo=solo)
+        for name, comps in got.items():
+            for comp in comps:
+                assert _digest(got[name][comp]) == want[name][comp]["sha256"], (solo, name, comp)
 
 
 @pytest.mark.parametrize("exchange", ["p2p", "allgather"])

@@ -164,3 +164,36 @@ def test_three_ranks_with_a_rank_out_of_rows_equal_one_process_three_devices():
             for rank in range(3):
                 want = shards[rank].cpu().numpy() if rank < len(shards) else np.zeros((0, eng.ctx.N), dtype=np.int64)
                 assert (got[f"{name}.{comp}.{rank}.npy"] == want).all(), (name, comp, rank)
+
+
+# ---- RCCL itself, at the world size a one-GPU lease allows --------------------------------------------------------------
+def test_rccl_world_size_one_under_the_sharded_engine():
+    """tools/rccl_world1.py in a FRESH process: init_process_group("nccl", world_size=1) on the leased GPU, then
+      * all_gather_into_tensor, broadcast, a self-addressed batch_isend_irecv, the empty batches and the padded all-gather of
+        fhe/comm.py at one rank;
+      * stream ordering: a collective behind a slow producer reads the producer's words, a consumer behind work.wait() reads the
+        collective's (default and side stream, async and blocking form, and a point-to-point batch);
+      * gold cc_mult / rotate_single (levels 0 and 9) on the SHARDED code path — DistComm(solo_sharded=True), exchange "p2p"
+        and "allgather", eager launches and HIP-graph replay (first op eager + capture, then replays around the live
+        exchange) — every row equal to the unsharded engine's, with the collectives counted at the backend.
+    Everything of the multi-GPU path except xGMI traffic itself (eng.py:778-810, 999-1011 are the reference's exchange sites)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_world1.py"), "--preset", "gold"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert lines, f"no JSON line (rc {r.returncode}): {r.stderr[-1500:]}"
+    rep = json.loads(lines[-1])
+    assert rep["backend"] == "nccl" and rep["world_size"] == 1, rep
+    bad = {k: v for k, v in rep["checks"].items() if not v.get("ok")}
+    bad.update({k: v for k, v in rep["engine"].items() if isinstance(v, dict) and not v.get("ok")})
+    assert not bad and rep["ok"] and r.returncode == 0, json.dumps(bad)[:2000] + r.stderr[-800:]
+    for mode in ("p2p", "allgather"):
+        e = rep["engine"][f"sharded_path_{mode}"]
+        assert e["eager_rows_differing"] == 0 and e["graph_rows_differing"] == 0 and e["graph_segment_sets"] >= 2, e
+    assert rep["engine"]["sharded_path_allgather"]["backend_calls"]["all_gather_into_tensor"] >= 4
+    assert set(rep["checks"]) >= {"communicator", "all_gather_into_tensor", "broadcast", "batch_isend_irecv_self_addressed",
+                                  "comm_patterns_one_rank", "stream_ordering"}

@@ -153,3 +153,33 @@ def test_bronze_single_limb_forward_ntt_equals_the_reference_fixture():
             for c in reversed(coeffs):
                 acc = (acc * pt + c) % q
             assert int(b[0, k]) % q == acc, (i, k)
+
+
+def test_native_build_of_the_oracle_computes_the_portable_builds_words():
+    """bench.py's cpu_baseline times a second build of the same C text (-O3 -march=native, compiled on the box that runs it);
+    it must be the same function: forward + every inverse chain on lazy, signed and boundary words, both word modes' entry
+    points present."""
+    from oracle import oracle as orc
+    from tests.helpers import Limbs, pick_primes
+    logN = 11
+    lim = Limbs(logN, pick_primes(logN, 2, 2))
+    psi, ipsi = lim.mont_tables()
+    x = lim.uniform(5, lazy=True)
+    for r, q in enumerate(lim.q):
+        x[r, :4] = [0, -(q - 1), 2 * q - 1, q]
+    got = {}
+    try:
+        for flavor in ("portable", "native"):
+            orc.use_build(flavor)
+            assert ("-march=native" in orc.build_flags()) == (flavor == "native") and "-fwrapv" in orc.build_flags()
+            f = x.copy()
+            orc.ntt(f, psi, lim.rows, logN, lim._2q, *lim.mont_args())
+            i = f.copy()
+            orc.intt(i, ipsi, lim.Ninv, lim.rows, logN, lim._2q, *lim.mont_args())
+            orc.mont_redc(i, lim.rows, *lim.mont_args())
+            orc.reduce_2q(i, lim.rows, lim._2q)
+            got[flavor] = (f, i, orc.mm_scalar(lim.q[0] - 1, 2 * lim.q[0] - 1, int(lim.ql[0]), int(lim.qh[0]), int(lim.kl[0]), int(lim.kh[0])))
+    finally:
+        orc.use_build("portable")
+    for a, b in zip(got["portable"], got["native"]):
+        assert np.array_equal(a, b)

@@ -106,6 +106,15 @@ def test_w30_elementwise_ops_equal_the_oracle_on_signed_and_boundary_words():
     # mixed word modes are refused, not reinterpreted (the reference would read int32 constants as int64 words)
     with pytest.raises(TypeError):
         ntt_cuda.reduce_2q([dev(b.astype(np.int64))], [q2])
+    # .. by the transforms too: int64 data with this mode's int32 constants (they would be read as int64 words)
+    wide = dev(b.astype(np.int64))
+    psi32 = dev(lim.mont_tables()[0])
+    c32 = [[dev(v)] for v in (lim._2q, lim.ql, lim.qh, lim.kl, lim.kh)]
+    for call in (lambda: ntt_cuda.ntt([wide], [None], [None], [psi32], *c32),
+                 lambda: ntt_cuda.enter_ntt([wide], [dev(lim.Rs)], [None], [None], [psi32], *c32),
+                 lambda: ntt_cuda.intt_exit_reduce([wide], [None], [None], [psi32], [dev(lim.Ninv)], *c32)):
+        with pytest.raises(TypeError):
+            call()
 
 
 def test_ntt_context30_on_the_gpu_reproduces_the_reference_digests():
