@@ -492,7 +492,7 @@ struct RelinFold {
 };
 
 template <int NCT, bool FOLD, bool PLANES, bool DPL>   // DPL: fp64-class rows of `ext` in planes format (digit_planes())
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCT == 4 ? 5 : 1))) ks_inner2_kernel(const i64 *__restrict__ ext, const i64 *__restrict__ ksk,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCT == 4 ? (DPL ? 5 : 4) : 1))) ks_inner2_kernel(const i64 *__restrict__ ext, const i64 *__restrict__ ksk,
                                                         i64 part_stride, i64 comp_stride, i64 row_off, i64 *__restrict__ s,
                                                         int nparts, int rows, i64 N, RelinFold fold,
                                                         const i64 *__restrict__ ql, const i64 *__restrict__ qh,
@@ -515,18 +515,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCT ==
         for (int t = 0; t < NCT; ++t) acc[t][0][0] = acc[t][0][1] = acc[t][1][0] = acc[t][1][1] = 0.0;
         const int p_own = (FOLD && fold.own != nullptr && r < fold.ell) ? (int)fold.own[r] : -1;
         const unsigned bo_lo = (unsigned)j0 * 4u, bo_hi = (unsigned)j0 * 2u;   // DPL: byte offsets of the thread's pair in the planes
-        longlong2 xo[NCT];   // the own digit's words: x1 * y1, plain canonical
+        // the own digit's words: x1 * y1, plain canonical.  SCALAR arrays, selected by value below: a choice between a 16-byte
+        // struct in registers and one in global memory is compiled to a load through select(private address, global address),
+        // and an array whose address is taken that way lives in scratch memory (48 .. 128 bytes per lane in the batched kernels
+        // until round 6; profiles/r06_kernel_resources.txt)
+        i64 xo_x[NCT], xo_y[NCT];
         if (p_own >= 0) {
 #pragma unroll
             for (int t = 0; t < NCT; ++t) {
                 const i64 *xs = fold.x + t * fold.ct_stride + (i64)r * N + j0 + (i64)fold.ell * N;
                 const longlong2 X1 = *reinterpret_cast<const longlong2 *>(xs), Y1 = *reinterpret_cast<const longlong2 *>(xs + 2 * (i64)fold.ell * N);
-                xo[t].x = dp_to_word(dp_mulmod(dp_from_word(X1.x), dp_from_word(Y1.x), d));
-                xo[t].y = dp_to_word(dp_mulmod(dp_from_word(X1.y), dp_from_word(Y1.y), d));
+                xo_x[t] = dp_to_word(dp_mulmod(dp_from_word(X1.x), dp_from_word(Y1.x), d));
+                xo_y[t] = dp_to_word(dp_mulmod(dp_from_word(X1.y), dp_from_word(Y1.y), d));
                 if constexpr (DPL) {   // in the register form of a pair read from the planes: one conversion for every digit
-                    const u64 a = (u64)xo[t].x, b = (u64)xo[t].y;
-                    xo[t].x = (i64)((a & 0xffffffffull) | (b << 32));
-                    xo[t].y = (i64)((a >> 32) | ((b >> 32) << 16));
+                    const u64 a = (u64)xo_x[t], b = (u64)xo_y[t];
+                    xo_x[t] = (i64)((a & 0xffffffffull) | (b << 32));
+                    xo_y[t] = (i64)((a >> 32) | ((b >> 32) << 16));
                 }
             }
         }
@@ -538,7 +542,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCT ==
                 for (int t = 0; t < NCT; ++t) {
                     const char *er = reinterpret_cast<const char *>(uniform_ptr(ext + (((i64)t * nparts + p) * rows + r) * N));
                     if (p == p_own) {
-                        x[t] = xo[t];
+                        x[t].x = xo_x[t], x[t].y = xo_y[t];
                     } else {
                         x[t].x = *reinterpret_cast<const i64 *>(er + bo_lo);
                         x[t].y = (i64)*reinterpret_cast<const unsigned *>(er + 4 * N + bo_hi);
@@ -546,8 +550,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCT ==
                 }
             } else {
 #pragma unroll
-                for (int t = 0; t < NCT; ++t)
-                    x[t] = p == p_own ? xo[t] : *reinterpret_cast<const longlong2 *>(e + t * ct_ext + (i64)p * rows * N);
+                for (int t = 0; t < NCT; ++t) {
+                    if (p == p_own) {
+                        x[t].x = xo_x[t], x[t].y = xo_y[t];
+                    } else {
+                        const longlong2 v = *reinterpret_cast<const longlong2 *>(e + t * ct_ext + (i64)p * rows * N);
+                        x[t].x = v.x, x[t].y = v.y;
+                    }
+                }
             }
             double k0x, k0y, k1x, k1y;
             if (PLANES) {   // 16 + 8 bytes for both components (see lf_key_planes)
@@ -610,14 +620,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCT ==
 #pragma unroll
         for (int t = 0; t < NCT; ++t) acc[t][0][0] = acc[t][0][1] = acc[t][1][0] = acc[t][1][1] = 0;
         const int p_own = (FOLD && fold.own != nullptr && r < fold.ell) ? (int)fold.own[r] : -1;
-        longlong2 xo[NCT];   // the own digit's words: REDC62(x1 * y1), Montgomery form below 2q
+        i64 xo_x[NCT], xo_y[NCT];   // the own digit's words: REDC62(x1 * y1), Montgomery form below 2q (scalars: see above)
         if (p_own >= 0) {
 #pragma unroll
             for (int t = 0; t < NCT; ++t) {
                 const i64 *xs = fold.x + t * fold.ct_stride + (i64)r * N + j0 + (i64)fold.ell * N;
                 const longlong2 X1 = *reinterpret_cast<const longlong2 *>(xs), Y1 = *reinterpret_cast<const longlong2 *>(xs + 2 * (i64)fold.ell * N);
-                xo[t].x = mm62u((u64)X1.x, (u64)Y1.x, m.q, m.k);
-                xo[t].y = mm62u((u64)X1.y, (u64)Y1.y, m.q, m.k);
+                xo_x[t] = mm62u((u64)X1.x, (u64)Y1.x, m.q, m.k);
+                xo_y[t] = mm62u((u64)X1.y, (u64)Y1.y, m.q, m.k);
             }
         }
         for (int p = 0; p < nparts; ++p) {
@@ -625,7 +635,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCT ==
             const longlong2 k1 = ld_nt(k + (i64)p * part_stride + comp_stride);
 #pragma unroll
             for (int t = 0; t < NCT; ++t) {
-                const longlong2 x = p == p_own ? xo[t] : *reinterpret_cast<const longlong2 *>(e + t * ct_ext + (i64)p * rows * N);
+                longlong2 x;
+                if (p == p_own) {
+                    x.x = xo_x[t], x.y = xo_y[t];
+                } else {
+                    const longlong2 v = *reinterpret_cast<const longlong2 *>(e + t * ct_ext + (i64)p * rows * N);
+                    x.x = v.x, x.y = v.y;
+                }
                 acc[t][0][0] = csub(acc[t][0][0] + mm62u((u64)x.x, (u64)k0.x, m.q, m.k), m.q2);
                 acc[t][0][1] = csub(acc[t][0][1] + mm62u((u64)x.y, (u64)k0.y, m.q, m.k), m.q2);
                 acc[t][1][0] = csub(acc[t][1][0] + mm62u((u64)x.x, (u64)k1.x, m.q, m.k), m.q2);

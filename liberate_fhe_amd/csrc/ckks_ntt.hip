@@ -31,6 +31,7 @@
 //   * LF_NTT_RELAXED transforms are for callers that only need the result modulo q (the fused key
 //     switch): negative input words are folded, outputs are canonical residues.  Their integer class (logN 13..16)
 //     multiplies by PLAIN twiddles with precomputed Shoup quotients from the auxiliary table (ckks_common.h).
+#include <utility>
 #include "../../include/ckks_hip.h"
 #include "ckks_ntt_core.h"
 #include "ckks_ntt_tile16.h"
@@ -118,6 +119,65 @@ void launch_cols_mixed_rs(int K, unsigned per_limb, hipStream_t st, i64 *base, c
 // stages: silver 2 x 8, bronze 1 x 4 — the column thread of the inverse pass takes the columns of ALL limbs of its digit, runs
 // the Garner step on the canonical words it holds and stores the digit state directly: the coefficient-domain product is never
 // written, one launch (of silver's eleven) and its dependency gap disappear.  desc / tab = lf_ks_digits' tables.
+// coefficient k of the thread (a compile-time index: as a `#pragma unroll` loop over k the 32-word shapes — <2, 8>, <3, 4>, <4, 2> —
+// were left rolled by the optimizer, x[][k] became a dynamic index and the 256 bytes of x lived in scratch memory)
+template <int AMAX, int R, int k>
+__device__ __forceinline__ void garner_col(const i64 (&x)[AMAX][R], i64 *out, int row_start, int alpha, const i64 *__restrict__ Y,
+                                           const i64 *__restrict__ Ls, int logN, int logC, const i64 *__restrict__ ql,
+                                           const i64 *__restrict__ qh, const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    i64 st[AMAX];
+#pragma unroll
+    for (int i = 0; i < AMAX; ++i) st[i] = x[0][k];
+    int lc = 0;
+#pragma unroll
+    for (int i = 0; i < AMAX - 1; ++i) {
+        if (i + 1 < alpha) {
+            const RowMod m = load_mod(ql, qh, kl, kh, row_start + i + 1);
+            const i64 y = mm62s(x[i + 1][k] - st[i + 1], Y[i], m.q, m.k);
+            st[i + 1] = y;
+#pragma unroll
+            for (int jj = i + 2; jj < AMAX; ++jj) {
+                if (jj < alpha) {
+                    const RowMod mj = load_mod(ql, qh, kl, kh, row_start + jj);
+                    st[jj] += mm62s(y, Ls[lc], mj.q, mj.k);
+                    ++lc;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < AMAX; ++i)
+        if (i < alpha) out[((i64)(row_start + i) << logN) + ((i64)k << logC)] = st[i];
+}
+
+template <int AMAX, int R, int... Ks>
+__device__ __forceinline__ void garner_cols(std::integer_sequence<int, Ks...>, const i64 (&x)[AMAX][R], i64 *out, int row_start, int alpha,
+                                            const i64 *__restrict__ Y, const i64 *__restrict__ Ls, int logN, int logC,
+                                            const i64 *__restrict__ ql, const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                            const i64 *__restrict__ kh) {
+    (garner_col<AMAX, R, Ks>(x, out, row_start, alpha, Y, Ls, logN, logC, ql, qh, kl, kh), ...);
+}
+
+// limb i of the thread's digit through the last inverse pass (compile-time i, for the same reason)
+template <int K, int AMAX, int... Is>
+__device__ __forceinline__ void digit_cols(std::integer_sequence<int, Is...>, i64 (&x)[AMAX][1 << K], int poly, int row_start, int alpha,
+                                           int chunk, const i64 *__restrict__ src, const PassGeom &g, const i64 *__restrict__ ipsi_br,
+                                           const double *__restrict__ ipsi_dp, const i64 *__restrict__ Ninv,
+                                           const i64 *__restrict__ ql, const i64 *__restrict__ qh, const i64 *__restrict__ kl,
+                                           const i64 *__restrict__ kh) {
+    auto one = [&](auto idx) {
+        constexpr int i = decltype(idx)::value;
+        if (i < alpha) {
+            const int crow = row_start + i;
+            const u64 q = ((u64)qh[crow] << 31) | (u64)ql[crow];
+            // tail 2 (intt_exit_reduce): canonical coefficients, what ks_digits_kernel reads
+            if (q < SMALL_PRIME_LIMIT) inv_cols_compute<true, K>(poly, crow, chunk, src, g, ipsi_br, ipsi_dp, Ninv, 2, ql, qh, kl, kh, x[i]);
+            else inv_cols_compute<false, K>(poly, crow, chunk, src, g, ipsi_br, ipsi_dp, Ninv, 2, ql, qh, kl, kh, x[i]);
+        }
+    };
+    (one(std::integral_constant<int, Is>{}), ...);
+}
+
 template <int K, int AMAX>
 __global__ void __launch_bounds__(NTT_COL_THREADS) ntt_inv_cols_digits(const i64 *__restrict__ src, i64 *__restrict__ state, PassGeom g,
                                                                       const i64 *__restrict__ desc, const i64 *__restrict__ tab,
@@ -136,44 +196,10 @@ __global__ void __launch_bounds__(NTT_COL_THREADS) ntt_inv_cols_digits(const i64
     const i64 *Ls = tab + desc[p * 4 + 3];
     if (alpha > AMAX) __builtin_trap();   // a digit wider than the caller's max_alpha: a broken table must not pass for a result
     i64 x[AMAX][R];
-#pragma unroll
-    for (int i = 0; i < AMAX; ++i) {
-        if (i < alpha) {
-            const int crow = row_start + i;
-            const u64 q = ((u64)qh[crow] << 31) | (u64)ql[crow];
-            // tail 2 (intt_exit_reduce): canonical coefficients, what ks_digits_kernel reads
-            if (q < SMALL_PRIME_LIMIT) inv_cols_compute<true, K>(poly, crow, chunk, src, g, ipsi_br, ipsi_dp, Ninv, 2, ql, qh, kl, kh, x[i]);
-            else inv_cols_compute<false, K>(poly, crow, chunk, src, g, ipsi_br, ipsi_dp, Ninv, 2, ql, qh, kl, kh, x[i]);
-        }
-    }
+    digit_cols<K, AMAX>(std::make_integer_sequence<int, AMAX>{}, x, poly, row_start, alpha, chunk, src, g, ipsi_br, ipsi_dp, Ninv, ql, qh, kl, kh);
     // the Garner step of ks_digits_kernel (ckks_fused.hip; pre_extend, ckks_engine.py:654-705), per held coefficient
     i64 *out = state + ((i64)poly * g.rows << g.logN) + chunk * NTT_COL_THREADS + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        i64 st[AMAX];
-#pragma unroll
-        for (int i = 0; i < AMAX; ++i) st[i] = x[0][k];
-        int lc = 0;
-#pragma unroll
-        for (int i = 0; i < AMAX - 1; ++i) {
-            if (i + 1 < alpha) {
-                const RowMod m = load_mod(ql, qh, kl, kh, row_start + i + 1);
-                const i64 y = mm62s(x[i + 1][k] - st[i + 1], Y[i], m.q, m.k);
-                st[i + 1] = y;
-#pragma unroll
-                for (int jj = i + 2; jj < AMAX; ++jj) {
-                    if (jj < alpha) {
-                        const RowMod mj = load_mod(ql, qh, kl, kh, row_start + jj);
-                        st[jj] += mm62s(y, Ls[lc], mj.q, mj.k);
-                        ++lc;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < AMAX; ++i)
-            if (i < alpha) out[((i64)(row_start + i) << g.logN) + ((i64)k << logC)] = st[i];
-    }
+    garner_cols<AMAX, R>(std::make_integer_sequence<int, R>{}, x, out, row_start, alpha, Y, Ls, g.logN, logC, ql, qh, kl, kh);
 }
 
 // forward transform of a stack; `rsrc` (optional): the column pass takes its input from a rescale on the fly

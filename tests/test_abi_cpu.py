@@ -198,3 +198,43 @@ def test_bench_refuses_more_ranks_than_gpus_without_touching_one():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "GPU(s)" in r.stderr and r.stdout.strip() == ""
+
+
+def test_hot_kernels_use_no_scratch_memory_and_the_tracked_table_is_current():
+    """The design argues from register counts and occupancies: they come from the compiler's own
+    kernel-resource-usage remarks of the objects the library is linked from (__graft_entry__.kernel_resources()) and are tracked as
+    profiles/r06_kernel_resources.txt.  Held here: no stack object and no spill (scratch = 0 bytes per lane) in the kernels
+    every preset's hot path launches — the column passes, the 16-words-per-thread tiled passes, the key switch's extension,
+    inner product and digit kernels (a 16-byte struct selected between registers and global memory once put 48 .. 128 bytes per
+    lane of ks_inner2_kernel<2 | 4, fold> into scratch; a rolled loop 272 bytes of ntt_inv_cols_digits) — and the occupancies the
+    launch shapes were chosen for."""
+    import re
+    import __graft_entry__ as g
+    rows = g.kernel_resources()
+    assert len(rows) > 100
+    by = {}
+    for r in rows:
+        by.setdefault(r["kernel"], []).append(r)
+    hot = re.compile(r"^(ntt_fwd_cols_ws<|ntt_fwd_cols_mixed|ntt_inv_cols_mixed<|ntt_inv_cols_ws<|ntt_inv_cols_digits<|ntt_pass16|"
+                     r"ks_ext_cols_mixed<|ks_inner2_kernel<|ks_digits_kernel|ks_moddown|ks_pivots|ew_kernel<|galois_kernel)")
+    seen = [k for k in by if hot.match(k)]
+    for need in ("ntt_fwd_cols_ws<5>", "ntt_pass16_fwd_seq_ws<true>", "ntt_pass16_fwd_seq_ws<false>", "ntt_pass16_fwd_planes",
+                 "ks_ext_cols_mixed<4>", "ks_inner2_kernel<1, true, true, true>", "ks_inner2_kernel<4, true, true, true>"):
+        assert need in by, (need, sorted(seen)[:20])
+    bad = {k: [(r["file"], r["scratch"], r["vgpr_spill"]) for r in by[k]] for k in seen if any(r["scratch"] or r["vgpr_spill"] for r in by[k])}   # (SGPR spills go to VGPR lanes, not to memory)
+    assert not bad, bad
+    # what the launch shapes rest on: 4 tiles of 34 KiB LDS per CU for the tiled passes, 3 waves per SIMD for the five-stage column pass
+    for k in seen:
+        if k.startswith("ntt_pass16"):
+            assert all(r["occupancy"] >= 4 and r["lds"] <= 40960 for r in by[k]), (k, by[k])
+    assert all(r["occupancy"] >= 3 for r in by["ntt_fwd_cols_ws<5>"])
+    assert all(r["occupancy"] >= 5 for r in by["ks_inner2_kernel<4, true, true, true>"])
+    # the only kernels with scratch at all are the 8-words tiled passes (logN <= 12 / in-place logN 17), capped at 80 VGPRs for 6 waves
+    allowed = re.compile(r"^(ntt_fwd_pass<|ntt_inv_pass_io<|ntt_inv_pass_mixed<)")
+    other = sorted({r["kernel"] for r in rows if r["scratch"] and not allowed.match(r["kernel"])})
+    assert not other, other
+    assert max(r["scratch"] for r in rows) <= 64
+    # the tracked table is the current build's (tools/kernel_resources.py writes it)
+    path = os.path.join(ROOT, "profiles", "r06_kernel_resources.txt")
+    head = open(path).readline()
+    assert g.library_digest()[:16] in head, "profiles/r06_kernel_resources.txt is stale: python tools/kernel_resources.py r06"
