@@ -33,9 +33,13 @@ extern "C" {
 #endif
 
 #define LF_ERR_ARG 10001
+/* Two halves of one operation were called under different lf_tune settings: the scratch the first half left is in another
+ * format than the second half is about to read (lf_ks_fwd -> lf_ks_tail, lf_cc_mult_evk_pre -> _post, lf_ntt_pass_ws 1 -> 2).
+ * Nothing is launched; repeat the first half. */
+#define LF_ERR_STATE 10002
 
 /* Library probe: returns the ABI version (currently LF_ABI_VERSION; __graft_entry__.build() asserts it). */
-#define LF_ABI_VERSION 14
+#define LF_ABI_VERSION 15
 int lf_abi_version(void);
 
 /* Compile-time capacities of the fused kernels, so that callers can refuse a parameter set BEFORE any launch
@@ -61,15 +65,19 @@ int lf_limits(int which);
  *                             them) the fp64-class rows of the scratch `tmp` hold their words as two planes, 6 bytes per word
  *                             (u32 low[N], u16 high[N] behind them) instead of 8, at logN >= 13 when the limbs are of both
  *                             classes; 0: raw words.  `tmp` is scratch either way; the knob must not change
- *                             between an lf_ks_fwd and its lf_ks_tail.
+ *                             between an lf_ks_fwd and its lf_ks_tail: the tail then returns LF_ERR_STATE instead of reading the wrong format.
  *   LF_TUNE_WS_EXTRA_STAGE    1 (default): in lf_ntt_ws at logN 13 .. 16 the column pass takes one stage more than logN - 12 (it is
  *                             HBM-bound with issue slots to spare) and the tiled pass, which is issue-bound, skips its first; 0: the
- *                             split of lf_ntt.  The knob must not change between the two launches of a transform (lf_ntt_pass_ws).
+ *                             split of lf_ntt.  A change between the two launches of a transform (lf_ntt_pass_ws 1 -> 2): LF_ERR_STATE.
  *   (knob 0 was the one-launch key-switch transform of round 3: slower at every preset size on MI355X, removed.) */
 #define LF_TUNE_KS_EXT_COLS_MAX 1
 #define LF_TUNE_INTT_DIGITS 2
 #define LF_TUNE_DIGIT_PLANES 3
 #define LF_TUNE_WS_EXTRA_STAGE 4
+/*   LF_TUNE_MORE_PLANES       with LF_TUNE_DIGIT_PLANES on: bit 0 (default 1) the SUMS of a key switch travel from the inner product through
+ *                             the tiled inverse pass to the column pass as planes (through `tmp`, two digits or more); bit 1
+ *                             (default 1) lf_stack_planes() answers 1: the op entries keep cc_mult's operand stack as planes. */
+#define LF_TUNE_MORE_PLANES 5
 int lf_tune(int which, int value);
 
 /* Measurement entry (not one of the reference's ops; the engine never calls it): ONE wave, launched on `stream`, takes
@@ -141,6 +149,18 @@ int lf_mont_sub(const int64_t *a, const int64_t *b, int64_t *c, int rows, int64_
  * caller may keep it, with the launches behind it, in a HIP graph: lf_cc_mult_evk_pre's `which`).  Not both. */
 #define LF_NTT_ONLY_COLS 4
 #define LF_NTT_ONLY_TILED 8
+/* The operand stack of the fused cc_mult — what lf_rescale_ntt writes with LF_NTT_RELAXED | LF_NTT_PLAIN and only lf_intt_mul(_digits)
+ * and lf_relin_* read — may keep its fp64-class rows (primes below 2^41: canonical words below 2^41) as two PLANES: u32 low[N] at
+ * byte 0 of the row's 8 N bytes, u16 high[N] at byte 4 N, 6 bytes per word on each of the stack's four trips through HBM;
+ * integer-class rows stay raw words.  lf_rescale_ntt with LF_NTT_PLANES writes that format (two-launch ring degrees, rows of both
+ * classes: lf_stack_planes() says when; otherwise LF_ERR_ARG), lf_intt_mul(_digits) with LF_NTT_PLANES read their factors in
+ * it, lf_relin_core_batch / lf_relin_tail with LF_STACK_PLANES OR-ed into `key_format` read `x` in it.  A stack written in one
+ * format and read in the other: LF_ERR_STATE. */
+#define LF_NTT_PLANES 16
+#define LF_STACK_PLANES 4
+/* 1 when internal stacks of the rows [0, rows) of q_host (HOST) keep fp64-class rows as planes: lf_tune(LF_TUNE_DIGIT_PLANES)
+ * is on, 13 <= logN <= 24, and the rows hold primes of both arithmetic classes.  (The engine-op entries ask this themselves.) */
+int lf_stack_planes(int logN, int rows, const int64_t *q_host);
 
 /* The auxiliary table from the Montgomery-form compact table mont[rows][N]: out[rows][2N] (8-byte words).
  * Primes below 2^41: out[r][j] = (double)reduce_q(redc(mont[r][j])) for j < N; entry 0 of the row (psi^0 = 1, which
@@ -317,13 +337,14 @@ int lf_ks_core_batch(const int64_t *state, int64_t state_stride, int nct, int np
  * every digit through the host before any extension starts):
  *   lf_ks_fwd   extension + forward NTT of `nparts` digits, descriptors desc[0 .. nparts); the caller offsets desc
  *               and tmp to the first digit of the group (desc + 3 * first, tmp + first * rows * N);
- *   lf_ks_tail  after the last group: inner product of ALL nparts digits in tmp with the key + inverse NTT.
+ *   lf_ks_tail  after the last group: inner product of ALL nparts digits in tmp with the key + inverse NTT (tmp is scratch
+ *               afterwards: with two digits or more the sums' inverse transform passes through it).
  * lf_ks_fwd over all digits followed by lf_ks_tail == lf_ks_core. */
 int lf_ks_fwd(const int64_t *state, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E, const double *Ed,
               int64_t *tmp, const int64_t *psi_br, const double *psi_dp, const int64_t *q_host, const int64_t *ql,
               const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream);
 int lf_ks_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
-               int key_format, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
+               int key_format, int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
                const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
                const int64_t *kh, int device, void *stream);
 
@@ -351,7 +372,7 @@ int lf_relin_fwd(const int64_t *state, int first, int nparts, int rows, int logN
                  const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
                  void *stream);
 int lf_relin_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
-                  int key_format, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
+                  int key_format, int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
                   const int64_t *x, const int64_t *PR, int ell, const uint8_t *own, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
                   void *stream);
 

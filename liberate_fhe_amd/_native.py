@@ -29,6 +29,7 @@ _SIGNATURES = {
     "lf_abi_version": [],
     "lf_limits": [_I],
     "lf_tune": [_I, _I],
+    "lf_stack_planes": [_I, _I, _P],
     "lf_clock_probe": [_P, _I, _U, _I, _P],
     "lf_ntt_pass": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
     "lf_ntt_ws_words": [_I, _I, _I],
@@ -132,6 +133,9 @@ class HipError(RuntimeError):
 
 
 def check(code: int, what: str):
+    if code == LF_ERR_STATE:
+        raise HipError(f"{what} refused (status {code}, LF_ERR_STATE): the scratch the first half of this operation left is in another "
+                       "format than this half reads — lf_tune changed between the two; repeat the first half")
     if code != 0:
         raise HipError(f"{what} failed with status {code}")
 
@@ -143,3 +147,7 @@ LF_NTT_RELAXED = 1
 LF_NTT_PLAIN = 2
 LF_NTT_ONLY_COLS = 4
 LF_NTT_ONLY_TILED = 8
+LF_NTT_PLANES = 16
+LF_STACK_PLANES = 4
+LF_ERR_ARG = 10001
+LF_ERR_STATE = 10002

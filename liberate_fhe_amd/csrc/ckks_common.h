@@ -170,6 +170,22 @@ static __device__ __forceinline__ double dp_from_signed(i64 x) {
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Host side: the format of library-internal scratch that crosses NATIVE CALLS (ckks_hip.hip)
+// ------------------------------------------------------------------------------------------------
+// Where a kernel hands fp64-class rows to the next one as 6-byte planes (the extended digits of a key switch, cc_mult's operand
+// stack, the workspace of a transform), producer and consumer may be launched by DIFFERENT native calls (lf_ks_fwd -> lf_ks_tail,
+// lf_cc_mult_evk_pre -> _post, lf_ntt_pass_ws 1 -> 2) and both decide the format from lf_tune's process-wide knobs.  The
+// producer notes the format it wrote over [p, p + bytes); the consumer states the format it is about to read and gets
+// LF_ERR_STATE — nothing launched — when a noted range it overlaps was written in another one (a knob flipped between the
+// halves).  Ranges nobody noted are taken on trust (a caller may fill scratch by hand).  Mutex-protected, 256 ranges, oldest out.
+#define LF_FMT_RAW 0
+#define LF_FMT_PLANES 1
+#define LF_FMT_WS_SPLIT0 2      // lf_ntt_ws workspace written by a column pass without / with the extra stage
+#define LF_FMT_WS_SPLIT1 3
+void lf_fmt_note(const void *p, size_t bytes, int fmt);
+int lf_fmt_expect(const void *p, size_t bytes, int fmt);   // 0, or LF_ERR_STATE
+
 static inline int lf_set_device(int device) {
     if (device >= 0) {
         hipError_t e = hipSetDevice(device);

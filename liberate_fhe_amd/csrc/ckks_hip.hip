@@ -8,6 +8,7 @@
 //    which is exactly (a*b + s*q) / 2^62 for all |a|,|b| < 2^62, i.e. bit-identical outputs.
 //  * The NTT family lives in ckks_ntt.hip, the engine-level fused kernels in ckks_fused.hip.
 //  * No MFMA: this is 64-bit integer modular arithmetic.  No CUDA shims; gfx950 only.
+#include <mutex>
 #include "../../include/ckks_hip.h"
 #include "ckks_common.h"
 
@@ -121,6 +122,59 @@ __global__ void clock_probe_kernel(unsigned long long *out, int samples, unsigne
 }
 
 }  // namespace
+
+// ---- formats of scratch that crosses native calls (ckks_common.h) ------------------------------------------------------------
+namespace {
+struct FmtRange {
+    uintptr_t lo, hi;
+    int fmt;
+    unsigned long long age;
+};
+std::mutex g_fmt_mutex;
+FmtRange g_fmt[256];
+int g_fmt_n = 0;
+unsigned long long g_fmt_clock = 0;
+}  // namespace
+
+void lf_fmt_note(const void *p, size_t bytes, int fmt) {
+    if (!p || !bytes) return;
+    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+    std::lock_guard<std::mutex> lock(g_fmt_mutex);
+    // what this write covers is forgotten (ranges it cuts keep the part it left; a range split in two keeps the lower part:
+    // forgetting is always safe, unknown ranges are taken on trust)
+    int n = 0;
+    for (int i = 0; i < g_fmt_n; ++i) {
+        FmtRange r = g_fmt[i];
+        if (r.hi <= lo || r.lo >= hi) {
+            g_fmt[n++] = r;
+            continue;
+        }
+        if (r.lo < lo) {
+            r.hi = lo;
+            g_fmt[n++] = r;
+        } else if (r.hi > hi) {
+            r.lo = hi;
+            g_fmt[n++] = r;
+        }
+    }
+    g_fmt_n = n;
+    if (g_fmt_n == 256) {   // oldest out
+        int o = 0;
+        for (int i = 1; i < 256; ++i)
+            if (g_fmt[i].age < g_fmt[o].age) o = i;
+        g_fmt[o] = g_fmt[--g_fmt_n];
+    }
+    g_fmt[g_fmt_n++] = FmtRange{lo, hi, fmt, ++g_fmt_clock};
+}
+
+int lf_fmt_expect(const void *p, size_t bytes, int fmt) {
+    if (!p || !bytes) return 0;
+    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+    std::lock_guard<std::mutex> lock(g_fmt_mutex);
+    for (int i = 0; i < g_fmt_n; ++i)
+        if (g_fmt[i].hi > lo && g_fmt[i].lo < hi && g_fmt[i].fmt != fmt) return LF_ERR_STATE;
+    return 0;
+}
 
 // ------------------------------------------------------------------------------------------------
 // C ABI

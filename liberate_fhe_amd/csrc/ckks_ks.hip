@@ -489,14 +489,28 @@ struct RelinFold {
     // component x1 * y1 in the NTT domain — the extension (mod q_r) of a digit's mixed-radix form to one of its own primes
     // is the residue it was built from — so it is formed here from the operands instead of being read from `ext`
     const unsigned char *own;
+    int xpl;            // 1: fp64-class rows of x are planes (lf_rescale_ntt with LF_NTT_PLANES; key_format | LF_STACK_PLANES)
 };
 
+// the two words at coefficients j0, j0 + 1 of an fp64-class row: raw 16 bytes, or 8 + 4 bytes of its planes
+static __device__ __forceinline__ void ld_pair_dp(const i64 *row, i64 j0, i64 N, int planes, double &a, double &b) {
+    if (planes) {
+        const lf_u2_t l = *reinterpret_cast<const lf_u2_t *>(reinterpret_cast<const unsigned *>(row) + j0);
+        const unsigned h = *reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned short *>(row + (N >> 1)) + j0);
+        a = dp_from_planes(l.x, h & 0xffffu), b = dp_from_planes(l.y, h >> 16);
+    } else {
+        const longlong2 v = *reinterpret_cast<const longlong2 *>(row + j0);
+        a = dp_from_word(v.x), b = dp_from_word(v.y);
+    }
+}
+
 template <int NCT, bool FOLD, bool PLANES, bool DPL>   // DPL: fp64-class rows of `ext` in planes format (digit_planes())
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCT == 4 ? (DPL ? 5 : 4) : 1))) ks_inner2_kernel(const i64 *__restrict__ ext, const i64 *__restrict__ ksk,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCT == 4 ? ((DPL && !FOLD) ? 5 : 4) : 1))) ks_inner2_kernel(const i64 *__restrict__ ext, const i64 *__restrict__ ksk,
                                                         i64 part_stride, i64 comp_stride, i64 row_off, i64 *__restrict__ s,
-                                                        int nparts, int rows, i64 N, RelinFold fold,
+                                                        int nparts, int rows, i64 N, RelinFold fold, int spl,
                                                         const i64 *__restrict__ ql, const i64 *__restrict__ qh,
                                                         const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    // spl: the sums of fp64-class rows leave as planes (the inverse passes behind read them so: ks_tail)
     // each thread owns KI_V 16-byte column pairs 4 KiB apart: every block streams KI_V x 4 KiB contiguous runs
     // from 3 x nparts arrays, enough bytes in flight to keep HBM busy
     constexpr int KI_V = KI_COLS;
@@ -523,10 +537,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCT ==
         if (p_own >= 0) {
 #pragma unroll
             for (int t = 0; t < NCT; ++t) {
-                const i64 *xs = fold.x + t * fold.ct_stride + (i64)r * N + j0 + (i64)fold.ell * N;
-                const longlong2 X1 = *reinterpret_cast<const longlong2 *>(xs), Y1 = *reinterpret_cast<const longlong2 *>(xs + 2 * (i64)fold.ell * N);
-                xo_x[t] = dp_to_word(dp_mulmod(dp_from_word(X1.x), dp_from_word(Y1.x), d));
-                xo_y[t] = dp_to_word(dp_mulmod(dp_from_word(X1.y), dp_from_word(Y1.y), d));
+                const i64 *xs = fold.x + t * fold.ct_stride + (i64)r * N + (i64)fold.ell * N;
+                double x1a, x1b, y1a, y1b;
+                ld_pair_dp(xs, j0, N, fold.xpl, x1a, x1b);
+                ld_pair_dp(xs + 2 * (i64)fold.ell * N, j0, N, fold.xpl, y1a, y1b);
+                xo_x[t] = dp_to_word(dp_mulmod(x1a, y1a, d));
+                xo_y[t] = dp_to_word(dp_mulmod(x1b, y1b, d));
                 if constexpr (DPL) {   // in the register form of a pair read from the planes: one conversion for every digit
                     const u64 a = (u64)xo_x[t], b = (u64)xo_y[t];
                     xo_x[t] = (i64)((a & 0xffffffffull) | (b << 32));
@@ -592,11 +608,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCT ==
             const i64 pstride = (i64)fold.ell * N;
 #pragma unroll
             for (int t = 0; t < NCT; ++t) {
-                const i64 *xs = fold.x + t * fold.ct_stride + (i64)r * N + j0;
-                const longlong2 X0 = *reinterpret_cast<const longlong2 *>(xs), X1 = *reinterpret_cast<const longlong2 *>(xs + pstride);
-                const longlong2 Y0 = *reinterpret_cast<const longlong2 *>(xs + 2 * pstride), Y1 = *reinterpret_cast<const longlong2 *>(xs + 3 * pstride);
-                const double x0[2] = {dp_from_word(X0.x), dp_from_word(X0.y)}, x1[2] = {dp_from_word(X1.x), dp_from_word(X1.y)};
-                const double y0[2] = {dp_from_word(Y0.x), dp_from_word(Y0.y)}, y1[2] = {dp_from_word(Y1.x), dp_from_word(Y1.y)};
+                const i64 *xs = fold.x + t * fold.ct_stride + (i64)r * N;
+                double x0[2], x1[2], y0[2], y1[2];
+                ld_pair_dp(xs, j0, N, fold.xpl, x0[0], x0[1]);
+                ld_pair_dp(xs + pstride, j0, N, fold.xpl, x1[0], x1[1]);
+                ld_pair_dp(xs + 2 * pstride, j0, N, fold.xpl, y0[0], y0[1]);
+                ld_pair_dp(xs + 3 * pstride, j0, N, fold.xpl, y1[0], y1[1]);
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {   // balanced terms: |d0| <= q / 2, |d1| <= q
                     const double d0 = dp_mulmod_bal(x0[e], y0[e], d);
@@ -613,7 +630,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NCT ==
                 longlong2 o;
                 o.x = dp_to_word(dp_reduce(acc[t][c][0], d.q, d.qinv));
                 o.y = dp_to_word(dp_reduce(acc[t][c][1], d.q, d.qinv));
-                *reinterpret_cast<longlong2 *>(s + t * ct_s + ((i64)c * rows + r) * N + j0) = o;
+                i64 *srow = s + t * ct_s + ((i64)c * rows + r) * N;
+                if (spl) {
+                    const lf_u2_t l = {(unsigned)o.x, (unsigned)o.y};
+                    *reinterpret_cast<lf_u2_t *>(reinterpret_cast<unsigned *>(srow) + j0) = l;
+                    *reinterpret_cast<unsigned *>(reinterpret_cast<unsigned short *>(srow + (N >> 1)) + j0) =
+                        (unsigned)((u64)o.x >> 32) | ((unsigned)((u64)o.y >> 32) << 16);
+                } else {
+                    *reinterpret_cast<longlong2 *>(srow + j0) = o;
+                }
             }
     } else {
         i64 acc[NCT][2][2];
@@ -692,10 +717,19 @@ int g_ks_ext_cols_max = 5;
 // kernel and the LDS-tiled extension both write it) where both classes are present.  BOTH halves decide with this function: the
 // knob must not change between an lf_ks_fwd and its lf_ks_tail (lf_tune is a start-up / A-B facility, see the header).
 int g_digit_planes = 1;
+int g_more_planes = 3;   // LF_TUNE_MORE_PLANES: bit 0 = the sums of a key switch, bit 1 = cc_mult's operand stack (with g_digit_planes)
 bool digit_planes(int logN, const RowList &dp, const RowList &in) {
     return g_digit_planes && logN > NTT_TILE_LOG_MAX && dp.n && in.n;
 }
 
+}  // namespace
+extern "C" int lf_stack_planes(int logN, int rows, const int64_t *q_host) {
+    if (!g_digit_planes || !(g_more_planes & 2) || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX || !q_host || rows < 1) return 0;
+    int small = 0, large = 0;
+    for (int r = 0; r < rows; ++r) ((uint64_t)q_host[r] < SMALL_PRIME_LIMIT ? small : large)++;
+    return small && large ? 1 : 0;
+}
+namespace {
 void classify_rows(int rows, const int64_t *q_host, RowList &dp, RowList &in) {
     dp.n = in.n = 0;
     for (int r = 0; r < rows; ++r) {
@@ -714,6 +748,7 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
     RowList dp, in;
     classify_rows(rows, q_host, dp, in);
     const bool dplanes = digit_planes(logN, dp, in);
+    lf_fmt_note(tmp, ((size_t)nct * nparts * rows << logN) * 8, dplanes ? LF_FMT_PLANES : LF_FMT_RAW);
     const KsGeom kg{logN, tl, S1, rows, nparts, (i64)1 << logN, nct, (i64)state_stride, own, p0, dplanes ? 1 : 0};
     const unsigned tiles = 1u << (logN - tl);
     const unsigned polys = (unsigned)nparts * (unsigned)nct;   // extended digits of all ciphertexts: one stack
@@ -756,7 +791,7 @@ int ks_forward(const int64_t *state, int64_t state_stride, int nct, int nparts, 
 
 // K3 + K4: inner product of the nparts extended digits with the key, inverse transform to canonical coefficients
 int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride,
-            int64_t row_off, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp,
+            int64_t row_off, int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp,
             const int64_t *Ninv, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
             const int64_t *kh, hipStream_t st, const RelinFold *fold = nullptr, int key_format = LF_KEY_RAW) {
     if (!ipsi_dp || (key_format != LF_KEY_RAW && key_format != LF_KEY_PLANES)) return LF_ERR_ARG;
@@ -766,14 +801,23 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
     RowList dp, in;
     classify_rows(rows, q_host, dp, in);
     const bool mixed = dp.n && in.n;
+    const bool dplanes = digit_planes(logN, dp, in);
+    const bool cols_last = S1 <= 4 || (S1 == 5 && mixed && g_ks_ext_cols_max > 4);   // column form of the last inverse pass
+    // the digits in tmp must be in the format this half is about to read (lf_tune flipped between lf_ks_fwd and here: LF_ERR_STATE)
+    if (int e = lf_fmt_expect(tmp, ((size_t)nct * nparts * rows << logN) * 8, dplanes ? LF_FMT_PLANES : LF_FMT_RAW)) return e;
+    // The SUMS travel the same way: the inner product writes fp64-class rows as planes into s, the tiled inverse pass carries
+    // them s -> tmp (the digits are spent by then: tmp is scratch, and a pass that changes the format cannot run in place),
+    // the column pass reads the planes and leaves canonical words in s.  6 instead of 8 bytes per word on three of the
+    // sums' four trips; needs room for 2 nct polynomials in tmp (two digits or more) and the column form of the last pass.
+    const bool spl = dplanes && (g_more_planes & 1) && cols_last && nparts >= 2;
     // K3: inner product with the key, summed over the digits
     {
         const i64 N = (i64)1 << logN;
         dim3 grid((unsigned)((N + 512 * KI_COLS - 1) / (512 * KI_COLS)), (unsigned)rows);
-        const RelinFold nofold{nullptr, 0, nullptr, 0, nullptr};
+        const RelinFold nofold{nullptr, 0, nullptr, 0, nullptr, 0};
 #define LF_INNER_LAUNCH(NCT, FOLDB, PL, DPLB, FOLDV)                                                                   \
     hipLaunchKernelGGL((ks_inner2_kernel<NCT, FOLDB, PL, DPLB>), grid, dim3(256), 0, st, (const i64 *)tmp, (const i64 *)ksk, \
-                       (i64)part_stride, (i64)comp_stride, (i64)row_off, (i64 *)s, nparts, rows, N, FOLDV, (const i64 *)ql, \
+                       (i64)part_stride, (i64)comp_stride, (i64)row_off, (i64 *)s, nparts, rows, N, FOLDV, spl ? 1 : 0, (const i64 *)ql, \
                        (const i64 *)qh, (const i64 *)kl, (const i64 *)kh)
 #define LF_INNER_DPL(NCT, FOLDB, PL, FOLDV)                                                                            \
     do {                                                                                                               \
@@ -788,7 +832,6 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
         else LF_INNER_DPL(NCT, false, false, nofold);                                                                  \
         break;
         const bool planes = key_format == LF_KEY_PLANES;
-        const bool dplanes = digit_planes(logN, dp, in);
         switch (nct) {
             LF_INNER_CASE(1) LF_INNER_CASE(2) LF_INNER_CASE(4)
         }
@@ -803,11 +846,15 @@ int ks_tail(int nct, int nparts, int rows, int logN, const int64_t *ksk, int64_t
         PassGeom g = pass == 0 ? PassGeom{logN, tl, 0, tl, 0, 0, rows, inv_polys, 1, 0, 0}
                                : PassGeom{logN, tl, 1, S1, tl, tl - S1, rows, inv_polys, 1, 1, 0};
         if (pass == 0) {
-            launch_pass16(true, 1, inv_polys, st, (const i64 *)s, (i64 *)s, g, in, dp, (const i64 *)ipsi_br, ipsi_dp,
-                          (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+            launch_pass16(true, 1, inv_polys, st, (const i64 *)s, spl ? (i64 *)tmp : (i64 *)s, g, in, dp, (const i64 *)ipsi_br, ipsi_dp,
+                          (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh, nullptr, spl);
             continue;
         }
-        if (pass == 1 && (S1 <= 4 || (S1 == 5 && mixed && g_ks_ext_cols_max > 4))) {   // (logN 17: the column form of both ends goes with the knob)
+        if (pass == 1 && cols_last) {   // (logN 17: the column form of both ends goes with the knob)
+            if (spl) {
+                g.pln = PLN_IN;
+                g.pln_src = (const i64 *)tmp;
+            }
             if (mixed) {
                 launch_inv_cols_mixed(S1, inv_polys, st, (i64 *)s, g, in, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)Ninv, 2,
                                       (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
@@ -850,11 +897,13 @@ extern "C" {
 
 int lf_tune(int which, int value) {
     int *knob = which == LF_TUNE_KS_EXT_COLS_MAX ? &g_ks_ext_cols_max : which == LF_TUNE_INTT_DIGITS ? &lf_g_intt_digits
-                : which == LF_TUNE_DIGIT_PLANES ? &g_digit_planes : which == LF_TUNE_WS_EXTRA_STAGE ? &lf_g_ws_extra_stage : nullptr;
+                : which == LF_TUNE_DIGIT_PLANES ? &g_digit_planes : which == LF_TUNE_WS_EXTRA_STAGE ? &lf_g_ws_extra_stage
+                : which == LF_TUNE_MORE_PLANES ? &g_more_planes : nullptr;
     if (!knob) return -1;
     const int old = *knob;
     if (value < 0) return old;
     if (which == LF_TUNE_KS_EXT_COLS_MAX && value > 5) return old;
+    if (which == LF_TUNE_MORE_PLANES && value > 3) return old;
     if ((which == LF_TUNE_INTT_DIGITS || which == LF_TUNE_DIGIT_PLANES || which == LF_TUNE_WS_EXTRA_STAGE) && value > 1) return old;
     *knob = value;
     return old;
@@ -906,7 +955,7 @@ int lf_ks_fwd(const int64_t *state, int nparts, int rows, int logN, const int64_
 }
 
 int lf_ks_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
-               int key_format, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
+               int key_format, int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
                const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl,
                const int64_t *kh, int device, void *stream) {
     if (nparts < 1 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
@@ -934,9 +983,12 @@ int lf_relin_core_batch(const int64_t *state, int64_t state_stride, int nct, int
     if (int e = ks_forward(state, state_stride, nct, nparts, rows, logN, desc, E, Ed, tmp, psi_br, psi_dp, q_host, ql, qh, kl, kh, st,
                            (const unsigned char *)own, 0))
         return e;
-    const RelinFold fold{(const i64 *)x, (i64)x_ct_stride, (const i64 *)PR, ell, (const unsigned char *)own};
+    const int xpl = (key_format & LF_STACK_PLANES) ? 1 : 0;
+    for (int t = 0; t < nct; ++t)   // the operand stacks must be in the format the caller says (see lf_fmt_expect)
+        if (int e = lf_fmt_expect(x + t * x_ct_stride, ((size_t)4 * ell << logN) * 8, xpl ? LF_FMT_PLANES : LF_FMT_RAW)) return e;
+    const RelinFold fold{(const i64 *)x, (i64)x_ct_stride, (const i64 *)PR, ell, (const unsigned char *)own, xpl};
     return ks_tail(nct, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh,
-                   kl, kh, st, &fold, key_format);
+                   kl, kh, st, &fold, key_format & ~LF_STACK_PLANES);
 }
 
 int lf_relin_fwd(const int64_t *state, int first, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,
@@ -953,16 +1005,18 @@ int lf_relin_fwd(const int64_t *state, int first, int nparts, int rows, int logN
 }
 
 int lf_relin_tail(int nparts, int rows, int logN, const int64_t *ksk, int64_t part_stride, int64_t comp_stride, int64_t row_off,
-                  int key_format, const int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
+                  int key_format, int64_t *tmp, int64_t *s, const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *Ninv,
                   const int64_t *x, const int64_t *PR, int ell, const uint8_t *own, const int64_t *q_host, const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device,
                   void *stream) {
     if (nparts < 1 || nparts > 254 || rows < 1 || rows > MAX_LIST_ROWS || logN <= NTT_TILE_LOG_MAX || logN > 2 * NTT_TILE_LOG_MAX ||
         !q_host || !ipsi_dp || !x || !PR || ell < 0 || ell > rows)
         return LF_ERR_ARG;
     if (int e = lf_set_device(device)) return e;
-    const RelinFold fold{(const i64 *)x, 0, (const i64 *)PR, ell, (const unsigned char *)own};
+    const int xpl = (key_format & LF_STACK_PLANES) ? 1 : 0;
+    if (int e = lf_fmt_expect(x, ((size_t)4 * ell << logN) * 8, xpl ? LF_FMT_PLANES : LF_FMT_RAW)) return e;
+    const RelinFold fold{(const i64 *)x, 0, (const i64 *)PR, ell, (const unsigned char *)own, xpl};
     return ks_tail(1, nparts, rows, logN, ksk, part_stride, comp_stride, row_off, tmp, s, ipsi_br, ipsi_dp, Ninv, q_host, ql, qh, kl,
-                   kh, (hipStream_t)stream, &fold, key_format);
+                   kh, (hipStream_t)stream, &fold, key_format & ~LF_STACK_PLANES);
 }
 
 int lf_ks_core(const int64_t *state, int nparts, int rows, int logN, const int64_t *desc, const int64_t *E,

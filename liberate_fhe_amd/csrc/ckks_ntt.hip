@@ -335,17 +335,41 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
     // through a workspace (lf_ntt_ws): exact two-launch sizes whose tiled pass is the 4096-word one; anything else ignores `ws`
     const bool through_ws = ws && !relaxed && !rsrc && S1 >= 1 && S1 <= 5 && tl == NTT_TILE_LOG_MAX;
     unsigned char *wflags = through_ws ? reinterpret_cast<unsigned char *>(ws + ((i64)nb * rows << logN)) : nullptr;
+    // the opening of cc_mult (rescale + relaxed plain-domain transform of the operand stack): the stack is internal to the
+    // library — read by lf_intt_mul(_digits) and lf_relin_* only — and with LF_NTT_PLANES keeps its fp64-class rows as planes
+    // (callers ask where lf_stack_planes() says so): 6 bytes per word on each of its four trips
+    const bool xpl = (flags & LF_NTT_PLANES) != 0;
+    if (xpl && !(rsrc && relaxed && plain && S1 >= 1 && S1 <= 5 && tl == NTT_TILE_LOG_MAX && dp.n && in.n)) return LF_ERR_ARG;
     for (int pass = (S1 > 0 ? 0 : 1); pass < 2; ++pass) {
         if (only_pass && pass + 1 != only_pass) continue;   // measurement only: time one pass kernel by itself
-        const PassGeom g = pass == 0 ? PassGeom{logN, tl, 1, S1, 0, tl - S1, rows, nb, relaxed, 0, plain}
-                                     : PassGeom{logN, tl, 0, tl, S1, 0, rows, nb, relaxed, 1, plain};
+        PassGeom g = pass == 0 ? PassGeom{logN, tl, 1, S1, 0, tl - S1, rows, nb, relaxed, 0, plain}
+                               : PassGeom{logN, tl, 0, tl, S1, 0, rows, nb, relaxed, 1, plain};
         const i64 *rs = (pass == 0 || S1 == 0) ? (const i64 *)Rs : nullptr;
+        if (xpl) {   // cc_mult's operand stack: the column pass writes planes, the tiled pass transforms them in place
+            const size_t bytes = ((size_t)nb * rows << logN) * 8;
+            if (pass == 0) {
+                g.pln = PLN_OUT;
+                lf_fmt_note(base, bytes, LF_FMT_PLANES);
+            } else if (int e = lf_fmt_expect(base, bytes, LF_FMT_PLANES)) {
+                return e;
+            }
+        } else if (rsrc && relaxed && plain) {
+            const size_t bytes = ((size_t)nb * rows << logN) * 8;
+            if (pass == 0) lf_fmt_note(base, bytes, LF_FMT_RAW);
+            else if (int e = lf_fmt_expect(base, bytes, LF_FMT_RAW)) return e;
+        }
         if (through_ws) {
             // the column pass is HBM-bound with half its issue slots free, the tiled pass issue-bound: through a workspace the
             // column pass takes ONE STAGE MORE (up to 5: 32 words per thread, 141 registers, still at the HBM rate) and the
             // tiles skip their first (lf_tune LF_TUNE_WS_EXTRA_STAGE)
             const bool extra = lf_g_ws_extra_stage && S1 <= 4;
             const int Kc = S1 + (extra ? 1 : 0);
+            {   // the two launches may be two calls (lf_ntt_pass_ws): the tiled pass must find the split the column pass left
+                const size_t bytes = ((size_t)nb * rows << logN) * 8;
+                const int fmt = extra ? LF_FMT_WS_SPLIT1 : LF_FMT_WS_SPLIT0;
+                if (pass == 0) lf_fmt_note(ws, bytes, fmt);
+                else if (int e = lf_fmt_expect(ws, bytes, fmt)) return e;
+            }
             if (pass == 0) {
                 const unsigned per_limb = (unsigned)nb * ((1u << (logN - Kc)) / NTT_COL_THREADS);
                 const ClassLists cl = class_lists(in, dp, per_limb * (unsigned)in.n);
@@ -381,7 +405,7 @@ int ntt_forward(int64_t *a, int batch, int rows, int logN, const int64_t *psi_br
         if (pass == 1 && S1 > 0 && tl == NTT_TILE_LOG_MAX && rs == nullptr) {
             // contiguous 12-stage pass: 16 words per thread (ckks_ntt_tile16.h), either class or both
             launch_pass16(false, relaxed, nb, st, base, base, g, in, dp, (const i64 *)psi_br, psi_dp, (const i64 *)ql,
-                          (const i64 *)qh, (const i64 *)kl, (const i64 *)kh);
+                          (const i64 *)qh, (const i64 *)kl, (const i64 *)kh, nullptr, xpl);
             continue;
         }
         if (mixed) {
@@ -427,6 +451,16 @@ static int intt_impl(int64_t *a, const int64_t *src, const MulSrc *ms, int batch
     classify(rows, q_host, ipsi_dp, dp, in);
     hipStream_t st = (hipStream_t)stream;
     const bool mixed = dp.n && in.n;   // both classes in one launch per pass
+    // LF_NTT_PLANES (product-on-load only): the factors are stacks whose fp64-class rows are planes (lf_rescale_ntt with the flag)
+    const bool mpl = (flags & LF_NTT_PLANES) != 0;
+    if (mpl && !(ms && relaxed && plain && mixed && SB >= 1 && tl == NTT_TILE_LOG_MAX)) return LF_ERR_ARG;
+    if (ms) {
+        const int want = mpl ? LF_FMT_PLANES : LF_FMT_RAW;
+        for (int t = 0; t < batch; ++t) {
+            if (int e = lf_fmt_expect(src + t * ms->a_stride, ((size_t)rows << logN) * 8, want)) return e;
+            if (int e = lf_fmt_expect(ms->b + t * ms->b_stride, ((size_t)rows << logN) * 8, want)) return e;
+        }
+    }
     // (splitting a batch so that its two passes meet in the Infinity Cache was measured on MI355X and only adds launch
     // tails, DESIGN.md §4: the whole batch goes through each pass in one launch)
     i64 *base = (i64 *)a;
@@ -472,7 +506,7 @@ static int intt_impl(int64_t *a, const int64_t *src, const MulSrc *ms, int batch
         }
         if (pass == 0 && SB > 0 && tl == NTT_TILE_LOG_MAX) {
             launch_pass16(true, relaxed, nb, st, ms ? (const i64 *)src : (const i64 *)base, base, g, in, dp, (const i64 *)ipsi_br,
-                          ipsi_dp, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh, ms);
+                          ipsi_dp, (const i64 *)ql, (const i64 *)qh, (const i64 *)kl, (const i64 *)kh, ms, mpl);
             continue;
         }
         if (mixed) {
@@ -529,9 +563,15 @@ int lf_intt_mul_digits(int64_t *scratch, const int64_t *a, int64_t a_stride, con
     classify(rows, q_host, ipsi_dp, dp, in);
     hipStream_t st = (hipStream_t)stream;
     const MulSrc ms{(const i64 *)b, (i64)a_stride, (i64)b_stride};
+    const bool mpl = (flags & LF_NTT_PLANES) != 0;   // the factors' fp64-class rows are planes (lf_rescale_ntt with the flag)
+    if (mpl && !(plain && dp.n && in.n)) return LF_ERR_ARG;
+    for (int t = 0; t < batch; ++t) {
+        if (int e = lf_fmt_expect(a + t * a_stride, ((size_t)rows << logN) * 8, mpl ? LF_FMT_PLANES : LF_FMT_RAW)) return e;
+        if (int e = lf_fmt_expect(b + t * b_stride, ((size_t)rows << logN) * 8, mpl ? LF_FMT_PLANES : LF_FMT_RAW)) return e;
+    }
     const PassGeom g0{logN, tl, 0, tl, 0, 0, rows, batch, 1, 0, plain};
     launch_pass16(true, 1, batch, st, (const i64 *)a, (i64 *)scratch, g0, in, dp, (const i64 *)ipsi_br, ipsi_dp, (const i64 *)ql,
-                  (const i64 *)qh, (const i64 *)kl, (const i64 *)kh, &ms);
+                  (const i64 *)qh, (const i64 *)kl, (const i64 *)kh, &ms, mpl);
     const PassGeom g1{logN, tl, 1, S1, tl, tl - S1, rows, batch, 1, 1, plain};
     const dim3 grid((unsigned)nparts * ((1u << (logN - S1)) / NTT_COL_THREADS), (unsigned)batch), block(NTT_COL_THREADS);
     const int amax = max_alpha <= 1 ? 1 : max_alpha <= 2 ? 2 : max_alpha <= 4 ? 4 : 8;

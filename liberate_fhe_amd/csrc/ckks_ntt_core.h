@@ -72,7 +72,14 @@ struct PassGeom {
     // a digit is made of need no extension and no transform (the caller has them in the NTT domain already): their blocks exit
     const unsigned char *skip_own;   // device, [rows]: digit that owns the limb (255: none); nullptr: nothing is skipped
     int skip_mod, skip_off;
+    // relaxed column passes of the fused ops: fp64-class rows of the stack are PLANES (u32 low[N] at byte 0 of the row's 8 N bytes,
+    // u16 high[N] at byte 4 N: canonical residues, 6 bytes per word) on the way in (bit 0) / on the way out (bit 1).  A pass
+    // that changes the format cannot run in place (a raw word covers the low plane of two others).
+    int pln;
+    const i64 *pln_src;   // inverse column pass with PLN_IN: the stack it reads (same geometry as the one it writes); nullptr: in place
 };
+#define PLN_IN 1
+#define PLN_OUT 2
 
 // tile-local index -> coefficient index of the row
 __device__ __forceinline__ int tile_gaddr(const PassGeom &g, int tile, int L) {
@@ -1212,6 +1219,19 @@ __device__ __forceinline__ void fwd_cols_body(int b, i64 *__restrict__ a, const 
             x[k] = v;
         }
         cols_fwd_stages<ArithDpR, K>(x, c);
+        if (g.pln & PLN_OUT) {   // cc_mult's operand stack: canonical words as two planes (the tiled pass behind: fwd_tile16<.., PLN>)
+            i64 *rowb = a + ((i64)(poly * g.rows + crow) << g.logN);
+            const i64 col0 = (i64)chunk * NTT_COL_THREADS;
+            unsigned *lo = reinterpret_cast<unsigned *>(rowb) + col0;
+            unsigned short *hi = reinterpret_cast<unsigned short *>(rowb + ((i64)1 << (g.logN - 1))) + col0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const i64 o = dp_to_word(dp_reduce(x[k], c.d.q, c.d.qinv));
+                __builtin_nontemporal_store((unsigned)o, uniform_ptr(lo + ((i64)k << logC)) + lane);
+                __builtin_nontemporal_store((unsigned short)((u64)o >> 32), uniform_ptr(hi + ((i64)k << logC)) + lane);
+            }
+            return;
+        }
         COLS_ST_ALL(uniform_row(colu, (i64)k << logC) + lane, dp_to_word(dp_reduce(x[k], c.d.q, c.d.qinv)))
         return;
     }
@@ -1626,6 +1646,17 @@ __device__ __forceinline__ void inv_cols_compute(int poly, int crow, int chunk, 
             for (int k = 0; k < R; ++k)
                 if (((fw[k >> 3] >> (8 * (k & 7))) & 0xffull) != 0) w[k] |= (i64)((u64)top[((i64)k << logC) + lane] << 48);
         }
+    } else if (!WS && DP && (g.pln & PLN_IN)) {   // relaxed stacks of the fused ops: canonical words as two planes
+        const i64 *rowb = a + ((i64)(poly * g.rows + crow) << g.logN);
+        const i64 col0 = (i64)chunk * NTT_COL_THREADS;
+        const unsigned *lo = reinterpret_cast<const unsigned *>(rowb) + col0;
+        const unsigned short *hi = reinterpret_cast<const unsigned short *>(rowb + ((i64)1 << (g.logN - 1))) + col0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const unsigned l = __builtin_nontemporal_load(uniform_ptr(lo + ((i64)k << logC)) + lane);
+            const unsigned m = __builtin_nontemporal_load(uniform_ptr(hi + ((i64)k << logC)) + lane);
+            w[k] = (i64)(((u64)m << 32) | (u64)l);
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < R; ++k) w[k] = INV_LD(uniform_row(colu, (i64)k << logC) + lane);
@@ -1693,7 +1724,7 @@ __device__ __forceinline__ void inv_cols_body(int b, i64 *__restrict__ a, const 
     // (the integer divisions run on the VALU: pin their wave-uniform results back into SGPRs)
     const int poly = __builtin_amdgcn_readfirstlane(r % g.batch), crow = __builtin_amdgcn_readfirstlane((int)rl.id[r / g.batch]);
     i64 out[R];
-    inv_cols_compute<DP, K>(poly, crow, chunk, a, g, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh, out);
+    inv_cols_compute<DP, K>(poly, crow, chunk, g.pln_src ? g.pln_src : a, g, ipsi_br, ipsi_dp, Ninv, tail, ql, qh, kl, kh, out);
     i64 *colu = a + ((i64)(poly * g.rows + crow) << g.logN) + chunk * NTT_COL_THREADS;
     const unsigned lane = threadIdx.x;
 #pragma unroll

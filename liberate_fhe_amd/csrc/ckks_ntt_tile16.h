@@ -559,15 +559,54 @@ __device__ __forceinline__ bool inv_tile16_steps(typename A::T *smt, const i64 *
 // MUL (relaxed only): the tile is the element-wise product src_row * mul_row, formed as the words come in — cc_mult's
 // x1 * y1 never exists in HBM.  fp64 class: plain canonical residues in, canonical product (held as doubles from here
 // on); integer class: Montgomery-form words below 2q in, the lazy REDC62 product.
-template <bool DP, bool RLX, bool MUL = false>
+// PLN (fp64 class, relaxed: the sums of a key switch between the inner product and the two inverse passes; cc_mult's operand stack
+// as the product-on-load pass reads it): source AND destination rows hold canonical words as planes (fwd_tile16).  A wave's
+// 1024-word span arrives as 4 x 16 bytes of the low plane + 4 x 8 bytes of the high plane per lane (words 4 lane .. + 3 of every
+// 256), assembled to words on the way into the LDS span; the results leave as one 4-byte and one 2-byte store per word.
+template <bool DP, bool RLX, bool MUL = false, int PLN = 0>   // PLN: PLN_IN | PLN_OUT
 __device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst_row, int tile, const PassGeom &g, const Ctx &c,
                                            const i64 *mul_row = nullptr) {
     static_assert(!MUL || RLX, "product-on-load exists for the relaxed inverse transform only");
+    static_assert(!PLN || (DP && RLX), "planes: relaxed fp64-class rows only");
     const int w = lf_tid();
     const int base = tile << 12, logN = g.logN, s = g.s0;
     constexpr bool CHECK = !RLX;   // relaxed inverse transforms take lazy words in [0, 2q) (include/ckks_hip.h)
     const int L0 = ((w >> 6) << 10) + ((w & 63) << 1);
-    {
+    if constexpr ((PLN & PLN_IN) != 0) {
+        const int L4 = ((w >> 6) << 10) + ((w & 63) << 2);
+        const unsigned *lo = reinterpret_cast<const unsigned *>(src_row) + base + L4;
+        const unsigned *hi = reinterpret_cast<const unsigned *>(src_row + ((i64)1 << (logN - 1))) + ((base + L4) >> 1);
+        lf_u4_t l[4], lb[4];
+        lf_u2_t h[4], hb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            l[i] = __builtin_nontemporal_load(reinterpret_cast<const lf_u4_t *>(lo + (i << 8)));
+            h[i] = __builtin_nontemporal_load(reinterpret_cast<const lf_u2_t *>(hi + (i << 7)));
+        }
+        if (MUL) {
+            const unsigned *mlo = reinterpret_cast<const unsigned *>(mul_row) + base + L4;
+            const unsigned *mhi = reinterpret_cast<const unsigned *>(mul_row + ((i64)1 << (logN - 1))) + ((base + L4) >> 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lb[i] = __builtin_nontemporal_load(reinterpret_cast<const lf_u4_t *>(mlo + (i << 8)));
+                hb[i] = __builtin_nontemporal_load(reinterpret_cast<const lf_u2_t *>(mhi + (i << 7)));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            i64 *sp = sm + PAD16(L4 + (i << 8));                  // 4-aligned + m < 4: no padding step inside the quad
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const unsigned hm = (h[i][m >> 1] >> (16 * (m & 1))) & 0xffffu;
+                if (MUL) {
+                    const unsigned hbm = (hb[i][m >> 1] >> (16 * (m & 1))) & 0xffffu;
+                    sp[m] = __double_as_longlong(dp_mulmod(dp_from_planes(l[i][m], hm), dp_from_planes(lb[i][m], hbm), c.d));
+                } else {
+                    sp[m] = (i64)(((u64)hm << 32) | (u64)l[i][m]);
+                }
+            }
+        }
+    } else {
         longlong2 in[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) in[i] = INV_LD2(src_row + base + L0 + (i << 7));
@@ -613,7 +652,16 @@ __device__ __forceinline__ void inv_tile16(i64 *sm, const i64 *src_row, i64 *dst
 #pragma unroll
         for (int e = 0; e < 16; ++e) x[e] = MUL ? __longlong_as_double(raw[e]) : dp_from_word(raw[e]);
         ok = inv_tile16_steps<AD, true, RLX>(reinterpret_cast<double *>(sm), sm, x, w, base, logN, s, cc, CHECK);
-        if (ok) {   // exact: the lazy word in [0, 2q); relaxed: balanced residue -> canonical
+        if constexpr ((PLN & PLN_OUT) != 0) {   // (relaxed: ok is always true)
+            unsigned *olo = reinterpret_cast<unsigned *>(dst_row) + base;
+            unsigned short *ohi = reinterpret_cast<unsigned short *>(dst_row + ((i64)1 << (logN - 1))) + base;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const i64 o = dp_to_word(dp_addmask(x[e], c.d.q));
+                uniform_ptr(olo + (e << 8))[(unsigned)w] = (unsigned)o;
+                uniform_ptr(ohi + (e << 8))[(unsigned)w] = (unsigned short)((u64)o >> 32);
+            }
+        } else if (ok) {   // exact: the lazy word in [0, 2q); relaxed: balanced residue -> canonical
 #pragma unroll
             for (int e = 0; e < 16; ++e) INV_ST(uniform_row(out, e << 8) + (unsigned)w, dp_to_word(RLX ? dp_addmask(x[e], c.d.q) : x[e]));
         }
@@ -755,7 +803,7 @@ struct MulSrc {
     i64 a_stride, b_stride;
 };
 
-template <bool DP, bool RLX, bool INV, bool MUL = false, bool PLN = false>
+template <bool DP, bool RLX, bool INV, bool MUL = false, int PLN = 0>   // PLN: forward: planes in place; inverse: PLN_IN | PLN_OUT
 __device__ __forceinline__ void pass16_body(i64 *sm, int b, const i64 *src, i64 *dst, const PassGeom &g, const RowList &rl,
                                             const i64 *__restrict__ tw_br, const double *__restrict__ tw_dp,
                                             const i64 *__restrict__ ql, const i64 *__restrict__ qh,
@@ -776,12 +824,12 @@ __device__ __forceinline__ void pass16_body(i64 *sm, int b, const i64 *src, i64 
     const i64 off = (i64)(poly * g.rows + crow) << g.logN;
     if constexpr (INV && MUL) {
         const i64 roff = (i64)crow << g.logN;
-        inv_tile16<DP, RLX, true>(sm, src + (i64)poly * ms->a_stride + roff, dst + off, tile, g, c,
-                                  ms->b + (i64)poly * ms->b_stride + roff);
+        inv_tile16<DP, RLX, true, PLN>(sm, src + (i64)poly * ms->a_stride + roff, dst + off, tile, g, c,
+                                       ms->b + (i64)poly * ms->b_stride + roff);
     } else if constexpr (INV) {
-        inv_tile16<DP, RLX>(sm, src + off, dst + off, tile, g, c);
+        inv_tile16<DP, RLX, false, PLN>(sm, src + off, dst + off, tile, g, c);
     } else {
-        fwd_tile16<DP, RLX, PLN>(sm, dst + off, tile, g, c);
+        fwd_tile16<DP, RLX, PLN != 0>(sm, dst + off, tile, g, c);
     }
 }
 
@@ -811,7 +859,38 @@ __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_fwd_planes(i64 *d
     if (b < cl.in_blocks) {
         if (b < cl.in_real) pass16_body<false, true, false>(sm, b, dst, dst, g, cl.in, tw_br, tw_dp, ql, qh, kl, kh);
     } else {
-        pass16_body<true, true, false, false, true>(sm, b - cl.in_blocks, dst, dst, g, cl.dp, tw_br, tw_dp, ql, qh, kl, kh);
+        pass16_body<true, true, false, false, PLN_IN | PLN_OUT>(sm, b - cl.in_blocks, dst, dst, g, cl.dp, tw_br, tw_dp, ql, qh, kl, kh);
+    }
+}
+
+// relaxed inverse pass whose fp64-class rows are planes on both sides (inv_tile16<.., PLN>): the sums of a key switch, src -> dst
+__global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_inv_planes(const i64 *src, i64 *dst, PassGeom g, ClassLists cl,
+                                                                            const i64 *__restrict__ tw_br,
+                                                                            const double *__restrict__ tw_dp,
+                                                                            const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                            const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT16_LDS_WORDS + 1];
+    const int b = blockIdx.x;
+    if (b < cl.in_blocks) {
+        if (b < cl.in_real) pass16_body<false, true, true>(sm, b, src, dst, g, cl.in, tw_br, tw_dp, ql, qh, kl, kh);
+    } else {
+        pass16_body<true, true, true, false, PLN_IN | PLN_OUT>(sm, b - cl.in_blocks, src, dst, g, cl.dp, tw_br, tw_dp, ql, qh, kl, kh);
+    }
+}
+
+// relaxed inverse pass of a product whose factors' fp64-class rows are planes (cc_mult's operand stack); the product leaves as raw
+// words (the column pass behind runs in place, and a pass that changes the format cannot)
+__global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_mul_planes(const i64 *src, i64 *dst, PassGeom g, ClassLists cl, MulSrc ms,
+                                                                            const i64 *__restrict__ tw_br,
+                                                                            const double *__restrict__ tw_dp,
+                                                                            const i64 *__restrict__ ql, const i64 *__restrict__ qh,
+                                                                            const i64 *__restrict__ kl, const i64 *__restrict__ kh) {
+    __shared__ i64 sm[NTT16_LDS_WORDS + 1];
+    const int b = blockIdx.x;
+    if (b < cl.in_blocks) {
+        if (b < cl.in_real) pass16_body<false, true, true, true>(sm, b, src, dst, g, cl.in, tw_br, tw_dp, ql, qh, kl, kh, &ms);
+    } else {
+        pass16_body<true, true, true, true, PLN_IN>(sm, b - cl.in_blocks, src, dst, g, cl.dp, tw_br, tw_dp, ql, qh, kl, kh, &ms);
     }
 }
 
@@ -1045,7 +1124,11 @@ inline void launch_pass16(bool inverse, int relaxed, int polys, hipStream_t st, 
     }
     const ClassLists cl = class_lists(in, dp, per_row * (unsigned)in.n);
     const dim3 grid((unsigned)cl.in_blocks + per_row * (unsigned)dp.n), block(NTT16_THREADS);
-    if (planes) {   // forward, relaxed, both classes present (ks_forward: digit_planes())
+    if (planes && ms) {   // relaxed, both classes present (the caller's condition: lf_stack_planes())
+        hipLaunchKernelGGL(ntt_pass16_mul_planes, grid, block, 0, st, src, dst, g, cl, *ms, tw_br, tw_dp, ql, qh, kl, kh);
+    } else if (planes && inverse) {
+        hipLaunchKernelGGL(ntt_pass16_inv_planes, grid, block, 0, st, src, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
+    } else if (planes) {   // forward, in place
         hipLaunchKernelGGL(ntt_pass16_fwd_planes, grid, block, 0, st, dst, g, cl, tw_br, tw_dp, ql, qh, kl, kh);
     } else if (ms) {
         hipLaunchKernelGGL(ntt_pass16_mul_mixed, grid, block, 0, st, src, dst, g, cl, *ms, tw_br, tw_dp, ql, qh, kl, kh);

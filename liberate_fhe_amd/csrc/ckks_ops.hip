@@ -21,6 +21,10 @@ static int plan_ok(const lf_ks_plan *p) {
            p->state && p->ext && p->sum && p->md_ws;
 }
 
+// cc_mult's operand stack x4 in planes format (include/ckks_hip.h LF_NTT_PLANES): decided per call from lf_tune's knob; the pieces
+// of a sharded op are separate calls, and a stack written under one setting is refused by a reader under the other (LF_ERR_STATE)
+static int stack_planes(const lf_ks_plan *p) { return lf_stack_planes(p->logN, p->ell, p->q_host); }
+
 static int batch_ok(const lf_ks_plan *p, int nct) {
     return plan_ok(p) && (nct == 1 || nct == 2 || nct == 4) && nct <= p->max_nct;
 }
@@ -44,7 +48,7 @@ static int moddown_any(const lf_ks_plan *p, const int64_t *const *ss, int64_t *c
 static int product_digits(const lf_ks_plan *p, int nct, void *stream) {
     const int ell = p->ell, logN = p->logN, dev = p->device;
     const int64_t N = (int64_t)1 << logN, poly = (int64_t)ell * N;
-    const int relaxed_plain = LF_NTT_RELAXED | LF_NTT_PLAIN;
+    const int relaxed_plain = LF_NTT_RELAXED | LF_NTT_PLAIN | (stack_planes(p) ? LF_NTT_PLANES : 0);
     const int64_t xs = nct > 1 ? 4 * poly : poly;   // stride between the operand stacks of a batch
     const int e = !lf_g_intt_digits ? LF_ERR_ARG : lf_intt_mul_digits(p->d2, p->x4 + poly, xs, p->x4 + 3 * poly, xs, nct, ell, logN, p->state, p->dig_nparts, p->K, p->dig_desc,
                                      p->dig_tab, p->ipsi, p->ipsi_dp, p->q_host, p->Ninv, relaxed_plain, p->ql, p->qh, p->kl, p->kh, dev, stream);
@@ -66,7 +70,8 @@ int lf_cc_mult_evk(const lf_ks_plan *p, const int64_t *const *in, const int64_t 
     if (!plan_ok(p) || !p->rescale_scales || !p->PR || !p->x4 || !p->d2 || !in || !row0 || !ksk || !out0 || !out1) return LF_ERR_ARG;
     const int ell = p->ell, rows = p->ell + p->K, logN = p->logN, dev = p->device;
     const int64_t N = (int64_t)1 << logN, poly = (int64_t)ell * N;
-    const int relaxed_plain = LF_NTT_RELAXED | LF_NTT_PLAIN;
+    const int xpl = stack_planes(p);
+    const int relaxed_plain = LF_NTT_RELAXED | LF_NTT_PLAIN | (xpl ? LF_NTT_PLANES : 0);
     // x0, x1, y0, y1: both rescales inside the first pass of one batched forward transform (ckks_engine.py:1085-1093)
     if (int e = lf_rescale_ntt(in, row0, 4, p->x4, ell, logN, p->rescale_scales, p->round_at, p->psi, p->psi_dp, p->q_host, p->Rs,
                                relaxed_plain, p->_2q, p->ql, p->qh, p->kl, p->kh, dev, stream))
@@ -75,7 +80,7 @@ int lf_cc_mult_evk(const lf_ks_plan *p, const int64_t *const *in, const int64_t 
     if (int e = product_digits(p, 1, stream)) return e;
     // key switch of d2 with d0, d1 folded into its sums (654-961, 1117-1151)
     if (int e = lf_relin_core_batch(p->state, 0, 1, p->nparts, rows, logN, p->ext_desc, p->E, p->Ed, ksk, part_stride, comp_stride,
-                                    row_off, key_format, p->ext, p->sum, p->psi, p->psi_dp, p->ipsi, p->ipsi_dp, p->Ninv, p->x4, 0, p->PR, ell,
+                                    row_off, key_format | (xpl ? LF_STACK_PLANES : 0), p->ext, p->sum, p->psi, p->psi_dp, p->ipsi, p->ipsi_dp, p->Ninv, p->x4, 0, p->PR, ell,
                                     p->own, p->q_host, p->ql, p->qh, p->kl, p->kh, dev, stream))
         return e;
     const int64_t *ss[2] = {p->sum, p->sum + (int64_t)rows * N};
@@ -137,7 +142,8 @@ int lf_cc_mult_evk_batch(const lf_ks_plan *p, int nct, const int64_t *const *in,
     if (!batch_ok(p, nct) || !p->rescale_scales || !p->PR || !p->x4 || !p->d2 || !in || !row0 || !ksk || !out0 || !out1) return LF_ERR_ARG;
     const int ell = p->ell, rows = p->ell + p->K, logN = p->logN, dev = p->device;
     const int64_t N = (int64_t)1 << logN, poly = (int64_t)ell * N;
-    const int relaxed_plain = LF_NTT_RELAXED | LF_NTT_PLAIN;
+    const int xpl = stack_planes(p);
+    const int relaxed_plain = LF_NTT_RELAXED | LF_NTT_PLAIN | (xpl ? LF_NTT_PLANES : 0);
     for (int t0 = 0; t0 < nct; t0 += 2) {   // rescale + forward transform of the operands, two pairs (8 polynomials) per launch
         const int n = nct - t0 < 2 ? nct - t0 : 2;
         if (int e = lf_rescale_ntt(in + 4 * t0, row0 + 4 * t0, 4 * n, p->x4 + (int64_t)t0 * 4 * poly, ell, logN, p->rescale_scales,
@@ -148,7 +154,7 @@ int lf_cc_mult_evk_batch(const lf_ks_plan *p, int nct, const int64_t *const *in,
     // the nct products x1 * y1 through one inverse transform (product on load), their digits
     if (int e = product_digits(p, nct, stream)) return e;
     if (int e = lf_relin_core_batch(p->state, poly, nct, p->nparts, rows, logN, p->ext_desc, p->E, p->Ed, ksk, part_stride, comp_stride,
-                                    row_off, key_format, p->ext, p->sum, p->psi, p->psi_dp, p->ipsi, p->ipsi_dp, p->Ninv, p->x4, 4 * poly,
+                                    row_off, key_format | (xpl ? LF_STACK_PLANES : 0), p->ext, p->sum, p->psi, p->psi_dp, p->ipsi, p->ipsi_dp, p->Ninv, p->x4, 4 * poly,
                                     p->PR, ell, p->own, p->q_host, p->ql, p->qh, p->kl, p->kh, dev, stream))
         return e;
     const int64_t *ss[8];
@@ -172,7 +178,7 @@ int lf_cc_mult_evk_pre(const lf_ks_plan *p, const int64_t *const *in, const int6
         return LF_ERR_ARG;
     const int ell = p->ell, logN = p->logN, dev = p->device;
     const int64_t N = (int64_t)1 << logN, poly = (int64_t)ell * N;
-    const int relaxed_plain = LF_NTT_RELAXED | LF_NTT_PLAIN;
+    const int relaxed_plain = LF_NTT_RELAXED | LF_NTT_PLAIN | (stack_planes(p) ? LF_NTT_PLANES : 0);
     // which = 3: everything.  1: only the launch that reads the operands (rescale + column pass) — the one launch of this half
     // whose addresses change from call to call; 2: the rest (fixed addresses of the plan: a caller may replay it from a graph)
     const int64_t *const none[8] = {};   // (lf_rescale_ntt takes up to 8 polynomials; unused by the tiled pass)
@@ -213,7 +219,8 @@ int lf_cc_mult_evk_post(const lf_ks_plan *p, const int64_t *ksk, int64_t part_st
     const int64_t N = (int64_t)1 << p->logN;
     // which: 1 = inner product + inverse NTT (fixed addresses: plan scratch and the key), 2 = the mod-down that writes out0 / out1
     if (which & 1)
-        if (int e = lf_relin_tail(p->nparts, rows, p->logN, ksk, part_stride, comp_stride, row_off, key_format, p->ext, p->sum, p->ipsi,
+        if (int e = lf_relin_tail(p->nparts, rows, p->logN, ksk, part_stride, comp_stride, row_off,
+                                  key_format | (stack_planes(p) ? LF_STACK_PLANES : 0), p->ext, p->sum, p->ipsi,
                                   p->ipsi_dp, p->Ninv, p->x4, p->PR, p->ell, p->own, p->q_host, p->ql, p->qh, p->kl, p->kh, p->device, stream))
             return e;
     if (!(which & 2)) return 0;

@@ -20,7 +20,7 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(so, n), f"{n} declared in include/ckks_hip.h but not exported"
     assert sorted(_native.EXPORTED) == names, "python binding table out of sync with the header"
-    assert _native.lib.lf_abi_version() == 14     # pure host call, no HIP runtime use
+    assert _native.lib.lf_abi_version() == 15     # pure host call, no HIP runtime use
 
 
 def test_python_binding_passes_as_many_arguments_as_the_header_declares():
@@ -228,7 +228,7 @@ def test_hot_kernels_use_no_scratch_memory_and_the_tracked_table_is_current():
         if k.startswith("ntt_pass16"):
             assert all(r["occupancy"] >= 4 and r["lds"] <= 40960 for r in by[k]), (k, by[k])
     assert all(r["occupancy"] >= 3 for r in by["ntt_fwd_cols_ws<5>"])
-    assert all(r["occupancy"] >= 5 for r in by["ks_inner2_kernel<4, true, true, true>"])
+    assert all(r["occupancy"] >= 4 for r in by["ks_inner2_kernel<4, true, true, true>"])
     # the only kernels with scratch at all are the 8-words tiled passes (logN <= 12 / in-place logN 17), capped at 80 VGPRs for 6 waves
     allowed = re.compile(r"^(ntt_fwd_pass<|ntt_inv_pass_io<|ntt_inv_pass_mixed<)")
     other = sorted({r["kernel"] for r in rows if r["scratch"] and not allowed.match(r["kernel"])})

@@ -365,6 +365,136 @@ def test_ks_fwd_groups_plus_tail_equal_ks_core(name, splits):
 
 
 @pytest.mark.gpu
+def test_a_knob_flipped_between_the_halves_of_an_op_is_refused_not_misread():
+    """lf_tune is process-wide; the halves of an op may be separate native calls whose scratch format follows a knob: the extended
+    digits between lf_ks_fwd and lf_ks_tail (LF_TUNE_DIGIT_PLANES), cc_mult's operand stack between lf_cc_mult_evk_pre(which = 1),
+    its (which = 2) and lf_cc_mult_evk_post (LF_TUNE_MORE_PLANES bit 1), the workspace between lf_ntt_pass_ws 1 and 2
+    (LF_TUNE_WS_EXTRA_STAGE).  The producer notes the format it wrote, the consumer gets LF_ERR_STATE (10002) — nothing launched, the
+    result buffer untouched — when it would read another one; with the knob back, or the first half repeated, the op completes
+    with the undivided call's words."""
+    import ctypes
+    from liberate_fhe_amd._native import lib, HipError, LF_ERR_STATE
+    from liberate_fhe_amd.fhe import ckks_engine
+    eng = ckks_engine(devices=["cuda:0"], **GOLD["silver"]["params"])
+    level, d = 0, 0
+    a, b = synth.ciphertext(eng, 7, level), synth.ciphertext(eng, 9, level)
+    key = synth.key_switch_key(eng, 8)
+    tabs = eng._ks_tables(level)
+    N, logN = eng.ctx.N, eng.ctx.logN
+    rows, ell = eng._rows(d, level, True), eng._rows(d, level, False)
+    nparts = len(tabs["order"])
+    st = torch.empty((ell, N), dtype=torch.int64, device="cuda:0")
+    n_d, desc_d, tab_d = tabs[("digits", d)]
+    eng.backend.ks_digits(a.data[1][0], st, n_d, desc_d, tab_d, eng._consts(d, level, False))
+    desc, E, Ed = tabs[("extend", d)]
+    cs = eng._consts(d, level, True)
+    kp = eng._key_pack(key)[0]
+    tw, itw, ninv = eng._tw(d, level, True), eng._tw(d, level, True, True), eng._vec("Ninv", d, level, True)
+    ext1, ext2 = (torch.zeros((nparts, rows, N), dtype=torch.int64, device="cuda:0") for _ in range(2))
+    s1 = torch.zeros((2, rows, N), dtype=torch.int64, device="cuda:0")
+    s2 = torch.full((2, rows, N), -7, dtype=torch.int64, device="cuda:0")
+    eng.backend.ks_core(st, nparts, rows, logN, desc, E, Ed, kp, tabs["first_part"], eng.ntt.starts[level][d], ext1, s1, tw, itw, ninv, cs)
+    tail = lambda: eng.backend.ks_tail(nparts, rows, logN, kp, tabs["first_part"], eng.ntt.starts[level][d], ext2, s2, itw, ninv, cs)
+    assert lib.lf_tune(3, -1) == 1
+    try:
+        # 1. digits written as planes, the tail asked to read raw words
+        eng.backend.ks_fwd(st, 0, nparts, rows, logN, desc, E, Ed, ext2, tw, cs)
+        lib.lf_tune(3, 0)
+        with pytest.raises(HipError, match="LF_ERR_STATE"):
+            tail()
+        torch.cuda.synchronize()
+        assert bool((s2 == -7).all()), "the refused half launched something"
+        lib.lf_tune(3, 1)
+        tail()                                           # knob back: the digits are still good
+        assert torch.equal(s1, s2)
+        # 2. the other way round, and only PART of the digits rewritten under the new setting
+        lib.lf_tune(3, 0)
+        eng.backend.ks_fwd(st, 0, nparts, rows, logN, desc, E, Ed, ext2, tw, cs)
+        lib.lf_tune(3, 1)
+        eng.backend.ks_fwd(st, 0, 2, rows, logN, desc, E, Ed, ext2, tw, cs)
+        s2.fill_(-7)
+        with pytest.raises(HipError, match="LF_ERR_STATE"):
+            tail()
+        eng.backend.ks_fwd(st, 2, nparts - 2, rows, logN, desc, E, Ed, ext2, tw, cs)     # the rest as well: consistent again
+        tail()
+        assert torch.equal(s1, s2)
+    finally:
+        lib.lf_tune(3, 1)
+    # 3. cc_mult in the pieces a sharded rank issues (lf_cc_mult_evk_pre which = 1 | 2, lf_ks_plan_fwd, lf_cc_mult_evk_post): the
+    #    operand stack is written by pre(1), transformed by pre(2), read by post
+    from liberate_fhe_amd.fhe.backend import _ds
+    be = eng.backend
+    want = eng.cc_mult(a, b, key)
+    plan, _, first_part, row_off = eng._op_plan(1, d)
+    polys = [a.data[0][0], a.data[1][0], b.data[0][0], b.data[1][0]]
+    rbuf = torch.stack([t[0] for t in polys]).contiguous()                       # the dropped limb's rows
+    ins = (ctypes.c_void_p * 4)(*[t.data_ptr() + N * 8 for t in polys])          # the surviving rows start behind it
+    row0s = (ctypes.c_void_p * 4)(*[rbuf[k].data_ptr() for k in range(4)])
+    stream = _ds(polys[0])[1]
+    state = eng._ws("ks_state", (plan.ell, N), d)
+    out = torch.full((2, plan.ell, N), -7, dtype=torch.int64, device="cuda:0")
+    assert lib.lf_tune(5, -1) == 3 and lib.lf_stack_planes(logN, plan.ell, plan.q_host) == 1
+    try:
+        be.cc_mult_pre(plan, ins, row0s, stream, which=1)                        # the stack leaves as planes
+        lib.lf_tune(5, 1)                                                        # .. and is now wanted as raw words
+        assert lib.lf_stack_planes(logN, plan.ell, plan.q_host) == 0
+        with pytest.raises(HipError, match="LF_ERR_STATE"):
+            be.cc_mult_pre(plan, None, None, stream, which=2)
+        lib.lf_tune(5, 3)
+        be.cc_mult_pre(plan, None, None, stream, which=2)
+        be.plan_fwd(plan, state, 0, plan.nparts, True)
+        lib.lf_tune(5, 1)
+        with pytest.raises(HipError, match="LF_ERR_STATE"):
+            be.cc_mult_post(plan, kp, first_part, row_off, out)
+        torch.cuda.synchronize()
+        assert bool((out == -7).all()), "the refused half launched something"
+        lib.lf_tune(5, 3)
+        be.cc_mult_post(plan, kp, first_part, row_off, out)
+        assert torch.equal(out[0], want.data[0][0]) and torch.equal(out[1], want.data[1][0])
+        # the whole op again with raw stacks (knob 5 = 1: sums as planes, stack raw): same words
+        lib.lf_tune(5, 1)
+        again = eng.cc_mult(a, b, key)
+        assert torch.equal(again.data[0][0], want.data[0][0]) and torch.equal(again.data[1][0], want.data[1][0])
+    finally:
+        lib.lf_tune(5, 3)
+
+
+@pytest.mark.gpu
+def test_the_split_of_a_workspace_transform_cannot_change_between_its_two_launches():
+    """lf_ntt_pass_ws(1) under LF_TUNE_WS_EXTRA_STAGE = 1 leaves 5 + 11 stages' worth in the workspace; the tiled pass launched
+    under 0 would run 12: LF_ERR_STATE, the tensor untouched."""
+    from liberate_fhe_amd._native import lib, LF_ERR_STATE
+    from liberate_fhe_amd.fhe.context.ckks_context import ckks_context
+    from liberate_fhe_amd.ntt import ntt_context, twiddles
+    ctx = ckks_context(logN=14, num_scales=4, num_special_primes=1, is_secured=False)
+    ntt = ntt_context(ctx, devices=["cuda:0"])
+    L, N = len(ctx.q), ctx.N
+    x = torch.from_numpy(synth.uniform_rows(5, range(L), ctx.q, N, lazy=True)).cuda()
+    keep = x.clone()
+    psi, ql, qh, kl, kh, q2 = (t[0] for t in (ntt.psi, ntt.ql, ntt.qh, ntt.kl, ntt.kh, ntt._2q))
+    st = torch.cuda.current_stream().cuda_stream
+    dp = twiddles.dp_pointer(psi, ql, qh, kl, kh, 0, st)
+    q = np.array(ctx.q, dtype=np.int64)
+    ws = torch.empty((int(lib.lf_ntt_ws_words(1, L, 14)),), dtype=torch.int64, device="cuda")
+    one = lambda which: lib.lf_ntt_pass_ws(x.data_ptr(), ws.data_ptr(), 1, L, 14, psi.data_ptr(), dp, q.ctypes.data, 0, 0, which,
+                                          ql.data_ptr(), qh.data_ptr(), kl.data_ptr(), kh.data_ptr(), 0, st)
+    try:
+        assert one(1) == 0
+        lib.lf_tune(4, 0)
+        assert one(2) == LF_ERR_STATE
+        torch.cuda.synchronize()
+        assert torch.equal(x, keep)
+        lib.lf_tune(4, 1)
+        assert one(2) == 0
+        ref = keep.clone()
+        assert lib.lf_ntt(ref.data_ptr(), 1, L, 14, psi.data_ptr(), dp, q.ctypes.data, 0, 0, q2.data_ptr(), ql.data_ptr(), qh.data_ptr(),
+                          kl.data_ptr(), kh.data_ptr(), 0, st) == 0
+        assert torch.equal(x, ref)
+    finally:
+        lib.lf_tune(4, 1)
+
+
+@pytest.mark.gpu
 def test_c3_silver_cc_mult_decode_within_2_pow_minus_30_of_the_checker():
     """BASELINE configs[2] / SURVEY §8(d) C3: silver cc_mult + relinearize with REAL keys and ciphertexts (HIP samplers)
     on the HIP engine and, on the very same tensors, on the checker engine (reference composition over the C oracle):
@@ -616,9 +746,12 @@ def test_extended_digits_in_planes_format_equal_raw_words(params):
     evk, rotk = synth.key_switch_key(eng, 5), synth.key_switch_key(eng, 6, origin="rotation key:3")
     outs = []
     try:
-        for planes, cols_max in ((1, 5), (0, 5), (1, 0), (0, 0), (1, 5)):   # cols_max 0: the LDS-tiled extension writes the planes
+        # (more: LF_TUNE_MORE_PLANES — bit 0 the sums between inner product, tiled inverse pass and column pass, bit 1 cc_mult's
+        # operand stack between the rescale-NTT, the product pass and the inner product's fold — 6-byte words there as well)
+        for planes, cols_max, more in ((1, 5, 3), (0, 5, 3), (1, 0, 3), (0, 0, 0), (1, 5, 0), (1, 5, 1), (1, 5, 2), (1, 0, 1), (1, 5, 3)):
             assert lib.lf_tune(3, planes) in (0, 1)
             lib.lf_tune(1, cols_max)
+            assert lib.lf_tune(5, more) in (0, 1, 2, 3)
             res = []
             for level in (0, 2):
                 a, b = synth.ciphertext(eng, 50 + level, level), synth.ciphertext(eng, 60 + level, level)
@@ -628,7 +761,8 @@ def test_extended_digits_in_planes_format_equal_raw_words(params):
     finally:
         lib.lf_tune(3, 1)
         lib.lf_tune(1, 5)
-    assert outs[0] == outs[1] == outs[2] == outs[3] == outs[4]
+        lib.lf_tune(5, 3)
+    assert all(o == outs[0] for o in outs)
     assert lib.lf_tune(3, -1) == 1 and lib.lf_tune(3, 2) == 1 and lib.lf_tune(3, -1) == 1      # query; out of range: unchanged
 
 
