@@ -43,7 +43,7 @@ from .version import VERSION
 class ckks_engine(EvaluatorOps):
     @errors.log_error
     def __init__(self, devices: list[int] = None, verbose: bool = False, bias_guard: bool = True,
-                 norm: str = "forward", backend=None, comm=None, **ctx_params):
+                 norm: str = "forward", backend=None, comm=None, balanced_limb_map: bool = False, **ctx_params):
         if backend is None:
             from .backend import HipBackend  # raises if libckks_hip.so is missing: no fallback
             backend = HipBackend()
@@ -70,7 +70,9 @@ class ckks_engine(EvaluatorOps):
             logical, local_ids = [local] * comm.world_size, [comm.rank]
         else:
             logical, local_ids = devices, None
-        self.ntt = ntt_context(self.ctx, devices=logical, verbose=verbose, ops=backend.ops, local_ids=local_ids)
+        # balanced_limb_map (default off: the reference's layout): rns_partition(balance=True) — rank 0 of a limb-sharded gold
+        # engine over 8 GPUs holds 5 rows instead of 7 (the largest share 6 instead of 7): same digits, same words per limb
+        self.ntt = ntt_context(self.ctx, devices=logical, verbose=verbose, ops=backend.ops, local_ids=local_ids, balance=balanced_limb_map)
         self.local_ids = self.ntt.local_ids
         self.num_levels = self.ntt.num_levels - 1
         self.num_slots = self.ctx.N // 2
@@ -261,7 +263,9 @@ class ckks_engine(EvaluatorOps):
         self.final_alpha = [self.scale / np.float64(x) for x in self.final_q]
         self.corrections = [1 / (d * fa) for d, fa in zip(self.deviations, self.final_alpha)]
         self.base_prime = q[self.ntt.p.base_prime_idx]
-        self.final_scalar = [self._t64([pow(x, -1, self.base_prime) * self.ctx.R % self.base_prime], 0)
+        # (balanced_limb_map: from the level where device 0 has lost its scale digit its first row IS the base prime — there is no
+        # scale-prime row beside it to decrypt against; evaluation is unaffected, _final_scale refuses, see there)
+        self.final_scalar = [None if x == self.base_prime else self._t64([pow(x, -1, self.base_prime) * self.ctx.R % self.base_prime], 0)
                              for x in self.final_q]
 
     # =============================================================================================
@@ -506,6 +510,8 @@ class ckks_engine(EvaluatorOps):
         loc = self._loc(0, special=True)
         if hit is not None and hit["ref"]() is anchor:
             if hit["own"]:
+                if hit.get("compact"):
+                    return hit["planes"]
                 if not planes:
                     return hit["packs"]
                 ver = tuple(p._version for p in hit["packs"])
@@ -526,6 +532,56 @@ class ckks_engine(EvaluatorOps):
                 packs.append(torch.stack(parts).contiguous())
         return self._remember_pack(ksk, packs, own=False)
 
+    # ---- keys at half the memory ------------------------------------------------------------------------------------
+    # A key made by this engine is a raw pack [parts, 2, rows, N] (its data_structs are views of it: the reference's layout,
+    # eng.py:601-652) AND, once a fused key switch has used it, a planes copy of the same size (gold: 2 x 429 MB; a Galois set of
+    # 15 rotation keys ~ 13 GB).  The fused path only ever reads the planes.  compact_key() frees the raw pack's STORAGE (the
+    # tensors and every view stay valid objects of zero-size storage), expand_key() brings the words back from the planes.
+    def compact_key(self, ksk):
+        """Free the raw words of a key this engine made; the fused key switch goes on reading its planes copy (gold: 858 -> 429 MB
+        per key).  Until expand_key() the key's own tensors hold no data: reading them (save, the unfused path of logN <= 12,
+        another engine) is an error raised by torch.  Returns the bytes freed.  In-place edits of a compact key are not seen."""
+        if not self._planes_wanted():
+            raise ValueError("compact_key: this engine's key switch reads raw key words (logN <= 12 or a checker backend)")
+        hit = self._key_packs.get(id(self._key_anchor(ksk)))
+        if hit is None or hit["ref"]() is not self._key_anchor(ksk) or not hit.get("own"):
+            raise ValueError("compact_key: not a key made by this engine (a foreign key's tensors are the caller's)")
+        self._key_pack(ksk)                       # the planes copy, current
+        freed = 0
+        for pk in hit["packs"]:
+            st = pk.untyped_storage()
+            if st.nbytes():
+                hit.setdefault("raw_bytes", {})[id(pk)] = st.nbytes()
+                freed += st.nbytes()
+                st.resize_(0)
+        hit["compact"] = True
+        return freed
+
+    def expand_key(self, ksk):
+        """Undo compact_key(): the raw pack is allocated again and filled from the planes copy — integer-class rows word for word,
+        fp64-class rows with the CANONICAL residues of the words they held (a key's words are lazy Montgomery words, the planes keep
+        their residues: the same key, every key switch the same words; byte-identical to the original only on integer-class rows)."""
+        hit = self._key_packs.get(id(self._key_anchor(ksk)))
+        if hit is None or not hit.get("compact"):
+            return
+        loc = self._loc(0, special=True)
+        for i, (d, pk) in enumerate(zip(loc, hit["packs"])):
+            pk.untyped_storage().resize_(hit["raw_bytes"][id(pk)])
+            planes = hit["planes"][i]
+            q = self._consts(d, 0, True).q_host
+            N = self.ctx.N
+            for r in range(pk.size(2)):
+                if int(q[r]) >= (1 << 41):
+                    pk[:, :, r].copy_(planes[:, :, r])
+                    continue
+                lo = planes[:, 0, r].contiguous().view(torch.int32).view(-1, N // 2, 4).to(torch.int64) & 0xffffffff
+                hi = planes[:, 1, r, :N // 2].contiguous().view(torch.int16).view(-1, N // 2, 4).to(torch.int64) & 0xffff
+                w = (hi << 32) | lo                                            # [parts, N / 2, (b[j], b[j+1], a[j], a[j+1])]
+                pk[:, 0, r].copy_(w[:, :, 0:2].reshape(-1, N))
+                pk[:, 1, r].copy_(w[:, :, 2:4].reshape(-1, N))
+        hit["compact"] = False
+        hit["planes_ver"] = tuple(p_._version for p_ in hit["packs"])       # the copy_ above moved the counters: the planes are current
+
     def release_key(self, ksk):
         """Drop what the engine holds for a key-switch key beyond the key's own tensors, now: the packed copy of a foreign
         key; for a key made by this engine — whose tensors are views of its raw pack — the PLANES copy the fused key switch
@@ -533,6 +589,8 @@ class ckks_engine(EvaluatorOps):
         rebuilt on the key's next use and dropped when the key's tensors die."""
         hit = self._key_packs.get(id(self._key_anchor(ksk)))
         dropped = []
+        if hit is not None and hit.get("compact"):
+            self.expand_key(ksk)                 # the planes are the only copy of a compact key: the raw words come back first
         if hit is not None and hit.get("own"):
             dropped = hit.pop("planes", None) or []
             hit.pop("planes_ver", None)
@@ -648,8 +706,16 @@ class ckks_engine(EvaluatorOps):
         self.ntt.reduce_2q(pt, level)
         return pt
 
+    def _need_final_scalar(self, level):
+        if self.final_scalar[level] is None:
+            raise ValueError(f"decryption at level {level} is not available in the balanced limb map: device 0 holds only the base prime "
+                             "there, and the final scaling reads a scale-prime row beside it (eng.py:517-533).  Decrypt on an engine "
+                             "with the reference's layout (balanced_limb_map=False; download_to_cpu / upload_to_gpu convert between "
+                             "the two) or at a level where device 0 still holds scale primes")
+
     def _final_scale(self, base, scaler, level, final_round):
         """(base - scaler) * q_l^-1 mod base prime, centred, + rounding bit (eng.py:517-533)."""
+        self._need_final_scalar(level)
         scaled = self.ntt.mont_sub([base], [scaler], -1)
         self.ntt.mont_enter_scalar(scaled, [self.final_scalar[level]], -1)
         self.ntt.reduce_2q(scaled, -1)

@@ -457,6 +457,7 @@ class EvaluatorOps:
             pt = self.ntt.mont_add(pt, pct, level)
         self.ntt.reduce_2q(pt, level)
         base_at = -self.ctx.num_special_primes - 1 if include_special else -1
+        self._need_final_scalar(level)
         scaled = self.ntt.mont_sub([pt[0][base_at][None, :]], [pt[0][0][None, :]], -1)
         self.ntt.mont_enter_scalar(scaled, [self.final_scalar[level]], -1)
         self.ntt.reduce_2q(scaled, -1)

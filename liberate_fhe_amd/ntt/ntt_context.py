@@ -34,8 +34,9 @@ from .rns_partition import rns_partition
 
 class ntt_context:
     @errors.log_error
-    def __init__(self, ctx, index_type=torch.int32, devices=None, verbose=False, ops=None, local_ids=None):
-        """`ops`: module/object exposing the 15 `ntt_cuda` functions (default: the HIP shim).
+    def __init__(self, ctx, index_type=torch.int32, devices=None, verbose=False, ops=None, local_ids=None, balance=False):
+        """`balance`: rns_partition(balance=True) — the top digit on GPU 1 instead of GPU 0 (not the reference's layout).
+        `ops`: module/object exposing the 15 `ntt_cuda` functions (default: the HIP shim).
         `local_ids`: logical device ids whose rows this process materialises (default: all) — with one
         process per GPU each rank passes its own id and the other devices' constant tensors stay empty."""
         t0 = time.time()
@@ -54,7 +55,7 @@ class ntt_context:
         self.num_ordinary_primes = ctx.num_scales + 1
         self.num_special_primes = ctx.num_special_primes
         self.num_levels = ctx.num_scales + 1
-        self.p = rns_partition(self.num_ordinary_primes, self.num_special_primes, self.num_devices)
+        self.p = rns_partition(self.num_ordinary_primes, self.num_special_primes, self.num_devices, balance=balance)
         self._say(f"partitioning done: {self.num_levels} levels, {self.num_ordinary_primes} ordinary "
                   f"and {self.num_special_primes} special primes")
 

@@ -19,8 +19,17 @@ import numpy as np
 
 
 class rns_partition:
-    def __init__(self, num_ordinary_primes=17, num_special_primes=2, num_devices=2):
+    def __init__(self, num_ordinary_primes=17, num_special_primes=2, num_devices=2, balance=False):
+        """balance (NOT the reference's layout; default off): GPU 0 carries the base-prime digit on top of its share of the
+        scale-prime digits, and in the reference's walk it is also the GPU that receives the (short) top digit — gold over 8
+        GPUs: 2 + 4 + 1 = 7 rows against 4 on the other seven, so every limb-sharded op waits for rank 0 (37 % more transform
+        work, 3.67 MB per link against 2.1).  With balance=True the top digit goes to GPU 1 when that lowers the largest row
+        count (gold / 8: 5, 6, 4, 4, 4, 4, 4, 4).  Digits are unchanged — same key-switch decomposition, same canonical words
+        per limb — and GPUs still run out of rows from the last one down (GPU 0 keeps the base prime, GPU 1 the highest scale
+        primes), which is what the engine's per-level device lists assume.  Digit sizes cap what is reachable: eight digits of
+        4, one of 2 and one of 1 cannot be spread flatter than 6 / 5 / 4 x 6 without re-cutting digits, i.e. another key."""
         L, K, D = num_ordinary_primes, num_special_primes, num_devices
+        self.balance = bool(balance)
         self.num_ordinary_primes, self.num_special_primes, self.num_devices = L, K, D
         self.num_scales = L - 1
         self.base_prime_idx = L - 1
@@ -30,9 +39,17 @@ class rns_partition:
         digits = [list(range(j * K, min((j + 1) * K, L - 1))) for j in range(P)]
         self.partitions = digits + [[L - 1]] + [list(range(L, L + K))]
 
+        shares = [sorted(range(P - 1 - dev, -1, -D)) for dev in range(D)]
+        if self.balance and D >= 2 and len(shares[0]) >= 1 and shares[0][-1] == P - 1:
+            rows = lambda share, base: sum(len(digits[j]) for j in share) + base
+            before = max(rows(shares[dev], 1 if dev == 0 else 0) for dev in range(D))
+            moved = [shares[0][:-1], sorted(shares[1] + [P - 1])] + shares[2:]
+            after = max(rows(moved[dev], 1 if dev == 0 else 0) for dev in range(D))
+            if after < before:
+                shares = moved
         self.part_allocations = []
         for dev in range(D):
-            mine = sorted(range(P - 1 - dev, -1, -D))
+            mine = list(shares[dev])
             if dev == 0:
                 mine.append(P)
             mine.append(P + 1)

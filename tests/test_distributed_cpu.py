@@ -307,3 +307,79 @@ def test_eight_ranks_gold_chain_shape_through_levels_where_ranks_drop_out(exchan
                     got = np.load(os.path.join(outdir, f"{name}.{comp}.{rank}.npy"))
                     exp = shards[rank].numpy() if rank < len(shards) else np.zeros((0, eng.ctx.N), dtype=np.int64)
                     assert got.shape == exp.shape and (got == exp).all(), (name, comp, rank)
+
+
+# ---- balanced limb map (rns_partition(balance=True): not the reference's layout, default off) ----------------------------------
+def test_balanced_limb_map_keeps_digits_and_the_order_in_which_devices_run_out_of_rows():
+    from liberate_fhe_amd.ntt.rns_partition import rns_partition
+    ref, bal = rns_partition(35, 4, 8), rns_partition(35, 4, 8, balance=True)
+    assert [len(r) for r in ref.destination_arrays[0]] == [7, 4, 4, 4, 4, 4, 4, 4]            # the reference's gold / 8 layout
+    assert [len(r) for r in bal.destination_arrays[0]] == [5, 6, 4, 4, 4, 4, 4, 4]
+    assert bal.partitions == ref.partitions                                                   # same digits: same key, same words
+    assert sorted(x for rows in bal.destination_arrays[0] for x in rows) == list(range(35))
+    assert 34 in bal.destination_arrays[0][0] and bal.destination_arrays[0][1][-2:] == [32, 33]
+    for shape in ((35, 4, 8), (35, 4, 4), (35, 4, 2), (17, 2, 2), (17, 2, 4), (6, 2, 2), (6, 2, 3), (80, 6, 8)):
+        a, b = rns_partition(*shape), rns_partition(*shape, balance=True)
+        L, K, D = shape
+        assert max(len(r) for r in b.destination_arrays[0]) <= max(len(r) for r in a.destination_arrays[0])
+        for lvl in range(L):                                   # alive devices are always 0 .. n - 1 (the engine's per-level lists)
+            alive = [len(r) > K for r in b.destination_arrays_with_special[lvl]]
+            assert alive == [True] * sum(alive) + [False] * (D - sum(alive)), (shape, lvl)
+            assert len(b.destination_arrays[lvl]) == sum(alive)
+            assert sorted(x for rows in b.destination_arrays[lvl] for x in rows) == list(range(lvl, L))
+        assert [r[-K:] for r in b.destination_arrays_with_special[0]] == [list(range(L, L + K))] * D
+    # max bytes per link of the point-to-point digit exchange at level 0, N = 65536: rows of the largest owner x 512 KiB
+    assert max(len(r) for r in bal.destination_arrays[0]) * 65536 * 8 == 6 * 524288 < 7 * 524288
+
+
+def _balanced_worker(rank, world, port, outdir):
+    warnings.filterwarnings("ignore")
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from liberate_fhe_amd.fhe import ckks_engine
+    from liberate_fhe_amd.fhe.comm import DistComm
+    from liberate_fhe_amd.utils import synth
+    from tests.oracle_backend import OracleBackend
+    eng = ckks_engine(devices=["cpu"], backend=OracleBackend(), comm=DistComm(local_device="cpu"), balanced_limb_map=True, **PARAMS)
+    assert [len(r) for r in eng.ntt.p.destination_arrays[0]] == [3, 3]            # the reference's layout: 4 / 2
+    for name, ct in _ops(eng, synth).items():
+        dest = eng.ntt.p.destination_arrays[ct.level]
+        for comp, shards in enumerate(ct.data):
+            arr = shards[0].numpy() if shards else np.zeros((0, eng.ctx.N), dtype=np.int64)
+            np.save(os.path.join(outdir, f"{name.replace('/', '_')}.{comp}.{rank}.npy"), arr)
+            if rank < len(dest):
+                np.save(os.path.join(outdir, f"{name.replace('/', '_')}.{comp}.{rank}.primes.npy"), np.array(dest[rank]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_the_balanced_limb_map_hold_the_one_device_words_limb_by_limb():
+    """small over 2 ranks with balanced_limb_map=True (3 / 3 rows instead of 4 / 2): rescale fan-out, digit exchange, deeper
+    levels — every limb's canonical words equal the single-device engine's (the reference digests are per device layout, so the
+    comparison is by prime index)."""
+    warnings.filterwarnings("ignore")
+    from liberate_fhe_amd.fhe import ckks_engine
+    from liberate_fhe_amd.utils import synth
+    from tests.oracle_backend import OracleBackend
+    one = ckks_engine(devices=["cpu"], backend=OracleBackend(), **PARAMS)
+    want = {name.replace("/", "_"): ct for name, ct in _ops(one, synth).items()}
+    port = 29500 + (os.getpid() % 2000) + 171
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_balanced_worker, args=(2, port, outdir), nprocs=2, join=True)
+        for name, ct in want.items():
+            first = one.ntt.p.destination_arrays[ct.level][0][0]
+            for comp in range(2):
+                seen = 0
+                for rank in range(2):
+                    f = os.path.join(outdir, f"{name}.{comp}.{rank}.primes.npy")
+                    if not os.path.exists(f):
+                        continue
+                    primes, rows = np.load(f), np.load(os.path.join(outdir, f"{name}.{comp}.{rank}.npy"))
+                    assert rows.shape[0] == len(primes)
+                    for r, prime in enumerate(primes):
+                        assert (rows[r] == ct.data[comp][0][prime - first].numpy()).all(), (name, comp, rank, int(prime))
+                        seen += 1
+                assert seen == ct.data[comp][0].shape[0], (name, comp)

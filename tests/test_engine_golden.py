@@ -109,6 +109,112 @@ def natural_rows(eng, ct):
 
 
 @pytest.mark.gpu
+def test_hip_gold_balanced_limb_map_equals_one_device_row_by_row():
+    """ckks_engine(balanced_limb_map=True) = rns_partition(35, 4, 8, balance=True): the top digit on device 1 instead of device 0
+    (rows 5 / 6 / 4 x 6 instead of 7 / 4 x 7; NOT the reference's layout, default off).  Digits are unchanged, so every canonical
+    word per limb is: cc_mult / rotate at level 0, across the rescale 3 -> 4 (device 0 loses its scale digit and keeps the base
+    prime), 9 -> 10 (device 7 runs out of rows) and at level 31 (two devices left) equal the undivided engine in prime order."""
+    from liberate_fhe_amd.fhe import ckks_engine, presets
+    params = {k: v for k, v in presets.params["gold"].items() if k != "devices"}
+    outs = []
+    for n_dev, bal in ((1, False), (8, True)):
+        eng = ckks_engine(devices=["cuda:0"] * n_dev, balanced_limb_map=bal, **params)
+        if bal:
+            assert [len(r) for r in eng.ntt.p.destination_arrays[0]] == [5, 6, 4, 4, 4, 4, 4, 4]
+            assert eng.len_devices[10] == 7 and eng.len_devices[31] == 2
+        evk = synth.key_switch_key(eng, 5)
+        rotk = synth.key_switch_key(eng, 6, origin="rotation key:1")
+        res = []
+        for lvl in (0, 3, 9, 30):
+            a, b = synth.ciphertext(eng, 3 + lvl, lvl), synth.ciphertext(eng, 4 + lvl, lvl)
+            res += [eng.cc_mult(a, b, evk), eng.rotate_single(a, rotk)]
+            res.append(eng.rotate_single(res[-2], rotk))
+        outs.append([natural_rows(eng, ct) for ct in res])
+        del eng, evk, rotk
+        torch.cuda.empty_cache()
+    for one, eight in zip(*outs):
+        for x, y in zip(one, eight):
+            assert x.shape == y.shape and (x == y).all()
+
+
+@pytest.mark.gpu
+def test_balanced_limb_map_decrypts_where_device_0_has_a_scale_prime_and_says_so_where_not():
+    """The reference's final scaling reads a scale-prime row beside the base prime on device 0 (eng.py:517-533).  In the balanced
+    map device 0 keeps one while its own scale digit lives (small over 2 devices: levels 0 and 1): same plaintext as the
+    reference layout; from level 2 on it holds only the base prime: a ValueError that names the way out, not a wrong plaintext."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    params = GOLD["small"]["params"]
+    ref = ckks_engine(devices=["cuda:0"] * 2, **params)
+    bal = ckks_engine(devices=["cuda:0"] * 2, balanced_limb_map=True, **params)
+    assert [len(r) for r in ref.ntt.p.destination_arrays[0]] == [4, 2] and [len(r) for r in bal.ntt.p.destination_arrays[0]] == [3, 3]
+    assert [len(r) for r in bal.ntt.p.destination_arrays[2]][0] == 1
+    sk = bal.create_secret_key()
+    pk = bal.create_public_key(sk)
+    np.random.seed(3)
+    m = bal.example(-1, 1)
+    ct = bal.encorypt(m, pk, level=0)
+    got = bal.decrode(ct, sk)
+    assert np.abs(got - m).max() < 1e-6
+    ct1 = bal.encorypt(m, pk, level=1)
+    assert np.abs(bal.decrode(ct1, sk) - m).max() < 1e-6
+    ct2 = bal.encorypt(m, pk, level=2)
+    with pytest.raises(Exception, match="balanced limb map"):
+        bal.decrode(ct2, sk)
+    # evaluation is unaffected at that level: the words equal the reference layout's, limb by limb
+    rotk_b, rotk_r = synth.key_switch_key(bal, 6, origin="rotation key:1"), synth.key_switch_key(ref, 6, origin="rotation key:1")
+    a_b, a_r = synth.ciphertext(bal, 21, 2), synth.ciphertext(ref, 21, 2)
+    for x, y in zip(natural_rows(bal, bal.rotate_single(a_b, rotk_b)), natural_rows(ref, ref.rotate_single(a_r, rotk_r))):
+        assert (x == y).all()
+
+
+@pytest.mark.gpu
+def test_compact_key_halves_a_keys_memory_and_changes_no_result():
+    """engine.compact_key(): the raw pack of a key the engine made is freed (the fused key switch reads the planes copy only);
+    expand_key() restores it from the planes — integer-class rows byte for byte, fp64-class rows as the canonical residues of the
+    lazy words they held.  Same cc_mult / rotate words before, while compact, and after."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    eng = ckks_engine(devices=["cuda:0"], **GOLD["silver"]["params"])
+    sk = eng.create_secret_key()
+    evk = eng.create_evk(sk)
+    rotk = eng.create_rotation_key(sk, 1)
+    a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
+    want = [eng.cc_mult(a, b, evk), eng.rotate_single(a, rotk)]
+    raw = [part.data[c][0].clone() for part in evk.data for c in range(2)]
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    freed = eng.compact_key(evk)
+    pack_bytes = len(evk.data) * 2 * evk.data[0].data[0][0].size(0) * eng.ctx.N * 8
+    assert freed == pack_bytes and eng.compact_key(evk) == 0
+    assert before - torch.cuda.memory_allocated() >= freed - (4 << 20)
+    for _ in range(2):
+        got = [eng.cc_mult(a, b, evk), eng.rotate_single(a, rotk)]
+        for g, w in zip(got, want):
+            assert torch.equal(g.data[0][0], w.data[0][0]) and torch.equal(g.data[1][0], w.data[1][0])
+    eng.expand_key(evk)
+    q = [eng.ctx.q[i] for i in eng.ntt.p.d_special[0]]
+    k = 0
+    for part in evk.data:
+        for c in range(2):
+            now, old = part.data[c][0], raw[k]
+            k += 1
+            for r, qr in enumerate(q):
+                if qr >= (1 << 41):
+                    assert torch.equal(now[r], old[r])
+                else:
+                    assert bool(((now[r] >= 0) & (now[r] < qr)).all()) and bool((((old[r] - now[r]) % qr) == 0).all())
+    got = eng.cc_mult(a, b, evk)
+    assert torch.equal(got.data[0][0], want[0].data[0][0]) and torch.equal(got.data[1][0], want[0].data[1][0])
+    eng.compact_key(evk)
+    eng.release_key(evk)                              # the planes are a compact key's only copy: the raw words come back first
+    got = eng.cc_mult(a, b, evk)
+    assert torch.equal(got.data[0][0], want[0].data[0][0])
+    foreign = synth.key_switch_key(eng, 5)
+    eng.cc_mult(a, b, foreign)
+    with pytest.raises(ValueError):
+        eng.compact_key(foreign)
+
+
+@pytest.mark.gpu
 def test_hip_gold_eight_logical_devices_equal_one_device():
     """BASELINE configs[3]'s partition (rns_partition(35, 4, 8): 11 / 8 / .. / 8 rows with the special limbs, digit
     exchange between 8 shards) against the undivided engine, row by row in prime order, at level 0 and across the
