@@ -208,8 +208,10 @@ def test_compact_key_halves_a_keys_memory_and_changes_no_result():
     eng.release_key(evk)                              # the planes are a compact key's only copy: the raw words come back first
     got = eng.cc_mult(a, b, evk)
     assert torch.equal(got.data[0][0], want[0].data[0][0])
-    foreign = synth.key_switch_key(eng, 5)
-    eng.cc_mult(a, b, foreign)
+    # a key whose tensors are the caller's (here: clones of the parts) is never touched
+    foreign = evk._replace(data=[part._replace(data=([t.clone() for t in part.data[0]], [t.clone() for t in part.data[1]])) for part in evk.data])
+    got = eng.cc_mult(a, b, foreign)
+    assert torch.equal(got.data[0][0], want[0].data[0][0])
     with pytest.raises(ValueError):
         eng.compact_key(foreign)
 
