@@ -1232,6 +1232,18 @@ def main():
         extra["poly_ntt_per_s_ciphertext_limbs_1_integer_class"] = B / (ct_ms * 1e-3)
         extra["ciphertext_limbs_note"] = (f"rows {lo_ct}..{total - 5}: 29 scale primes + base prime (a level-5 ciphertext, no special primes);"
                                           " reported for the limb-mix sensitivity only, the metric above keeps its 5 integer-class limbs")
+        if ws is not None:
+            # .. and its tiled pass alone: with one integer-class limb the pass is no longer bound by instruction issue but by
+            # its own bytes (6 + 8 per word), which bounds what ANY cheaper integer butterfly could buy the headline
+            def tiled_ct():
+                check(lib.lf_ntt_pass_ws(x.data_ptr(), ws.data_ptr(), B, L_LIMBS, LOGN, psi_c.data_ptr(), dp_c, qh_ct.ctypes.data, 0, 0, 2,
+                                         ql_c.data_ptr(), qh_c.data_ptr(), kl_c.data_ptr(), kh_c.data_ptr(), local_rank, stream), "lf_ntt_pass_ws")
+            tiled_ct()
+            torch.cuda.synchronize()
+            t_ms = event_time_ms(tiled_ct, 40)
+            moved = B * L_LIMBS * N * (8 + 6 * (L_LIMBS - 1) / L_LIMBS + 8 / L_LIMBS)
+            extra["tiled_pass_1_integer_class"] = {"avg_launch_ms": t_ms, "moved_TB_per_s": moved / (t_ms * 1e-3) / 1e12,
+                                                   "headline_tiled_pass_ms": k_ms}
         # the other halves of BASELINE's metric ("NTTs/sec at logN = 15, 16"): every limb of the silver chain at logN 15, the
         # whole gold chain incl. the inverse chain, and the reference's largest preset — each with its own roofline block
         x = ws = None      # the headline's stack and workspace are not needed any more

@@ -424,7 +424,7 @@ int lf_galois_batch(const int64_t *const *a, int64_t *const *dst, int count, int
  * and stores the digit state — the coefficient-domain product is never written (cc_mult: ckks_engine.py:1099-1101, 1129, 654-705).
  * `scratch` [batch][rows][N] receives the tiled pass's output; `state` [batch][rows][N]; desc / tab = lf_ks_digits' tables for
  * `nparts` digits of at most `max_alpha` limbs.  Applies to two-pass ring degrees with max_alpha * 2^(logN - 12) <= 32 (silver,
- * bronze); otherwise returns LF_ERR_ARG with nothing launched and the caller takes the two calls.  Same words in `state`. */
+ * bronze; <= 64 at logN 16 — gold — when batch >= 2); otherwise returns LF_ERR_ARG with nothing launched and the caller takes the two calls.  Same words in `state`. */
 int lf_intt_mul_digits(int64_t *scratch, const int64_t *a, int64_t a_stride, const int64_t *b, int64_t b_stride, int batch, int rows,
                        int logN, int64_t *state, int nparts, int max_alpha, const int64_t *desc, const int64_t *tab,
                        const int64_t *ipsi_br, const double *ipsi_dp, const int64_t *q_host, const int64_t *Ninv, int flags,

@@ -545,7 +545,9 @@ int lf_intt_ws(int64_t *a, int64_t *ws, int batch, int rows, int logN, const int
 /* lf_intt_mul followed by lf_ks_digits of its result, the coefficient-domain product never written: the first inverse pass forms
  * a * b into `scratch` ([batch][rows][N], the tiled pass's output), the column pass of every digit's limbs ends in the Garner
  * step and stores the digit states ([batch][rows][N], state_stride words apart).  Returns LF_ERR_ARG — nothing launched — when
- * the shape does not qualify (two-pass degrees with max_alpha * 2^(logN - 12) <= 32 words per thread only): the caller then
+ * the shape does not qualify (two-pass degrees with max_alpha * 2^(logN - 12) <= 32 words per thread; 64 — gold's 4 limbs x 16 words,
+ * 200 VGPRs at 2 waves per SIMD — for batches only: measured, in one process, gold cc_mult x 16 318 -> 311 us per ciphertext,
+ * but a single cc_mult 414 -> 430 us: two waves per SIMD do not hide the latency of a launch that small): the caller then
  * takes lf_intt_mul + lf_ks_digits.  Same words in `state` either way. */
 int lf_intt_mul_digits(int64_t *scratch, const int64_t *a, int64_t a_stride, const int64_t *b, int64_t b_stride, int batch, int rows,
                        int logN, int64_t *state, int nparts, int max_alpha, const int64_t *desc, const int64_t *tab,
@@ -553,7 +555,7 @@ int lf_intt_mul_digits(int64_t *scratch, const int64_t *a, int64_t a_stride, con
                        const int64_t *ql, const int64_t *qh, const int64_t *kl, const int64_t *kh, int device, void *stream) {
     const int S1 = logN - NTT_TILE_LOG_MAX;
     if (!scratch || !a || !b || !state || !desc || !tab || !ipsi_dp || !q_host || batch < 1 || batch > LF_BATCH_MAX || rows < 1 ||
-        rows > MAX_LIST_ROWS || nparts < 1 || max_alpha < 1 || max_alpha > KS_MAX_ALPHA || S1 < 1 || S1 > 4 || (max_alpha << S1) > 32 ||
+        rows > MAX_LIST_ROWS || nparts < 1 || max_alpha < 1 || max_alpha > KS_MAX_ALPHA || S1 < 1 || S1 > 4 || (max_alpha << S1) > ((S1 == 4 && batch >= 2) ? 64 : 32) ||
         !(flags & LF_NTT_RELAXED))
         return LF_ERR_ARG;
     if (int e = lf_set_device(device)) return e;
@@ -582,7 +584,7 @@ int lf_intt_mul_digits(int64_t *scratch, const int64_t *a, int64_t a_stride, con
     if (S1 == 1) { if (amax == 1) LF_ICD(1, 1); else if (amax == 2) LF_ICD(1, 2); else if (amax == 4) LF_ICD(1, 4); else LF_ICD(1, 8); }
     else if (S1 == 2) { if (amax == 1) LF_ICD(2, 1); else if (amax == 2) LF_ICD(2, 2); else if (amax == 4) LF_ICD(2, 4); else LF_ICD(2, 8); }
     else if (S1 == 3) { if (amax == 1) LF_ICD(3, 1); else if (amax == 2) LF_ICD(3, 2); else LF_ICD(3, 4); }
-    else { if (amax == 1) LF_ICD(4, 1); else LF_ICD(4, 2); }
+    else { if (amax == 1) LF_ICD(4, 1); else if (amax == 2) LF_ICD(4, 2); else LF_ICD(4, 4); }   // (gold: 4 limbs x 16 words per thread)
 #undef LF_ICD
     return (int)hipGetLastError();
 }
