@@ -111,6 +111,7 @@ class ckks_engine(EvaluatorOps):
         # sum over L_{i-1} y_i — same residues either way (tools/ab_engines.py times one against the other)
         self.ks_horner = True
         self._lane_streams = {}
+        self._last_stream = {}  # (device, lane) -> the torch stream its last op was enqueued on (_same_stream)
         self._check_kernel_limits()
 
         ds, nd, ls = data_struct, np.ndarray, list
@@ -181,13 +182,28 @@ class ckks_engine(EvaluatorOps):
             self._md_ready.add(id(ws))      # (workspaces live as long as the engine: the id stays theirs)
         return ws, one
 
+    def _same_stream(self, dev_id):
+        """The scratch of (device, lane) is ordered by the stream its ops run on.  An op enqueued on ANOTHER current stream than the
+        lane's previous op first makes that stream wait for the previous one (a device-side dependency, no host block): a caller
+        that alternates streams between ops of one engine gets serialised scratch instead of a race.  One pointer compare per op."""
+        dev = self.ntt.devices[dev_id]
+        if not str(dev).startswith("cuda"):
+            return
+        cur = torch.cuda.current_stream(dev)
+        k = (dev_id, self._lane)
+        last = self._last_stream.get(k)
+        if last is not None and last.cuda_stream != cur.cuda_stream:
+            cur.wait_stream(last)
+        self._last_stream[k] = cur
+
     def _ws(self, key, shape, dev_id):
         """Reusable scratch tensor (never returned to the caller); one set per pipeline lane (see _lanes).
         STREAMS: the scratch belongs to the engine, not to a stream — the reference allocates its intermediates per call, this
-        engine reuses them, ordered only by the stream its ops are enqueued on.  Every op of one engine must therefore be
-        enqueued on ONE torch stream per device (the current stream at the time of the call; the batched methods fork and
-        join their own lanes).  A caller that alternates streams between ops of the same engine has to order them itself
-        (stream.wait_stream) or use one engine per stream; ops of DIFFERENT engines are independent."""
+        engine reuses them, ordered by the stream its ops are enqueued on.  Ops of one engine on ONE torch stream per device are
+        ordered by that stream; an op that arrives on another current stream is made to wait for the lane's previous op
+        (_same_stream): alternating streams is safe and serial.  For concurrency use one engine per stream — ops of DIFFERENT
+        engines are independent (the batched methods fork and join their own lanes)."""
+        self._same_stream(dev_id)
         k = (key, tuple(shape), dev_id, self._lane)
         t = self._workspace.get(k)
         if t is None:
@@ -893,6 +909,7 @@ class ckks_engine(EvaluatorOps):
         resolved once (per pipeline lane: the scratch tensors are per lane).  nct = ciphertexts per batched call the scratch
         is sized for (1: the single-ciphertext workspaces the step-by-step path uses too).  `d` may be this rank's device of a
         limb-sharded engine: the plan then describes its rows, `nparts` all digits, `dig_nparts` the digits it owns."""
+        self._same_stream(d)
         key = ("plan", level, d, self._lane, nct)
         hit = self._tables.get(key)
         if hit is not None:

@@ -168,6 +168,38 @@ def test_balanced_limb_map_decrypts_where_device_0_has_a_scale_prime_and_says_so
 
 
 @pytest.mark.gpu
+def test_ops_of_one_engine_alternating_between_two_streams_are_ordered_not_raced():
+    """The engine's scratch (digits, sums, operand stack, plan workspaces) is per engine and lane, not per stream.  An op that
+    arrives on another current stream than the lane's previous op makes its stream wait for the previous one (_same_stream): 40
+    ops alternating between two streams with no synchronisation in between give the single-stream words."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    eng = ckks_engine(devices=["cuda:0"], **GOLD["silver"]["params"])
+    a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
+    evk, rotk = synth.key_switch_key(eng, 5), synth.key_switch_key(eng, 6, origin="rotation key:1")
+    want_m, want_r = eng.cc_mult(a, b, evk), eng.rotate_single(a, rotk)
+    want_b = eng.rotate_single_batch([a, b, a, b, a], rotk)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    got = []
+    for i in range(20):
+        with torch.cuda.stream(s1):
+            got.append(("m", eng.cc_mult(a, b, evk)))
+        with torch.cuda.stream(s2):
+            got.append(("r", eng.rotate_single(a, rotk)))
+        if i % 7 == 3:
+            with torch.cuda.stream(s1):
+                got.append(("b", eng.rotate_single_batch([a, b, a, b, a], rotk)))
+    torch.cuda.synchronize()
+    for kind, ct in got:
+        if kind == "b":
+            for x, y in zip(ct, want_b):
+                assert torch.equal(x.data[0][0], y.data[0][0]) and torch.equal(x.data[1][0], y.data[1][0])
+            continue
+        w = want_m if kind == "m" else want_r
+        assert torch.equal(ct.data[0][0], w.data[0][0]) and torch.equal(ct.data[1][0], w.data[1][0]), kind
+
+
+@pytest.mark.gpu
 def test_compact_key_halves_a_keys_memory_and_changes_no_result():
     """engine.compact_key(): the raw pack of a key the engine made is freed (the fused key switch reads the planes copy only);
     expand_key() restores it from the planes — integer-class rows byte for byte, fp64-class rows as the canonical residues of the
