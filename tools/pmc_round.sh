@@ -2,7 +2,7 @@
 # PMC passes (separate runs, as the guide prescribes) over the bench step and over gold / silver cc_mult:
 #   tools/pmc_round.sh <tag>      (on the GPU box; then tools/summarize_round.py <tag> -> profiles/)
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out; mkdir -p $OUT; REPO=$PWD
 # build ONCE, unprofiled: a profiled process must never spawn the compiler (the profiler's preload would ride along into hipcc,

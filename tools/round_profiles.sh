@@ -2,7 +2,7 @@
 # Everything the committed profiles/ of a round are made from, in ONE GPU-box call:  tools/round_profiles.sh <tag>
 #   PMC passes + kernel stats + bench line (pmc_round.sh), engine-op kernel traces (profile_engine_ops.sh), summaries.
 # The summaries land in profiles/ on the box; they are copied to gpurun_out/profiles_<tag>/ to travel back.
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "$(dirname "$0")/.." || exit 1
 bash tools/pmc_round.sh $TAG > gpurun_out/pmc_round_$TAG.log 2>&1
 python3 tools/summarize_round.py $TAG > gpurun_out/summarize_round_$TAG.log 2>&1
