@@ -868,6 +868,8 @@ def main():
     # semantics of work.wait(); its JSON becomes comm.rccl_world1 of the line.
     rccl_world1 = None
     if world == 1 and not args.no_extra and os.environ.get("LF_BENCH_RCCL_WORLD1", "1") != "0" and torch.cuda.device_count() >= 1:
+        import __graft_entry__ as g0
+        g0.build()                      # (hipcc cross-compiles without touching the GPU: the child must load THIS tree's library)
         rccl_world1 = run_rccl_world1()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")

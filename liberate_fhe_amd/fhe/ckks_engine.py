@@ -40,6 +40,39 @@ from .presets import errors, types
 from .version import VERSION
 
 
+class _OneShard:
+    """The ntt_context calls of a decryption restricted to ONE local shard (pack index `li`, logical device `dev`): the
+    context's wrappers walk every device's list from index 0, which is what the reference's decryption — device 0 only — wants;
+    the balanced limb map also needs the first row of device 1."""
+
+    def __init__(self, eng, li, dev):
+        self.n, self.li, self.dev, self.starts = eng.ntt, li, dev, eng.ntt.starts
+
+    def _pk(self, pack):
+        return [x[self.li:self.li + 1] for x in pack]
+
+    def enter_ntt(self, a, lvl):
+        self.n.ops.enter_ntt(a, self.n.Rs_prepack[-1][lvl][0][self.li:self.li + 1], *self._pk(self.n.ntt_prepack[-1][lvl][0]))
+
+    def mont_mult(self, a, b, lvl):
+        return self.n.ops.mont_mult(a, b, *self._pk(self.n.mont_prepack[-1][lvl][0]))
+
+    def intt_exit(self, a, lvl):
+        self.n.ops.intt_exit(a, *self._pk(self.n.intt_prepack[-1][lvl][0]))
+
+    def intt_exit_reduce(self, a, lvl):
+        self.n.ops.intt_exit_reduce(a, *self._pk(self.n.intt_prepack[-1][lvl][0]))
+
+    def mont_add(self, a, b, lvl):
+        return self.n.ops.mont_add(a, b, self.n._2q_prepack[-1][lvl][0][self.li:self.li + 1])
+
+    def reduce_2q(self, a, lvl):
+        self.n.ops.reduce_2q(a, self.n._2q_prepack[-1][lvl][0][self.li:self.li + 1])
+
+    def _decrypt_rows(self, ct, sk):
+        return ckks_engine._decrypt_rows_on(self, ct, sk, self.li, self.dev)
+
+
 class ckks_engine(EvaluatorOps):
     @errors.log_error
     def __init__(self, devices: list[int] = None, verbose: bool = False, bias_guard: bool = True,
@@ -274,13 +307,18 @@ class ckks_engine(EvaluatorOps):
         self.deviations = [1]
         for al in self.alpha:
             self.deviations.append(self.deviations[-1] ** 2 * al)
-        self.final_q_ind = [da[0][0] for da in self.ntt.p.destination_arrays[:-1]]
+        # The final scaling of a decryption reads a scale-prime row ("scaler") beside the base-prime row.  In the reference's
+        # limb map both sit on device 0 at every level (eng.py:517-533: its first and last row).  In the balanced map device 0
+        # holds only the base prime once its scale digit is gone: the scaler is then the first row of device 1, which holds the
+        # highest scale primes (_scaler_dev; decrypt fetches that one row).
+        base = self.ntt.p.base_prime_idx
+        self._scaler_dev = [0 if (da[0][0] != base or len(da) < 2) else 1 for da in self.ntt.p.destination_arrays[:-1]]
+        self.final_q_ind = [da[sd][0] for da, sd in zip(self.ntt.p.destination_arrays[:-1], self._scaler_dev)]
         self.final_q = [q[i] for i in self.final_q_ind]
         self.final_alpha = [self.scale / np.float64(x) for x in self.final_q]
         self.corrections = [1 / (d * fa) for d, fa in zip(self.deviations, self.final_alpha)]
         self.base_prime = q[self.ntt.p.base_prime_idx]
-        # (balanced_limb_map: from the level where device 0 has lost its scale digit its first row IS the base prime — there is no
-        # scale-prime row beside it to decrypt against; evaluation is unaffected, _final_scale refuses, see there)
+        # (a level whose only limb is the base prime has nothing to scale by: None, _need_final_scalar refuses)
         self.final_scalar = [None if x == self.base_prime else self._t64([pow(x, -1, self.base_prime) * self.ctx.R % self.base_prime], 0)
                              for x in self.final_q]
 
@@ -693,41 +731,46 @@ class ckks_engine(EvaluatorOps):
             pt = self.rng.randround(pt * np.float64(self.scale))
         return self._encrypt_poly(self._replicate_plain(pt), pk, level, dc_rns)
 
-    def _decrypt_rows(self, ct, sk):
-        """pt rows on device 0 (c0 + c1*s, or the triplet form), canonical; eng.py:481-566."""
+    def _decrypt_rows(self, ct, sk, li=0, dev=0):
+        """pt rows (c0 + c1*s, or the triplet form), canonical, of the local shard `li` = logical device `dev`: device 0 as in the
+        reference (eng.py:481-566); the balanced limb map also asks for device 1's (see _scaler_dev)."""
         level = ct.level
-        sk0 = sk.data[0][self.ntt.starts[level][0]:]
+        if li or dev:
+            return _OneShard(self, li, dev)._decrypt_rows(ct, sk)
+        return self._decrypt_rows_on(self.ntt, ct, sk, 0, 0)
+
+    @staticmethod
+    def _decrypt_rows_on(n, ct, sk, li, dev):
+        level = ct.level
+        sk0 = sk.data[li][n.starts[level][dev]:]
         if ct.origin == types.origins["ct"]:
             if ct.ntt_state or ct.montgomery_state:
                 raise errors.NotMatchDataStructState(origin=ct.origin)
-            a = ct.data[1][0].clone()
-            self.ntt.enter_ntt([a], level)
-            sa = self.ntt.mont_mult([a], [sk0], level)
-            self.ntt.intt_exit(sa, level)
-            pt = self.ntt.mont_add([ct.data[0][0]], sa, level)
+            a = ct.data[1][li].clone()
+            n.enter_ntt([a], level)
+            sa = n.mont_mult([a], [sk0], level)
+            n.intt_exit(sa, level)
+            pt = n.mont_add([ct.data[0][li]], sa, level)
         elif ct.origin == types.origins["ctt"]:
             if not ct.ntt_state or not ct.montgomery_state:
                 raise errors.NotMatchDataStructState(origin=ct.origin)
-            d0 = [ct.data[0][0].clone()]
-            self.ntt.intt_exit_reduce(d0, level)
-            d1_s = self.ntt.mont_mult([ct.data[1][0]], [sk0], level)
-            s2 = self.ntt.mont_mult([sk0], [sk0], level)
-            d2_s2 = self.ntt.mont_mult([ct.data[2][0]], s2, level)
-            self.ntt.intt_exit(d1_s, level)
-            self.ntt.intt_exit(d2_s2, level)
-            pt = self.ntt.mont_add(d0, d1_s, level)
-            pt = self.ntt.mont_add(pt, d2_s2, level)
+            d0 = [ct.data[0][li].clone()]
+            n.intt_exit_reduce(d0, level)
+            d1_s = n.mont_mult([ct.data[1][li]], [sk0], level)
+            s2 = n.mont_mult([sk0], [sk0], level)
+            d2_s2 = n.mont_mult([ct.data[2][li]], s2, level)
+            n.intt_exit(d1_s, level)
+            n.intt_exit(d2_s2, level)
+            pt = n.mont_add(d0, d1_s, level)
+            pt = n.mont_add(pt, d2_s2, level)
         else:
             raise errors.NotMatchType(origin=ct.origin, to=f"{types.origins['ct']} or {types.origins['ctt']}")
-        self.ntt.reduce_2q(pt, level)
+        n.reduce_2q(pt, level)
         return pt
 
     def _need_final_scalar(self, level):
         if self.final_scalar[level] is None:
-            raise ValueError(f"decryption at level {level} is not available in the balanced limb map: device 0 holds only the base prime "
-                             "there, and the final scaling reads a scale-prime row beside it (eng.py:517-533).  Decrypt on an engine "
-                             "with the reference's layout (balanced_limb_map=False; download_to_cpu / upload_to_gpu convert between "
-                             "the two) or at a level where device 0 still holds scale primes")
+            raise ValueError(f"decryption at level {level}: the base prime is the only limb left, there is no scale prime to scale by")
 
     def _final_scale(self, base, scaler, level, final_round):
         """(base - scaler) * q_l^-1 mod base prime, centred, + rounding bit (eng.py:517-533)."""
@@ -737,7 +780,9 @@ class ckks_engine(EvaluatorOps):
         self.ntt.reduce_2q(scaled, -1)
         self.ntt.make_signed(scaled, -1)
         if final_round:
-            rounding_prime = self.ntt.qlists[0][-self.ctx.num_special_primes - 2]
+            # (the reference compares against device 0's last scale prime whatever the scaler's own prime is — kept, for parity;
+            # with the scaler fetched from device 1 — balanced limb map — it is the scaler's prime)
+            rounding_prime = self.final_q[level] if self._scaler_dev[level] else self.ntt.qlists[0][-self.ctx.num_special_primes - 2]
             scaled[0] += (scaler[0] > (rounding_prime // 2)) * 1
         return scaled
 
@@ -746,11 +791,41 @@ class ckks_engine(EvaluatorOps):
             raise errors.NotMatchType(origin=sk.origin, to=types.origins["sk"])
         if not sk.ntt_state or not sk.montgomery_state:
             raise errors.NotMatchDataStructState(origin=sk.origin)
-        if 0 not in self.local_ids:
+        got = self._base_and_scaler(ct, sk)
+        if got is None:
             return None  # the base-prime row lives on device 0
-        pt = self._decrypt_rows(ct, sk)
+        base, scaler, _ = got
+        return self._final_scale(base, scaler, ct.level, final_round)
+
+    def _base_and_scaler(self, ct, sk):
+        """(base-prime row, scaler row, pt rows of device 0) on device 0, or None on a rank that does not hold device 0.  The
+        scaler is device 0's first row as in the reference — or, in the balanced limb map once device 0 has lost its scale
+        digit, the first row of device 1 (_scaler_dev): computed there and moved (one process: a device copy; one process per
+        GPU: one message from rank 1 to rank 0; ranks 0 and 1 both call decrypt, every other rank returns at once)."""
+        level = ct.level
+        src = self._scaler_dev[level]
         base_at = -self.ctx.num_special_primes - 1 if ct.include_special else -1
-        return self._final_scale(pt[0][base_at][None, :], pt[0][0][None, :], ct.level, final_round)
+        if src == 0:
+            if 0 not in self.local_ids:
+                return None
+            pt = self._decrypt_rows(ct, sk)
+            return pt[0][base_at][None, :], pt[0][0][None, :], pt
+        N = self.ctx.N
+        if self._multi:
+            me = self.local_ids[0]
+            if me not in (0, src):
+                return None
+            buf = self._ws("scaler_row", (1, N), me)
+            pt = self._decrypt_rows(ct, sk, 0, me)
+            if me == src:
+                buf[0].copy_(pt[0][0])
+            self.comm.fanout_into(buf, src, [0, src])
+            if me != 0:
+                return None
+            return pt[0][base_at][None, :], buf, pt
+        pt = self._decrypt_rows(ct, sk)
+        other = self._decrypt_rows(ct, sk, src, src)
+        return pt[0][base_at][None, :], other[0][0][None, :].to(pt[0].device), pt
 
     def decrypt_double(self, ct, sk, final_round=True):
         if ct.origin != types.origins["ct"]:
@@ -765,15 +840,14 @@ class ckks_engine(EvaluatorOps):
     def decryptcode(self, ct: data_struct, sk: data_struct, is_real=False, final_round=True):
         if (not sk.ntt_state) or (not sk.montgomery_state):
             raise errors.NotMatchDataStructState(origin=sk.origin)
-        if 0 not in self.local_ids:
-            return None
         level = ct.level
-        pt = self._decrypt_rows(ct, sk)
+        got = self._base_and_scaler(ct, sk)
+        if got is None:
+            return None
+        base, scaler, pt = got
         base_at = -self.ctx.num_special_primes - 1 if ct.include_special else -1
-        base = pt[0][base_at][None, :]
-        scaler = pt[0][0][None, :]
         dest0 = self.ntt.p.destination_arrays[level][0]
-        guard = len(dest0) >= 3 and self.bias_guard
+        guard = len(dest0) >= 3 and self.bias_guard and self._scaler_dev[level] == 0
         if guard:
             # the DC coefficient is rebuilt from three residues by CRT in Python ints (eng.py:1616-1646)
             dc0, dc1, dc2 = base[0][0].item(), scaler[0][0].item(), pt[0][1][0].item()

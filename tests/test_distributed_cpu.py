@@ -383,3 +383,43 @@ def test_two_ranks_with_the_balanced_limb_map_hold_the_one_device_words_limb_by_
                         assert (rows[r] == ct.data[comp][0][prime - first].numpy()).all(), (name, comp, rank, int(prime))
                         seen += 1
                 assert seen == ct.data[comp][0].shape[0], (name, comp)
+
+
+def _balanced_decrypt_worker(rank, world, port, outdir):
+    warnings.filterwarnings("ignore")
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from liberate_fhe_amd.fhe import ckks_engine
+    from liberate_fhe_amd.fhe.comm import DistComm
+    from tests.oracle_backend import OracleBackend
+    eng = ckks_engine(devices=["cpu"], backend=OracleBackend(), comm=DistComm(local_device="cpu"), balanced_limb_map=True, **PARAMS)
+    assert eng._scaler_dev[:4] == [0, 0, 1, 1]
+    sk = eng.create_secret_key()
+    pk = eng.create_public_key(sk)
+    np.random.seed(5)
+    m = eng.example(-1, 1)
+    out = {}
+    for level in (0, 1, 2, 3):
+        ct = eng.encorypt(m, pk, level=level)
+        got = eng.decrode(ct, sk)                      # level >= 2: rank 1 computes the scaler row and sends it to rank 0
+        assert (got is None) == (rank != 0)
+        if rank == 0:
+            out[level] = float(np.abs(got - m).max())
+    if rank == 0:
+        with open(os.path.join(outdir, "err.json"), "w") as f:
+            json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_decrypt_in_the_balanced_limb_map_with_the_scaler_row_from_rank_one():
+    """From the level where device 0 holds only the base prime (small / 2 ranks: level 2) the final scaling's scale-prime row is
+    the first row of rank 1: both ranks call decrode, rank 1 sends that one row, rank 0 returns the plaintext."""
+    port = 29500 + (os.getpid() % 2000) + 173
+    with tempfile.TemporaryDirectory() as outdir:
+        mp.spawn(_balanced_decrypt_worker, args=(2, port, outdir), nprocs=2, join=True)
+        err = json.load(open(os.path.join(outdir, "err.json")))
+    assert set(err) == {"0", "1", "2", "3"} and all(v < 1e-5 for v in err.values()), err

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--no-engine", action="store_true")
     args = ap.parse_args()
     warnings.filterwarnings("ignore")
+    import __graft_entry__ as g
+    g.build()                                         # a no-op when libckks_hip.so is current; never touches the GPU
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     import datetime
