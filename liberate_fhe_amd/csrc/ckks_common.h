@@ -178,12 +178,15 @@ static __device__ __forceinline__ double dp_from_signed(i64 x) {
 // lf_cc_mult_evk_pre -> _post, lf_ntt_pass_ws 1 -> 2) and both decide the format from lf_tune's process-wide knobs.  The
 // producer notes the format it wrote over [p, p + bytes); the consumer states the format it is about to read and gets
 // LF_ERR_STATE — nothing launched — when a noted range it overlaps was written in another one (a knob flipped between the
-// halves).  Ranges nobody noted are taken on trust (a caller may fill scratch by hand).  Mutex-protected, 256 ranges, oldest out.
+// halves: only notes made under an EARLIER knob setting count — a mismatching note of the current setting is a stale one on memory
+// the caller's allocator recycled).  Ranges nobody noted are taken on trust (a caller may fill scratch by hand).  Mutex-protected,
+// 256 ranges, oldest out.
 #define LF_FMT_RAW 0
 #define LF_FMT_PLANES 1
 #define LF_FMT_WS_SPLIT0 2      // lf_ntt_ws workspace written by a column pass without / with the extra stage
 #define LF_FMT_WS_SPLIT1 3
 void lf_fmt_note(const void *p, size_t bytes, int fmt);
+void lf_fmt_epoch_bump();   // lf_tune changed a format knob
 int lf_fmt_expect(const void *p, size_t bytes, int fmt);   // 0, or LF_ERR_STATE
 
 static inline int lf_set_device(int device) {

@@ -129,12 +129,20 @@ struct FmtRange {
     uintptr_t lo, hi;
     int fmt;
     unsigned long long age;
+    unsigned epoch;   // lf_tune generation the range was written under
 };
 std::mutex g_fmt_mutex;
 FmtRange g_fmt[256];
 int g_fmt_n = 0;
 unsigned long long g_fmt_clock = 0;
+unsigned g_fmt_epoch = 0;
 }  // namespace
+
+// lf_tune changed a format knob: ranges noted before are now "written under another setting"
+void lf_fmt_epoch_bump() {
+    std::lock_guard<std::mutex> lock(g_fmt_mutex);
+    ++g_fmt_epoch;
+}
 
 void lf_fmt_note(const void *p, size_t bytes, int fmt) {
     if (!p || !bytes) return;
@@ -164,15 +172,17 @@ void lf_fmt_note(const void *p, size_t bytes, int fmt) {
             if (g_fmt[i].age < g_fmt[o].age) o = i;
         g_fmt[o] = g_fmt[--g_fmt_n];
     }
-    g_fmt[g_fmt_n++] = FmtRange{lo, hi, fmt, ++g_fmt_clock};
+    g_fmt[g_fmt_n++] = FmtRange{lo, hi, fmt, ++g_fmt_clock, g_fmt_epoch};
 }
 
 int lf_fmt_expect(const void *p, size_t bytes, int fmt) {
     if (!p || !bytes) return 0;
     const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
     std::lock_guard<std::mutex> lock(g_fmt_mutex);
+    // a mismatching note made under the CURRENT knob setting is not this hazard: it is a stale note on memory the caller's
+    // allocator has recycled (nobody unregisters a freed buffer), or a caller that passes explicit format flags and owns them
     for (int i = 0; i < g_fmt_n; ++i)
-        if (g_fmt[i].hi > lo && g_fmt[i].lo < hi && g_fmt[i].fmt != fmt) return LF_ERR_STATE;
+        if (g_fmt[i].hi > lo && g_fmt[i].lo < hi && g_fmt[i].fmt != fmt && g_fmt[i].epoch != g_fmt_epoch) return LF_ERR_STATE;
     return 0;
 }
 

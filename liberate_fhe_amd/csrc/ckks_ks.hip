@@ -905,6 +905,8 @@ int lf_tune(int which, int value) {
     if (which == LF_TUNE_KS_EXT_COLS_MAX && value > 5) return old;
     if (which == LF_TUNE_MORE_PLANES && value > 3) return old;
     if ((which == LF_TUNE_INTT_DIGITS || which == LF_TUNE_DIGIT_PLANES || which == LF_TUNE_WS_EXTRA_STAGE) && value > 1) return old;
+    if (*knob != value && (which == LF_TUNE_DIGIT_PLANES || which == LF_TUNE_WS_EXTRA_STAGE || which == LF_TUNE_MORE_PLANES))
+        lf_fmt_epoch_bump();   // scratch written so far was written under another format setting
     *knob = value;
     return old;
 }
