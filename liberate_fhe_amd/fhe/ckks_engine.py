@@ -597,6 +597,8 @@ class ckks_engine(EvaluatorOps):
         another engine) is an error raised by torch.  Returns the bytes freed.  In-place edits of a compact key are not seen."""
         if not self._planes_wanted():
             raise ValueError("compact_key: this engine's key switch reads raw key words (logN <= 12 or a checker backend)")
+        if ksk.origin == types.origins["galk"]:          # a Galois key = one rotation key per power of two: each of them
+            return sum(self.compact_key(k) for k in ksk.data)
         hit = self._key_packs.get(id(self._key_anchor(ksk)))
         if hit is None or hit["ref"]() is not self._key_anchor(ksk) or not hit.get("own"):
             raise ValueError("compact_key: not a key made by this engine (a foreign key's tensors are the caller's)")
@@ -615,6 +617,10 @@ class ckks_engine(EvaluatorOps):
         """Undo compact_key(): the raw pack is allocated again and filled from the planes copy — integer-class rows word for word,
         fp64-class rows with the CANONICAL residues of the words they held (a key's words are lazy Montgomery words, the planes keep
         their residues: the same key, every key switch the same words; byte-identical to the original only on integer-class rows)."""
+        if ksk.origin == types.origins["galk"]:
+            for k in ksk.data:
+                self.expand_key(k)
+            return
         hit = self._key_packs.get(id(self._key_anchor(ksk)))
         if hit is None or not hit.get("compact"):
             return

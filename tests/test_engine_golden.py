@@ -166,6 +166,94 @@ def test_balanced_limb_map_decrypts_at_every_level():
 
 
 @pytest.mark.gpu
+def test_ops_of_one_engine_alternating_between_two_streams_are_ordered_not_raced():
+    """The engine's scratch (digits, sums, operand stack, plan workspaces) is per engine and lane, not per stream.  An op that
+    arrives on another current stream than the lane's previous op makes its stream wait for the previous one (_same_stream): 40
+    ops alternating between two streams with no synchronisation in between give the single-stream words."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    eng = ckks_engine(devices=["cuda:0"], **GOLD["silver"]["params"])
+    a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
+    evk, rotk = synth.key_switch_key(eng, 5), synth.key_switch_key(eng, 6, origin="rotation key:1")
+    want_m, want_r = eng.cc_mult(a, b, evk), eng.rotate_single(a, rotk)
+    want_b = eng.rotate_single_batch([a, b, a, b, a], rotk)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    got = []
+    for i in range(20):
+        with torch.cuda.stream(s1):
+            got.append(("m", eng.cc_mult(a, b, evk)))
+        with torch.cuda.stream(s2):
+            got.append(("r", eng.rotate_single(a, rotk)))
+        if i % 7 == 3:
+            with torch.cuda.stream(s1):
+                got.append(("b", eng.rotate_single_batch([a, b, a, b, a], rotk)))
+    torch.cuda.synchronize()
+    for kind, ct in got:
+        if kind == "b":
+            for x, y in zip(ct, want_b):
+                assert torch.equal(x.data[0][0], y.data[0][0]) and torch.equal(x.data[1][0], y.data[1][0])
+            continue
+        w = want_m if kind == "m" else want_r
+        assert torch.equal(ct.data[0][0], w.data[0][0]) and torch.equal(ct.data[1][0], w.data[1][0]), kind
+
+
+@pytest.mark.gpu
+def test_compact_key_halves_a_keys_memory_and_changes_no_result():
+    """engine.compact_key(): the raw pack of a key the engine made is freed (the fused key switch reads the planes copy only);
+    expand_key() restores it from the planes — integer-class rows byte for byte, fp64-class rows as the canonical residues of the
+    lazy words they held.  Same cc_mult / rotate words before, while compact, and after."""
+    from liberate_fhe_amd.fhe import ckks_engine
+    eng = ckks_engine(devices=["cuda:0"], **GOLD["silver"]["params"])
+    sk = eng.create_secret_key()
+    evk = eng.create_evk(sk)
+    rotk = eng.create_rotation_key(sk, 1)
+    a, b = synth.ciphertext(eng, 3, 0), synth.ciphertext(eng, 4, 0)
+    want = [eng.cc_mult(a, b, evk), eng.rotate_single(a, rotk)]
+    raw = [part.data[c][0].clone() for part in evk.data for c in range(2)]
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    freed = eng.compact_key(evk)
+    pack_bytes = len(evk.data) * 2 * evk.data[0].data[0][0].size(0) * eng.ctx.N * 8
+    assert freed == pack_bytes and eng.compact_key(evk) == 0
+    assert before - torch.cuda.memory_allocated() >= freed - (4 << 20)
+    for _ in range(2):
+        got = [eng.cc_mult(a, b, evk), eng.rotate_single(a, rotk)]
+        for g, w in zip(got, want):
+            assert torch.equal(g.data[0][0], w.data[0][0]) and torch.equal(g.data[1][0], w.data[1][0])
+    eng.expand_key(evk)
+    q = [eng.ctx.q[i] for i in eng.ntt.p.d_special[0]]
+    k = 0
+    for part in evk.data:
+        for c in range(2):
+            now, old = part.data[c][0], raw[k]
+            k += 1
+            for r, qr in enumerate(q):
+                if qr >= (1 << 41):
+                    assert torch.equal(now[r], old[r])
+                else:
+                    assert bool(((now[r] >= 0) & (now[r] < qr)).all()) and bool((((old[r] - now[r]) % qr) == 0).all())
+    got = eng.cc_mult(a, b, evk)
+    assert torch.equal(got.data[0][0], want[0].data[0][0]) and torch.equal(got.data[1][0], want[0].data[1][0])
+    eng.compact_key(evk)
+    eng.release_key(evk)                              # the planes are a compact key's only copy: the raw words come back first
+    got = eng.cc_mult(a, b, evk)
+    assert torch.equal(got.data[0][0], want[0].data[0][0])
+    # a Galois key set: every rotation key of it
+    galk = eng._new([eng.create_rotation_key(sk, d) for d in (1, 2)], "galois key", include_special=True, ntt_state=True, montgomery_state=True)
+    r_before = eng.rotate_single(a, galk.data[1])
+    assert eng.compact_key(galk) == 2 * pack_bytes
+    assert torch.equal(eng.rotate_single(a, galk.data[1]).data[1][0], r_before.data[1][0])
+    eng.expand_key(galk)
+    assert torch.equal(eng.rotate_single(a, galk.data[1]).data[1][0], r_before.data[1][0])
+    # a key whose tensors are the caller's (here: clones of the parts) is never touched
+    foreign = evk._replace(data=[part._replace(data=([t.clone() for t in part.data[0]], [t.clone() for t in part.data[1]])) for part in evk.data])
+    got = eng.cc_mult(a, b, foreign)
+    assert torch.equal(got.data[0][0], want[0].data[0][0])
+    with pytest.raises(ValueError):
+        eng.compact_key(foreign)
+
+
+@pytest.mark.gpu
 def test_hip_gold_eight_logical_devices_equal_one_device():
     """BASELINE configs[3]'s partition (rns_partition(35, 4, 8): 11 / 8 / .. / 8 rows with the special limbs, digit
     exchange between 8 shards) against the undivided engine, row by row in prime order, at level 0 and across the
