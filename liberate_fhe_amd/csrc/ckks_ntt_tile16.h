@@ -984,6 +984,123 @@ __global__ void __launch_bounds__(NTT16_THREADS, 4) ntt_pass16_fwd_seq(i64 *dst,
     else seq16_loop<true, RLX>(sm, dst, g, cl.dp, vb0 - cl.in_blocks, total - cl.in_blocks, tpb, tw_br, tw_dp, ql, qh, kl, kh);
 }
 
+// ---- the same tile with its NEXT tile's words requested early (seq16_loop_ws) ------------------------------------------------
+// A block walks 8 tiles; the loads of tile i + 1 are issued when tile i's results have gone to the LDS staging span (its 32
+// result registers are dead from there on) and fly while the wave reads the span back, stores the tile and sets up the next
+// one.  The words stay UNASSEMBLED in their registers (an OR on arrival would put the wait right behind the loads): fp64 class
+// low / mid planes (16 + 16 registers), integer class raw words.  A flagged wave (third plane, rare) reloads the slow way.
+template <bool DP> struct TilePf;
+template <> struct TilePf<true> {
+    unsigned lo[16], mid[16];
+};
+template <> struct TilePf<false> {
+    i64 raw[16];
+};
+
+template <bool DP, bool SKIP0>
+__device__ __forceinline__ bool ws_prefetch_tile(const i64 *__restrict__ srow, const unsigned char *__restrict__ wf, int base, int E, int w,
+                                                 TilePf<DP> &pf) {
+    const int wave = __builtin_amdgcn_readfirstlane(w >> 6);
+    const u64 *fp = reinterpret_cast<const u64 *>(wf + (wave << 4));
+    const u64 fl = fp[0], fh = SKIP0 ? fp[0] : fp[1];
+    if constexpr (DP) {
+        const unsigned *lo = reinterpret_cast<const unsigned *>(srow) + base;
+        const unsigned short *mid = reinterpret_cast<const unsigned short *>(srow + ((i64)1 << (E - 1))) + base;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            pf.lo[e] = __builtin_nontemporal_load(uniform_ptr(lo + (e << 8)) + (unsigned)w);
+            pf.mid[e] = __builtin_nontemporal_load(uniform_ptr(mid + (e << 8)) + (unsigned)w);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pf.raw[e] = __builtin_nontemporal_load(uniform_ptr(srow + base + (e << 8)) + (unsigned)w);
+    }
+    return (fl | fh) != 0;
+}
+
+// cur / cur_flagged: this tile's words as ws_prefetch_tile left them; next_*: where the block's next tile is (ntile < 0: none)
+template <bool DP, bool SKIP0>
+__device__ __forceinline__ void fwd_tile16_ws_pf(i64 *sm, TilePf<DP> &pf, bool &pf_flagged, const i64 *__restrict__ srow,
+                                                  const unsigned char *__restrict__ wf, i64 *__restrict__ row, int tile,
+                                                  const PassGeom &g, const Ctx &c, const Tw16Last<typename FwdArith<DP, false>::type> *lastC,
+                                                  const i64 *__restrict__ nsrow, const unsigned char *__restrict__ nwf, int ntile) {
+    const int w = lf_tid();
+    const int base = tile << 12, E = g.logN, s = g.s0;
+    i64 raw[16];
+    const bool flagged = pf_flagged;
+    if (flagged) {
+        ws_load_tile<DP, SKIP0>(srow, wf, base, E, w, raw);   // third plane behind a raised flag: the complete load
+    } else if constexpr (DP) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) raw[e] = (i64)(((u64)pf.mid[e] << 32) | (u64)pf.lo[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) raw[e] = pf.raw[e];
+    }
+    {
+        int odd = 0;
+        if (flagged) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) odd |= ((u64)raw[e] >= (u64)c.m.q2);
+        }
+        wave_flag_set16(sm, odd, w);
+    }
+    i64 o[16];
+    bool ok;
+    if constexpr (DP) {
+        double x[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[e] = dp_from_word(raw[e]);
+        ok = fwd_tile16_steps<ArithDp, true, false, SKIP0 ? 1 : 0>(reinterpret_cast<double *>(sm), sm, x, w, base, E, s, c, true, lastC);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = dp_to_word(dp_reduce(x[e], c.d.q2, c.d.q2inv));
+    } else {
+        ok = fwd_tile16_steps<ArithInt<false>, false, false, SKIP0 ? 1 : 0>(sm, sm, raw, w, base, E, s, c, true, lastC);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = raw[e];
+    }
+    if (!ok) {   // a word outside [0, 2q): nothing has been stored yet; the raw words once more, into LDS, then the generic tile
+        __syncthreads();
+        ws_load_tile<DP, SKIP0>(srow, wf, base, E, w, raw);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sm[PAD16(w + (e << 8))] = raw[e];
+        __syncthreads();
+        tile16_slow_lds(sm, row + base, base, s, E, false, c, SKIP0 ? 1 : 0);
+        if (ntile >= 0) pf_flagged = ws_prefetch_tile<DP, SKIP0>(nsrow, nwf, ntile << 12, E, w, pf);
+        else pf = TilePf<DP>{};
+        return;
+    }
+
+    {
+        i64 *sp = sm + 17 * w;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sp[e] = o[e];
+    }
+    // the next tile's words, requested once this tile's results sit in the staging span (their 32 registers are dead from here
+    // on; requested right behind the register steps instead, 25 .. 29 registers spill).  A scheduling fence on both sides: hoisted
+    // into the steps — the kernel's pressure peak — the prefetch registers would spill; defined on every path: left as they
+    // were, the OLD words would stay live across the steps.
+    __builtin_amdgcn_sched_barrier(0);
+    if (ntile >= 0) pf_flagged = ws_prefetch_tile<DP, SKIP0>(nsrow, nwf, ntile << 12, E, w, pf);
+    else pf = TilePf<DP>{};
+    __builtin_amdgcn_sched_barrier(0);
+    wave_lds_sync();
+    const int L0 = ((w >> 6) << 10) + ((w & 63) << 1);
+    const i64 *so = sm + PAD16(L0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        longlong2 v;
+        v.x = so[i * 136];
+        v.y = so[i * 136 + 1];
+        if constexpr (NT_EXACT) nt_store2(row + base + L0 + (i << 7), v);
+        else *reinterpret_cast<longlong2 *>(row + base + L0 + (i << 7)) = v;
+    }
+}
+
+#ifndef NTT16_WS_PREFETCH
+#define NTT16_WS_PREFETCH 1
+#endif
+
 // the same two kernels for a transform through a workspace (fwd_tile16_ws): ws -> dst, wflags = 64 flag bytes per (poly, limb)
 template <bool DP, bool SKIP0>
 __device__ __forceinline__ void seq16_loop_ws(i64 *sm, const i64 *ws, const unsigned char *wflags, i64 *dst, const PassGeom &g,
@@ -994,6 +1111,37 @@ __device__ __forceinline__ void seq16_loop_ws(i64 *sm, const i64 *ws, const unsi
     const int w = lf_tid();
     Tw16Last<AC> last;
     int last_crow = -1, last_tile = -1;
+#if NTT16_WS_PREFETCH
+    TilePf<DP> pf;
+    bool pf_flagged = false;
+    TileAt t = tile_at(g, rl, b0, b0 < bend);
+    if (!t.live) return;
+    {
+        const i64 ri = (i64)(t.poly * g.rows + t.crow);
+        pf_flagged = ws_prefetch_tile<DP, SKIP0>(ws + (ri << g.logN), wflags + (ri << 6), t.tile << 12, g.logN, w, pf);
+    }
+    for (int i = 0; i < tpb; ++i) {
+        const int bn = b0 + 8 * (i + 1);
+        TileAt tn = tile_at(g, rl, bn, i + 1 < tpb && bn < bend);
+        Ctx c;
+        c.m = load_mod(ql, qh, kl, kh, t.crow);
+        c.tw_mont = tw_br + ((i64)t.crow << g.logN);
+        set_aux<DP>(c, tw_dp, t.crow, g.logN);
+        c.d = DP ? make_dp_tab(c.m, c.tw_dp) : make_dp(c.m);
+        c.relaxed = 0;
+        c.inv_reduce = 0;
+        if (t.crow != last_crow || t.tile != last_tile) {
+            last.load(c, (1 << (g.s0 + 8)) + (((t.tile << 12) + 16 * w) >> (g.logN - g.s0 - 8)));
+            last_crow = t.crow, last_tile = t.tile;
+        }
+        if (i) lds_barrier();
+        const i64 ri = (i64)(t.poly * g.rows + t.crow), rn = (i64)(tn.poly * g.rows + tn.crow);
+        fwd_tile16_ws_pf<DP, SKIP0>(sm, pf, pf_flagged, ws + (ri << g.logN), wflags + (ri << 6), dst + (ri << g.logN), t.tile, g, c, &last,
+                                    ws + (rn << g.logN), wflags + (rn << 6), tn.live ? tn.tile : -1);
+        if (!tn.live) break;
+        t = tn;
+    }
+#else
     for (int i = 0; i < tpb; ++i) {
         const int b = b0 + 8 * i;
         const TileAt t = tile_at(g, rl, b, b < bend);
@@ -1013,6 +1161,7 @@ __device__ __forceinline__ void seq16_loop_ws(i64 *sm, const i64 *ws, const unsi
         const i64 ri = (i64)(t.poly * g.rows + t.crow);
         fwd_tile16_ws<DP, SKIP0>(sm, ws + (ri << g.logN), wflags + (ri << 6), dst + (ri << g.logN), t.tile, g, c, &last);
     }
+#endif
 }
 
 template <bool SKIP0>
