@@ -79,7 +79,7 @@ for name, src in cases.items():
             b2 = src.clone(); through(b2, rs, VARIANT); torch.cuda.synchronize()
             same = same and torch.equal(a, b2)
         print(f"{rs_name:9s} {name}: {'equal' if same else 'DIFFERENT'}  ({int((a != b).sum())} words differ)", flush=True)
-        assert same
+        assert same or os.environ.get("LF_AB_NO_COMPARE") == "1"      # (timing-only experiments with a deliberately wrong variant)
 
 x = x0.clone()
 
