@@ -177,7 +177,35 @@ def test_lf_tune_is_a_pure_host_call():
     assert lib.lf_tune(1, 9) == cols and lib.lf_tune(1, -1) == cols      # out of range: ignored
     assert lib.lf_tune(3, -1) == 1 and lib.lf_tune(3, 5) == 1     # digit planes: on by default; out of range: ignored
     assert lib.lf_tune(4, -1) == 1 and lib.lf_tune(4, 7) == 1     # extra column stage of lf_ntt_ws: on; out of range: ignored
+    assert lib.lf_tune(5, -1) == 3 and lib.lf_tune(5, 9) == 3     # planes for the sums (bit 0) and the operand stack (bit 1): on
     assert lib.lf_tune(77, 1) == -1
+
+
+def test_stack_planes_query_follows_the_primes_and_the_knobs():
+    """lf_stack_planes (pure host): internal stacks keep fp64-class rows as 6-byte planes at two-pass ring degrees when the rows
+    hold primes of BOTH classes and lf_tune's LF_TUNE_DIGIT_PLANES / LF_TUNE_MORE_PLANES (bit 1) say so."""
+    import numpy as np
+    from liberate_fhe_amd._native import lib
+    small, large = (1 << 40) + 12345, (1 << 60) - 93
+    mixed = np.array([small, small + 2, large], dtype=np.int64)
+    only_small = np.array([small, small + 2], dtype=np.int64)
+    only_large = np.array([large], dtype=np.int64)
+    q = lambda a: a.ctypes.data
+    assert lib.lf_stack_planes(16, 3, q(mixed)) == 1 and lib.lf_stack_planes(13, 3, q(mixed)) == 1
+    assert lib.lf_stack_planes(12, 3, q(mixed)) == 0                      # one-pass ring degree: no stack crosses HBM twice
+    assert lib.lf_stack_planes(16, 2, q(mixed)) == 0                      # the first two rows only: one class
+    assert lib.lf_stack_planes(16, 2, q(only_small)) == 0 and lib.lf_stack_planes(16, 1, q(only_large)) == 0
+    assert lib.lf_stack_planes(16, 3, None) == 0
+    try:
+        lib.lf_tune(5, 1)
+        assert lib.lf_stack_planes(16, 3, q(mixed)) == 0
+        lib.lf_tune(5, 3)
+        lib.lf_tune(3, 0)
+        assert lib.lf_stack_planes(16, 3, q(mixed)) == 0
+    finally:
+        lib.lf_tune(3, 1)
+        lib.lf_tune(5, 3)
+    assert lib.lf_stack_planes(16, 3, q(mixed)) == 1
 
 
 def test_clock_probe_checks_its_arguments_on_the_host():
